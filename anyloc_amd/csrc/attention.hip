@@ -1,0 +1,165 @@
+// Multi-head self-attention, fp32, head_dim 64, flash-style (scores never leave
+// registers).  Replaces the attention of every DINOv2 block executed by the
+// hub model forward the reference triggers at utilities.py:269
+// (facebookresearch/dinov2 layers/attention.py: softmax((q*64^-0.5) k^T) v).
+//
+// Design (CDNA4): one wave owns 32 queries; a 256-thread block = 4 waves = 128
+// queries of one (image, head) and shares K/V tiles of 32 keys staged in LDS
+// (double-buffered, register-prefetched).  The score block is computed
+// TRANSPOSED, S^T = K_tile * Q^T, with v_mfma_f32_32x32x2_f32, so that in the
+// MFMA C/D layout (col = lane&31 = query, rows = keys in registers) each lane
+// holds 16 keys of ONE query: the online-softmax max/sum are in-register plus
+// one lane^32 exchange, the running rescale of O^T is a per-lane scalar, and
+// the probabilities are already in B-operand layout for O^T += V^T * P^T.
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+constexpr int HD = 64;        // head dim
+constexpr int KT = 32;        // keys per tile
+constexpr int KLD = HD + 4;   // padded K row (ds_read_b128 conflict-free)
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int T, int D, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[2][KT][KLD];
+  __shared__ __attribute__((aligned(16))) float Vs[2][KT][HD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t ld = 3 * (int64_t)D;
+  const float* base = qkv + b * T * ld;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, h2 = lane >> 5;
+  const bool wave_active = q0 < T;
+
+  // ---- Q fragment (B operand): lane holds Q[q][8s + 4*h2 + j] * scale ----
+  f32x4 qf[8];
+  {
+    const int qr = min(q0 + ql, T - 1);
+    const float* qp = base + (int64_t)qr * ld + h * HD + 4 * h2;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(qp + 8 * s);
+      v[0] *= scale; v[1] *= scale; v[2] *= scale; v[3] *= scale;
+      qf[s] = v;
+    }
+  }
+
+  // ---- K/V staging: 16 lanes cover one 256-byte head row ----
+  const int sr = tid >> 4, sc = tid & 15;
+  f32x4 rk[2], rv[2];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = min(kt * KT + sr + 16 * i, T - 1);
+      const float* p = base + (int64_t)key * ld + h * HD + 4 * sc;
+      rk[i] = *reinterpret_cast<const f32x4*>(p + D);
+      rv[i] = *reinterpret_cast<const f32x4*>(p + 2 * D);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&Ks[buf][sr + 16 * i][4 * sc]) = rk[i];
+      *reinterpret_cast<f32x4*>(&Vs[buf][sr + 16 * i][4 * sc]) = rv[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (T + KT - 1) / KT;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) fetch(kt + 1);
+    if (wave_active) {
+      // S^T = K_tile (A: rows = keys) x Q^T (B: cols = queries)
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const float* kp = &Ks[buf][ql][4 * h2];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[s][j], sacc, 0, 0, 0);
+      }
+      // lane (ql, h2) now holds S[q = q0+ql][key = kt*32 + (r&3) + 8*(r>>2) + 4*h2]
+      const int kbase = kt * KT + 4 * h2;
+      if (kbase + 28 + 3 >= T) {   // tile reaches past the last key: mask
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + (r & 3) + 8 * (r >> 2) >= T) sacc[r] = -INFINITY;
+      }
+      float mloc = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = expf(m_run - m_new);
+      float lsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = expf(sacc[r] - m_new);
+        lsum += sacc[r];
+      }
+      lsum += __shfl_xor(lsum, 32, 64);
+      l_run = l_run * alpha + lsum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+      // O^T[d][q] += sum_key V[key][d] * P[q][key]:  A = V^T (rows = d), B = P^T (sacc)
+      const float* vp = &Vs[buf][4 * h2][ql];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int krow = (r & 3) + 8 * (r >> 2);
+        const float v0 = vp[krow * HD], v1 = vp[krow * HD + 32];
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], oacc[1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // oacc[db][r] = O[q0+ql][db*32 + (r&3) + 8*(r>>2) + 4*h2]  ->  float4 per (db, r>>2)
+  if (wave_active && q0 + ql < T) {
+    const float inv = 1.0f / l_run;
+    float* op = out + (b * T + q0 + ql) * (int64_t)D + h * HD + 4 * h2;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = oacc[db][4 * g + 0] * inv;
+        v[1] = oacc[db][4 * g + 1] * inv;
+        v[2] = oacc[db][4 * g + 2] * inv;
+        v[3] = oacc[db][4 * g + 3] * inv;
+        *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g) = v;
+      }
+  }
+}
+
+}  // namespace
+
+// qkv [B*T, 3D] (q | k | v, each head-major 64-wide), out [B*T, D]
+int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(D == heads * HD, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
+  ANYLOC_CHECK_ARG(T > 0 && batch > 0 && batch < 65536, "attention: bad T/batch");
+  const double flops = 4.0 * (double)batch * heads * (double)T * T * HD;
+  ProfScope prof("attention", stream, flops, 16.0 * batch * T * D);
+  hipLaunchKernelGGL(attention_kernel, dim3((T + 127) / 128, heads, (unsigned)batch), dim3(256), 0, stream, qkv, out,
+                     T, D, 1.0f / 8.0f);
+  return launch_status("attention_kernel");
+}
+
+}  // namespace anyloc

@@ -1,0 +1,119 @@
+// Shared host/device helpers for libanyloc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/anyloc_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace anyloc {
+
+// ---- error reporting (thread-local, never throws across the ABI) ----------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define ANYLOC_CHECK_ARG(cond, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::anyloc::set_error(__VA_ARGS__);        \
+      return ANYLOC_ERR_INVALID_ARG;           \
+    }                                          \
+  } while (0)
+
+#define ANYLOC_HIP(call)                                   \
+  do {                                                     \
+    hipError_t e__ = (call);                               \
+    if (e__ != hipSuccess) return ::anyloc::hip_fail(e__, #call); \
+  } while (0)
+
+#define ANYLOC_TRY(call)        \
+  do {                          \
+    int s__ = (call);           \
+    if (s__ != ANYLOC_OK) return s__; \
+  } while (0)
+
+// ---- per-kernel profiling with HIP events on the launch stream ------------
+// A Scope brackets one kernel launch; when profiling is off it costs one branch.
+struct ProfScope {
+  int slot;
+  hipStream_t stream;
+  ProfScope(const char* name, hipStream_t s, double flops, double bytes);
+  ~ProfScope();
+};
+
+int launch_status(const char* what);
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Arena {
+  char* base;
+  size_t cap, off;
+  Arena(void* p, size_t n) : base(static_cast<char*>(p)), cap(n), off(0) {}
+  template <class T>
+  T* take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T), 256);
+    T* r = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+// ---- device helpers --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- internal kernels shared between translation units ---------------------
+enum GemmEpilogue {
+  EPI_STORE = 0,      // C = acc (+ bias)
+  EPI_GELU = 1,       // C = gelu_erf(acc + bias)
+  EPI_LS_RESID = 2,   // C = resid + gamma * (acc + bias)        (C may alias resid)
+  EPI_SWIGLU = 3,     // C[:, n/2] = silu(acc_gate + b) * (acc_val + b), rows pair-interleaved
+  EPI_PATCH = 4       // C[b*T + 1 + p, :] = acc + bias + pos[1 + p, :]
+};
+
+struct GemmProblem {
+  const float* A; int64_t lda;
+  const float* W; int64_t ldw;
+  float* C; int64_t ldc;
+  int64_t M, N, K;
+  const float* bias;     // [N] or null
+  const float* gamma;    // EPI_LS_RESID
+  const float* resid;    // EPI_LS_RESID, leading dim ldc
+  const float* pos;      // EPI_PATCH: [T, N]
+  int patches;           // EPI_PATCH: patches per image (T = patches + 1)
+  float* rowsq;          // optional: rowsq[m] = sum_k A[m,k]^2 (written by the n-block 0 column)
+  const char* tag;       // profiling label
+};
+int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream);
+
+int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
+                int64_t dim, float eps, hipStream_t stream);
+int layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int dim,
+              float eps, hipStream_t stream);
+int im2col(const float* img, float* col, int64_t batch, int H, int W, int P, int kpad,
+           hipStream_t stream);
+int cls_rows(float* x, const float* cls, const float* pos, int64_t batch, int T, int dim,
+             hipStream_t stream);
+int facet_rows(const float* src, int64_t lds_, int coff, float* out, int64_t ldo, int ooff,
+               int64_t batch, int T, int skip, int rows_per_img, int dim, int normalize, float eps,
+               hipStream_t stream);
+int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads,
+              hipStream_t stream);
+
+}  // namespace anyloc

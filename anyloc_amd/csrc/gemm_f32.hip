@@ -1,0 +1,293 @@
+// fp32 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  with fused epilogues.
+//
+// Every dense contraction of the hot path runs on this kernel: the ViT's
+// patch-embed / QKV / attention-out / MLP projections (reference: the hub
+// model forward triggered at utilities.py:269), the VLAD and k-means cosine
+// scores (fast-pytorch-kmeans max_sim reached from utilities.py:786,:849) and
+// the retrieval inner products (faiss IndexFlatIP.search, utilities.py:450).
+//
+// Design (CDNA4, wave64):
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain) at 64
+//     FLOP/clk/SIMD = 157.3 TFLOP/s chip peak -- the governing roofline.
+//   * block tile BM x BN x 32, 4 waves; each wave owns (BM/WM) x (BN/WN) as
+//     32x32 MFMA blocks held in accumulator registers.
+//   * both operands are K-contiguous (torch Linear layout).  Global -> register
+//     -> LDS staging with coalesced 128-byte row segments (8 lanes x float4);
+//     loads of K-slab t+1 are issued before the MFMAs of slab t and written to
+//     the other LDS buffer afterwards (one barrier per slab).
+//   * LDS rows are padded to 36 floats: the per-lane ds_read_b128 fragment
+//     reads (row = lane&31, 16-byte column = lane>>5) hit 16 distinct 16-byte
+//     slots per 16-lane group -> conflict-free.
+//   * k-permutation: a lane's float4 holds k = 8s + 4*(lane>>5) + j, and MFMA
+//     number j consumes element j of both operands, so A and W see the same k
+//     in the same lane half; every k is consumed exactly once.
+//   * block id -> tile: XCD-aware (block b runs on XCD b % 8, each XCD has a
+//     private 4 MiB L2) + grouped ordering so co-resident blocks of one XCD
+//     share A row-panels and W column-panels.
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nb = tiles_m * tiles_n;
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  constexpr int GM = 8;
+  const int group_size = GM * tiles_n;
+  const int g = logical / group_size;
+  const int first_m = g * GM;
+  const int gm = min(tiles_m - first_m, GM);
+  const int within = logical - g * group_size;
+  tm = first_m + within % gm;
+  tn = within / gm;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {
+  return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
+
+template <int BM, int BN, int WM, int WN, int EPI, bool ROWSQ>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tiles_m, int tiles_n) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int A_LD4 = BM / 32;  // float4 per thread per K-slab (BM*BK/4/256)
+  constexpr int W_LD4 = BN / 32;
+  static_assert(WM * WN == 4, "4 waves per block");
+  static_assert(EPI != EPI_SWIGLU || NI == 2, "swiglu pairs the two 32-col blocks of a wave");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][BM][LDS_LD]
+  float* Ws = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int tile_m, tile_n;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+
+  // ---- staging coordinates: 8 lanes cover one 128-byte row segment ----
+  const int kq = tid & 7, r0 = tid >> 3;
+  const float* a_src[A_LD4];
+  const float* w_src[W_LD4];
+#pragma unroll
+  for (int i = 0; i < A_LD4; ++i) {
+    int64_t row = m0 + r0 + 32 * i;
+    row = row < p.M ? row : p.M - 1;
+    a_src[i] = p.A + row * p.lda + 4 * kq;
+  }
+#pragma unroll
+  for (int i = 0; i < W_LD4; ++i) {
+    int64_t row = n0 + r0 + 32 * i;
+    row = row < p.N ? row : p.N - 1;
+    w_src[i] = p.W + row * p.ldw + 4 * kq;
+  }
+  const int st_off = r0 * LDS_LD + 4 * kq;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  float rsq[A_LD4];
+#pragma unroll
+  for (int i = 0; i < A_LD4; ++i) rsq[i] = 0.0f;
+
+  const int nk = (int)((p.K + BK - 1) / BK);
+  f32x4 ra[A_LD4], rw[W_LD4];
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  auto fetch = [&](int kt) {
+    const int64_t k = (int64_t)kt * BK;
+    const bool ok = (k + 4 * kq) < p.K;   // K % 4 == 0: a float4 is all-in or all-out
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_src[i] + k) : zero4;
+#pragma unroll
+    for (int i = 0; i < W_LD4; ++i) rw[i] = ok ? *reinterpret_cast<const f32x4*>(w_src[i] + k) : zero4;
+  };
+  auto stash = [&](int buf) {
+    float* ad = As + buf * BM * LDS_LD + st_off;
+    float* wd = Ws + buf * BN * LDS_LD + st_off;
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) {
+      *reinterpret_cast<f32x4*>(ad + 32 * i * LDS_LD) = ra[i];
+      if (ROWSQ) rsq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD4; ++i) *reinterpret_cast<f32x4*>(wd + 32 * i * LDS_LD) = rw[i];
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) fetch(kt + 1);
+    const float* Ab = As + buf * BM * LDS_LD + wm * TM * LDS_LD + frag_off;
+    const float* Wb = Ws + buf * BN * LDS_LD + wn * TN * LDS_LD + frag_off;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      f32x4 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDS_LD + 8 * s);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(Wb + ni * 32 * LDS_LD + 8 * s);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (ROWSQ) {
+    if (tile_n == 0) {
+#pragma unroll
+      for (int i = 0; i < A_LD4; ++i) {
+        float v = rsq[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        const int64_t row = m0 + r0 + 32 * i;
+        if (kq == 0 && row < p.M) p.rowsq[row] = v;
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA:
+  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 ----
+  const int64_t wrow0 = m0 + wm * TM + 4 * (lane >> 5);
+  const int64_t wcol0 = n0 + wn * TN + (lane & 31);
+  if constexpr (EPI == EPI_SWIGLU) {
+    const int64_t colg = wcol0, colv = wcol0 + 32;
+    const int64_t ocol = (n0 + wn * TN) / 2 + (lane & 31);
+    const bool cok = colv < p.N;
+    const float bg = (cok && p.bias) ? p.bias[colg] : 0.0f;
+    const float bv = (cok && p.bias) ? p.bias[colv] : 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M && cok) {
+          const float g = acc[mi][0][r] + bg, v = acc[mi][1][r] + bv;
+          p.C[row * p.ldc + ocol] = silu(g) * v;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t col = wcol0 + ni * 32;
+      const bool cok = col < p.N;
+      const float b = (cok && p.bias) ? p.bias[col] : 0.0f;
+      float gam = 0.0f;
+      if constexpr (EPI == EPI_LS_RESID) gam = cok ? p.gamma[col] : 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+          if (row < p.M && cok) {
+            float v = acc[mi][ni][r] + b;
+            if constexpr (EPI == EPI_STORE) {
+              p.C[row * p.ldc + col] = v;
+            } else if constexpr (EPI == EPI_GELU) {
+              p.C[row * p.ldc + col] = gelu_erf(v);
+            } else if constexpr (EPI == EPI_LS_RESID) {
+              const int64_t o = row * p.ldc + col;
+              p.C[o] = p.resid[o] + v * gam;
+            } else if constexpr (EPI == EPI_PATCH) {
+              const int64_t img = row / p.patches, pi = row - img * p.patches;
+              const int64_t orow = img * (p.patches + 1) + 1 + pi;
+              p.C[orow * p.ldc + col] = v + p.pos[(1 + pi) * p.N + col];
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, bool ROWSQ>
+int launch(const GemmProblem& p, hipStream_t stream) {
+  const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI, ROWSQ>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+  const double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+  ProfScope prof(p.tag ? p.tag : "gemm_nt", stream, flops, bytes);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, p, tiles_m, tiles_n);
+  return launch_status("gemm_nt_kernel");
+}
+
+}  // namespace
+
+int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(p.A && p.W && p.C, "gemm_nt: null operand");
+  ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%lld N=%lld K=%lld",
+                   (long long)p.M, (long long)p.N, (long long)p.K);
+  ANYLOC_CHECK_ARG(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
+                   "gemm_nt: K, lda, ldw must be multiples of 4 (K=%lld lda=%lld ldw=%lld)",
+                   (long long)p.K, (long long)p.lda, (long long)p.ldw);
+  ANYLOC_CHECK_ARG((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0,
+                   "gemm_nt: operands must be 16-byte aligned");
+  ANYLOC_CHECK_ARG((p.M + 127) / 128 * ((p.N + 31) / 32) < (1ll << 31), "gemm_nt: grid too large");
+  const bool narrow = p.N <= 32;
+  switch (epilogue) {
+    case EPI_STORE:
+      if (p.rowsq) {
+        return narrow ? launch<128, 32, 4, 1, EPI_STORE, true>(p, stream)
+                      : launch<128, 128, 2, 2, EPI_STORE, true>(p, stream);
+      }
+      return narrow ? launch<128, 32, 4, 1, EPI_STORE, false>(p, stream)
+                    : launch<128, 128, 2, 2, EPI_STORE, false>(p, stream);
+    case EPI_GELU:
+      return launch<128, 128, 2, 2, EPI_GELU, false>(p, stream);
+    case EPI_LS_RESID:
+      ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_nt: LS_RESID needs gamma and resid");
+      return launch<128, 128, 2, 2, EPI_LS_RESID, false>(p, stream);
+    case EPI_SWIGLU:
+      ANYLOC_CHECK_ARG(p.N % 64 == 0, "gemm_nt: SWIGLU needs N %% 64 == 0");
+      return launch<128, 128, 2, 2, EPI_SWIGLU, false>(p, stream);
+    case EPI_PATCH:
+      ANYLOC_CHECK_ARG(p.pos && p.patches > 0, "gemm_nt: PATCH needs pos and patches");
+      return launch<128, 128, 2, 2, EPI_PATCH, false>(p, stream);
+    default:
+      set_error("gemm_nt: unknown epilogue %d", epilogue);
+      return ANYLOC_ERR_INVALID_ARG;
+  }
+}
+
+}  // namespace anyloc
+
+extern "C" int anyloc_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
+                              int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+  anyloc::GemmProblem g{};
+  g.A = A; g.lda = lda;
+  g.W = W; g.ldw = ldw;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.bias = bias;
+  g.tag = "gemm_nt";
+  return anyloc::gemm_nt(g, anyloc::EPI_STORE, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,181 @@
+// Row-wise HBM-bound kernels: L2 normalisation, LayerNorm, patch gather (im2col),
+// CLS row, facet slice (+ F.normalize).  One 256-thread block per row, float4
+// coalesced accesses; rows are re-read from L1/L2 for the second pass.
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// out[r,:] = x[r,:] / max(||x[r,:]||, eps)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, int64_t ldx, float* out,
+                                                          int64_t ldo, int64_t dim,
+                                                          float eps) {
+  __shared__ float red[4];
+  const float* xr = x + (int64_t)blockIdx.x * ldx;
+  float* orow = out + (int64_t)blockIdx.x * ldo;
+  float ss = 0.f;
+  if ((dim & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0) {
+    const int64_t n4 = dim >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(xr)[i];
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float nrm = fmaxf(sqrtf(block_sum(ss, red)), eps);
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      f32x4 v = reinterpret_cast<const f32x4*>(xr)[i];
+      v[0] /= nrm; v[1] /= nrm; v[2] /= nrm; v[3] /= nrm;
+      reinterpret_cast<f32x4*>(orow)[i] = v;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < dim; i += 256) ss += xr[i] * xr[i];
+    const float nrm = fmaxf(sqrtf(block_sum(ss, red)), eps);
+    for (int64_t i = threadIdx.x; i < dim; i += 256) orow[i] = xr[i] / nrm;
+  }
+}
+
+// y = (x - mean) / sqrt(var + eps) * w + b      (torch LayerNorm, biased variance)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        int dim, float eps) {
+  __shared__ float red[4];
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)blockIdx.x * dim);
+  f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.x * dim);
+  const int n4 = dim >> 2;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 v = xr[i];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mean = block_sum(s, red) / (float)dim;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 v = xr[i];
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)dim + eps);
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const f32x4 v = xr[i];
+    const f32x4 wv = reinterpret_cast<const f32x4*>(w)[i], bv = reinterpret_cast<const f32x4*>(b)[i];
+    f32x4 o;
+    o[0] = (v[0] - mean) * rstd * wv[0] + bv[0];
+    o[1] = (v[1] - mean) * rstd * wv[1] + bv[1];
+    o[2] = (v[2] - mean) * rstd * wv[2] + bv[2];
+    o[3] = (v[3] - mean) * rstd * wv[3] + bv[3];
+    yr[i] = o;
+  }
+}
+
+// col[(b*Np + py*gw + px), c*P*P + i*P + j] = img[b, c, py*P + i, px*P + j]
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ col,
+                                                     int H, int W, int P, int gh, int gw, int kpad) {
+  const int64_t prow = blockIdx.x;            // b*Np + patch
+  const int np = gh * gw;
+  const int64_t b = prow / np;
+  const int pi = (int)(prow - b * np), py = pi / gw, px = pi - py * gw;
+  const int kk = 3 * P * P;
+  float* dst = col + prow * kpad;
+  for (int k = threadIdx.x; k < kpad; k += 256) {
+    float v = 0.f;
+    if (k < kk) {
+      const int c = k / (P * P), rem = k - c * P * P, i = rem / P, j = rem - i * P;
+      v = img[((b * 3 + c) * H + (py * P + i)) * (int64_t)W + (px * P + j)];
+    }
+    dst[k] = v;
+  }
+}
+
+// x[b*T, :] = cls + pos[0, :]
+__global__ __launch_bounds__(256) void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                      const float* __restrict__ pos, int T, int dim) {
+  float* dst = x + (int64_t)blockIdx.x * T * dim;
+  for (int i = threadIdx.x; i < dim; i += 256) dst[i] = cls[i] + pos[i];
+}
+
+// out[b, n, ooff + d] = src[(b*T + skip + n), coff + d]   (optionally / max(||.||, eps))
+__global__ __launch_bounds__(256) void facet_rows_kernel(const float* __restrict__ src, int64_t lds_, int coff,
+                                                         float* __restrict__ out, int64_t ldo, int ooff, int T,
+                                                         int skip, int rows_per_img, int dim, int normalize,
+                                                         float eps) {
+  __shared__ float red[4];
+  const int64_t orow = blockIdx.x;
+  const int64_t b = orow / rows_per_img;
+  const int n = (int)(orow - b * rows_per_img);
+  const f32x4* s = reinterpret_cast<const f32x4*>(src + (b * T + skip + n) * lds_ + coff);
+  f32x4* o = reinterpret_cast<f32x4*>(out + orow * ldo + ooff);
+  const int n4 = dim >> 2;
+  float nrm = 1.0f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const f32x4 v = s[i];
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    nrm = fmaxf(sqrtf(block_sum(ss, red)), eps);
+  }
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    f32x4 v = s[i];
+    if (normalize) { v[0] /= nrm; v[1] /= nrm; v[2] /= nrm; v[3] /= nrm; }
+    o[i] = v;
+  }
+}
+
+}  // namespace
+
+int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int64_t dim, float eps,
+                hipStream_t stream) {
+  if (rows == 0 || dim == 0) return ANYLOC_OK;
+  ANYLOC_CHECK_ARG(x && out, "l2norm_rows: null pointer");
+  ANYLOC_CHECK_ARG(rows < (1ll << 31), "l2norm_rows: too many rows");
+  ProfScope prof("l2norm_rows", stream, 3.0 * rows * dim, 8.0 * rows * dim);
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ldx, out, ldo, dim, eps);
+  return launch_status("l2norm_rows_kernel");
+}
+
+int layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int dim, float eps,
+              hipStream_t stream) {
+  ANYLOC_CHECK_ARG(dim % 4 == 0, "layernorm: dim %% 4 != 0");
+  ProfScope prof("layernorm", stream, 8.0 * rows * dim, 8.0 * rows * dim);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, y, w, b, dim, eps);
+  return launch_status("layernorm_kernel");
+}
+
+int im2col(const float* img, float* col, int64_t batch, int H, int W, int P, int kpad, hipStream_t stream) {
+  const int gh = H / P, gw = W / P;
+  ProfScope prof("im2col", stream, 0.0, 4.0 * batch * (3.0 * H * W + (double)gh * gw * kpad));
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)(batch * gh * gw)), dim3(256), 0, stream, img, col, H, W, P, gh,
+                     gw, kpad);
+  return launch_status("im2col_kernel");
+}
+
+int cls_rows(float* x, const float* cls, const float* pos, int64_t batch, int T, int dim, hipStream_t stream) {
+  ProfScope prof("cls_rows", stream, 0.0, 12.0 * batch * dim);
+  hipLaunchKernelGGL(cls_row_kernel, dim3((unsigned)batch), dim3(256), 0, stream, x, cls, pos, T, dim);
+  return launch_status("cls_row_kernel");
+}
+
+int facet_rows(const float* src, int64_t lds_, int coff, float* out, int64_t ldo, int ooff, int64_t batch, int T,
+               int skip, int rows_per_img, int dim, int normalize, float eps, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(dim % 4 == 0 && coff % 4 == 0 && ooff % 4 == 0 && lds_ % 4 == 0 && ldo % 4 == 0,
+                   "facet_rows: alignment");
+  ProfScope prof("facet_rows", stream, 3.0 * batch * rows_per_img * dim, 8.0 * batch * rows_per_img * dim);
+  hipLaunchKernelGGL(facet_rows_kernel, dim3((unsigned)(batch * rows_per_img)), dim3(256), 0, stream, src, lds_, coff,
+                     out, ldo, ooff, T, skip, rows_per_img, dim, normalize, eps);
+  return launch_status("facet_rows_kernel");
+}
+
+}  // namespace anyloc
+
+extern "C" int anyloc_l2norm_rows(const float* x, float* out, int64_t rows, int64_t dim, float eps, void* stream) {
+  return anyloc::l2norm_rows(x, dim, out, dim, rows, dim, eps, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,219 @@
+// Exact brute-force top-k retrieval (inner product / squared L2).
+//
+// replaces: faiss.IndexFlatIP / IndexFlatL2 .add + .search as called by
+// get_top_k_recall (reference utilities.py:439-450).
+//
+// The database is processed in column panels: an fp32 MFMA GEMM (gemm_f32.hip)
+// writes the [nq, panel] score block, then one block per query merges the
+// panel into that query's running top-k list (k selection passes over an
+// LDS-resident candidate set; ties -> lower database index, deterministic).
+// Governing roofline: fp32 MFMA (2*nq flop per database float).
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+constexpr int CH = 4096;          // candidates staged in LDS per merge round
+constexpr int64_t PANEL = 32768;  // database rows per GEMM panel
+constexpr int KMAX = 1024;
+
+struct Cand {
+  float v;
+  long long i;   // global index (lower wins ties)
+  int pos;       // position in the LDS candidate array
+};
+__device__ __forceinline__ bool better(float v, long long i, float bv, long long bi) {
+  return v > bv || (v == bv && i < bi);
+}
+
+__global__ __launch_bounds__(256) void rownorm_sq_kernel(const float* __restrict__ x, int64_t dim,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4];
+  const float* r = x + (int64_t)blockIdx.x * dim;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < dim; i += 256) ss += r[i] * r[i];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// One block per query.  Running list (best first) lives in run_v/run_i [nq,k]; `first` != 0
+// initialises it to (-inf, -1).  metric 1: candidate value = -(qn + dn - 2 ip).
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, int64_t ld, int64_t ncols,
+                                                         int64_t col_base, int k, int metric,
+                                                         const float* __restrict__ qn, const float* __restrict__ dn,
+                                                         float* __restrict__ run_v, long long* __restrict__ run_i,
+                                                         int first) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* cv = reinterpret_cast<float*>(smem_raw);                       // [CH + k] candidate values
+  long long* ri = reinterpret_cast<long long*>(cv + CH + KMAX);         // [k] indices of the running entries
+  float* nv = reinterpret_cast<float*>(ri + KMAX);                      // [k] new list values
+  long long* ni = reinterpret_cast<long long*>(nv + KMAX);              // [k] new list indices
+  __shared__ Cand wbest[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t q = blockIdx.x;
+  const float* srow = scores + q * ld;
+  const float qq = metric ? qn[q] : 0.f;
+
+  for (int i = tid; i < k; i += 256) {
+    if (first) { cv[CH + i] = -INFINITY; ri[i] = -1; }
+    else { cv[CH + i] = run_v[q * k + i]; ri[i] = run_i[q * k + i]; }
+  }
+  for (int64_t c0 = 0; c0 < ncols; c0 += CH) {
+    const int nc = (int)min<int64_t>(CH, ncols - c0);
+    for (int i = tid; i < CH; i += 256) {
+      float v = -INFINITY;
+      if (i < nc) {
+        v = srow[c0 + i];
+        if (metric) v = -((qq + dn[c0 + i]) - 2.0f * v);
+      }
+      cv[i] = v;
+    }
+    __syncthreads();
+    const long long gbase = col_base + c0;
+    for (int sel = 0; sel < k; ++sel) {
+      float bv = -INFINITY;
+      long long bi = 0x7fffffffffffffffll;
+      int bp = -1;
+      for (int i = tid; i < CH + k; i += 256) {
+        if (i >= nc && i < CH) continue;
+        const float v = cv[i];
+        const long long gi = i < CH ? gbase + i : ri[i - CH];
+        if (bp < 0 || better(v, gi, bv, bi)) { bv = v; bi = gi; bp = i; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const long long oi = __shfl_xor(bi, o, 64);
+        const int op = __shfl_xor(bp, o, 64);
+        if (op >= 0 && (bp < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+      }
+      if (lane == 0) { wbest[wave].v = bv; wbest[wave].i = bi; wbest[wave].pos = bp; }
+      __syncthreads();
+      if (tid == 0) {
+        Cand b = wbest[0];
+        for (int w2 = 1; w2 < 4; ++w2)
+          if (wbest[w2].pos >= 0 && (b.pos < 0 || better(wbest[w2].v, wbest[w2].i, b.v, b.i))) b = wbest[w2];
+        nv[sel] = b.v;
+        ni[sel] = b.i;
+        // retire the winner: value -inf; a retired running entry also gets the largest index so
+        // that untouched (-inf, -1) padding entries are preferred over it
+        cv[b.pos] = -INFINITY;
+        if (b.pos >= CH) ri[b.pos - CH] = 0x7fffffffffffffffll;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < k; i += 256) { cv[CH + i] = nv[i]; ri[i] = ni[i]; }
+    __syncthreads();
+  }
+  for (int i = tid; i < k; i += 256) {
+    run_v[q * k + i] = cv[CH + i];
+    run_i[q * k + i] = ri[i];
+  }
+}
+
+// metric 1: stored values are negated squared distances -> flip sign; padding -> +inf
+__global__ void topk_finish_kernel(float* __restrict__ v, const long long* __restrict__ idx, int64_t n, int metric) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (metric) v[i] = idx[i] < 0 ? INFINITY : -v[i];
+}
+
+struct TopkWs {
+  float *scores, *qn, *dn;
+  size_t bytes;
+};
+TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb) {
+  Arena a(ws, cap);
+  TopkWs w;
+  const int64_t panel = std::min<int64_t>(PANEL, std::max<int64_t>(ndb, 1));
+  w.scores = a.take<float>(std::max<int64_t>(nq, 1) * panel);
+  w.qn = a.take<float>(std::max<int64_t>(nq, 1));
+  w.dn = a.take<float>(std::max<int64_t>(ndb, 1));
+  w.bytes = a.off;
+  return w;
+}
+
+}  // namespace
+}  // namespace anyloc
+
+using namespace anyloc;
+
+extern "C" {
+
+size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k) {
+  (void)dim; (void)k;
+  return carve(nullptr, 0, nq, ndb).bytes + 256;
+}
+
+int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, int64_t dim, int64_t k, int metric,
+                int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
+                void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(nq >= 0 && ndb >= 0, "topk: negative size");
+  if (nq == 0 || k == 0) return ANYLOC_OK;
+  ANYLOC_CHECK_ARG(queries && dist && idx, "topk: null pointer");
+  ANYLOC_CHECK_ARG(db || ndb == 0, "topk: null database");
+  ANYLOC_CHECK_ARG(k >= 1 && k <= KMAX, "topk: k=%lld outside [1,%d]", (long long)k, KMAX);
+  ANYLOC_CHECK_ARG(metric == 0 || metric == 1, "topk: metric %d", metric);
+  ANYLOC_CHECK_ARG(dim >= 4 && dim % 4 == 0, "topk: dim %lld must be a positive multiple of 4", (long long)dim);
+  ANYLOC_CHECK_ARG(nq < (1ll << 31), "topk: too many queries");
+  TopkWs w = carve(workspace, workspace_bytes, nq, ndb);
+  if (!workspace || w.bytes > workspace_bytes) {
+    set_error("topk: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  const size_t lds = sizeof(float) * (CH + KMAX) + sizeof(long long) * KMAX + sizeof(float) * KMAX +
+                     sizeof(long long) * KMAX;
+  static bool attr = false;
+  if (!attr) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  if (metric == 1) {
+    hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)nq), dim3(256), 0, stream, queries, dim, w.qn);
+    ANYLOC_TRY(launch_status("rownorm_sq_kernel(q)"));
+    for (int64_t r0 = 0; r0 < ndb; r0 += (1ll << 30)) {
+      const int64_t cnt = std::min<int64_t>(1ll << 30, ndb - r0);
+      hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, db + r0 * dim, dim, w.dn + r0);
+      ANYLOC_TRY(launch_status("rownorm_sq_kernel(db)"));
+    }
+  }
+  long long* idx_ll = reinterpret_cast<long long*>(idx);
+  int first = 1;
+  if (ndb == 0) {
+    // nothing to search: emit the padding list
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.scores, (int64_t)0,
+                       (int64_t)0, index_base, (int)k, metric, w.qn, w.dn, dist, idx_ll, 1);
+    ANYLOC_TRY(launch_status("topk_merge_kernel"));
+  }
+  for (int64_t c0 = 0; c0 < ndb; c0 += PANEL) {
+    const int64_t pc = std::min<int64_t>(PANEL, ndb - c0);
+    GemmProblem g{};
+    g.A = queries; g.lda = dim;
+    g.W = db + c0 * dim; g.ldw = dim;
+    g.C = w.scores; g.ldc = pc;
+    g.M = nq; g.N = pc; g.K = dim;
+    g.tag = "topk_scores_gemm";
+    ANYLOC_TRY(gemm_nt(g, EPI_STORE, stream));
+    {
+      ProfScope prof("topk_merge", stream, 0.0, 4.0 * nq * pc);
+      hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.scores, pc, pc,
+                         index_base + c0, (int)k, metric, w.qn, w.dn + c0, dist, idx_ll, first);
+      ANYLOC_TRY(launch_status("topk_merge_kernel"));
+    }
+    first = 0;
+  }
+  // padding entries carry index -1 regardless of index_base (faiss); L2 distances are sign-flipped back
+  hipLaunchKernelGGL(topk_finish_kernel, dim3((unsigned)((nq * k + 255) / 256)), dim3(256), 0, stream, dist, idx_ll,
+                     nq * k, metric);
+  return launch_status("topk_finish_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// DINOv2 ViT forward with early exit at the last tapped layer.
+//
+// replaces: DinoV2ExtractFeatures.__call__ (reference utilities.py:263-285):
+// the torch.hub DINOv2 forward at :269, the forward-hook capture of
+// blocks[L].attn.qkv / blocks[L] (:245-252, :258-261), CLS drop (:270-273),
+// facet slice (:274-281) and F.normalize (:282-283).
+//
+// The reference runs all blocks, the final norm and the head and throws the
+// result away; only the hooked tensor is used.  Here execution stops at the
+// last tap, and when a q/k/v tap sits in the last executed block only that
+// facet's third of the QKV projection is computed.
+//
+// Per block (all GEMMs on gemm_f32.hip, fp32 MFMA, fused epilogues):
+//   y   = LN1(x)                                    layernorm
+//   qkv = y Wqkv^T + b                              EPI_STORE
+//   a   = softmax((q/8) k^T) v                      attention.hip
+//   x  += ls1 * (a Wproj^T + b)                     EPI_LS_RESID (in place)
+//   y   = LN2(x)
+//   h   = gelu(y W1^T + b)  |  silu(y Wg^T+b)*(y Wv^T+b)    EPI_GELU | EPI_SWIGLU
+//   x  += ls2 * (h W2^T + b)                        EPI_LS_RESID (in place)
+#include <vector>
+
+#include "common.hpp"
+
+struct anyloc_vit {
+  anyloc_vit_config cfg;
+  const float* patch_w;
+  const float* patch_b;
+  const float* cls;
+  std::vector<anyloc_vit_block_weights> blocks;
+};
+
+namespace anyloc {
+namespace {
+
+struct VitWs {
+  float *x, *y, *qkv, *h;   // qkv doubles as the im2col buffer; attention output aliases y
+  size_t bytes;
+};
+
+VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int64_t H, int64_t W) {
+  Arena a(ws, cap);
+  const int64_t np = (H / c.patch) * (W / c.patch), T = np + 1, M = batch * T;
+  VitWs w;
+  w.x = a.take<float>(M * c.dim);
+  w.y = a.take<float>(M * c.dim);
+  const int64_t qkv_elems = std::max<int64_t>(M * 3 * c.dim, batch * np * c.patch_k_pad);
+  w.qkv = a.take<float>(qkv_elems);
+  w.h = a.take<float>(M * c.ffn_hidden);
+  w.bytes = a.off;
+  return w;
+}
+
+int linear(const float* A, int64_t lda, const float* Wt, int64_t K, const float* bias, float* C, int64_t ldc, int64_t M,
+           int64_t N, int epi, const float* gamma, const char* tag, hipStream_t stream) {
+  GemmProblem g{};
+  g.A = A; g.lda = lda;
+  g.W = Wt; g.ldw = K;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.bias = bias;
+  g.gamma = gamma;
+  g.resid = C;
+  g.tag = tag;
+  return gemm_nt(g, epi, stream);
+}
+
+}  // namespace
+}  // namespace anyloc
+
+using namespace anyloc;
+
+extern "C" {
+
+int anyloc_layernorm(const float* x, float* y, const float* weight, const float* bias, int64_t rows, int64_t dim,
+                     float eps, void* stream) {
+  ANYLOC_CHECK_ARG(x && y && weight && bias && rows > 0 && rows < (1ll << 31) && dim > 0, "layernorm: bad args");
+  return layernorm(x, y, weight, bias, rows, (int)dim, eps, static_cast<hipStream_t>(stream));
+}
+
+int anyloc_attention(const float* qkv, float* out, int64_t batch, int64_t tokens, int64_t dim, int64_t heads,
+                     void* stream) {
+  ANYLOC_CHECK_ARG(qkv && out, "attention: null pointer");
+  return attention(qkv, out, batch, (int)tokens, (int)dim, (int)heads, static_cast<hipStream_t>(stream));
+}
+
+int anyloc_vit_create(anyloc_vit_t** out, const anyloc_vit_config* cfg, const float* patch_w, const float* patch_b,
+                      const float* cls_token, const anyloc_vit_block_weights* blocks) {
+  ANYLOC_CHECK_ARG(out && cfg && patch_w && patch_b && cls_token && blocks, "vit_create: null pointer");
+  ANYLOC_CHECK_ARG(cfg->dim > 0 && cfg->dim % 64 == 0 && cfg->heads * 64 == cfg->dim,
+                   "vit_create: dim %d / heads %d (head_dim must be 64)", cfg->dim, cfg->heads);
+  ANYLOC_CHECK_ARG(cfg->depth > 0 && cfg->depth <= 256, "vit_create: depth %d", cfg->depth);
+  ANYLOC_CHECK_ARG(cfg->ffn_kind == 0 || cfg->ffn_kind == 1, "vit_create: ffn_kind %d", cfg->ffn_kind);
+  ANYLOC_CHECK_ARG(cfg->ffn_hidden > 0 && cfg->ffn_hidden % 64 == 0, "vit_create: ffn_hidden %d", cfg->ffn_hidden);
+  ANYLOC_CHECK_ARG(cfg->patch > 0 && cfg->patch_k_pad >= 3 * cfg->patch * cfg->patch && cfg->patch_k_pad % 4 == 0,
+                   "vit_create: patch %d / patch_k_pad %d", cfg->patch, cfg->patch_k_pad);
+  for (int i = 0; i < cfg->depth; ++i) {
+    const anyloc_vit_block_weights& b = blocks[i];
+    ANYLOC_CHECK_ARG(b.norm1_w && b.norm1_b && b.qkv_w && b.qkv_b && b.proj_w && b.proj_b && b.ls1 && b.norm2_w &&
+                         b.norm2_b && b.fc1_w && b.fc1_b && b.fc2_w && b.fc2_b && b.ls2,
+                     "vit_create: block %d has a null weight", i);
+  }
+  anyloc_vit* h = new (std::nothrow) anyloc_vit();
+  if (!h) {
+    set_error("vit_create: out of host memory");
+    return ANYLOC_ERR_HIP;
+  }
+  h->cfg = *cfg;
+  h->patch_w = patch_w;
+  h->patch_b = patch_b;
+  h->cls = cls_token;
+  h->blocks.assign(blocks, blocks + cfg->depth);
+  *out = h;
+  return ANYLOC_OK;
+}
+
+void anyloc_vit_destroy(anyloc_vit_t* h) { delete h; }
+
+size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch, int64_t img_h, int64_t img_w) {
+  if (!h || batch <= 0 || img_h < h->cfg.patch || img_w < h->cfg.patch) return 0;
+  return carve(nullptr, 0, h->cfg, batch, img_h, img_w).bytes + 256;
+}
+
+int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t img_h, int64_t img_w,
+                       const float* pos, int32_t n_taps, const int32_t* tap_layers, const int32_t* tap_facets,
+                       unsigned flags, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(h && img && pos && out && tap_layers && tap_facets, "vit_forward: null pointer");
+  const anyloc_vit_config& c = h->cfg;
+  ANYLOC_CHECK_ARG(batch > 0 && batch < 65536, "vit_forward: batch %lld", (long long)batch);
+  ANYLOC_CHECK_ARG(img_h >= c.patch && img_w >= c.patch && img_h % c.patch == 0 && img_w % c.patch == 0,
+                   "vit_forward: image %lldx%lld is not a positive multiple of the patch size %d", (long long)img_h,
+                   (long long)img_w, c.patch);
+  ANYLOC_CHECK_ARG(n_taps >= 1 && n_taps <= 64, "vit_forward: n_taps %d", n_taps);
+  for (int t = 0; t < n_taps; ++t) {
+    ANYLOC_CHECK_ARG(tap_layers[t] >= 0 && tap_layers[t] < c.depth, "vit_forward: tap layer %d outside [0,%d)",
+                     tap_layers[t], c.depth);
+    ANYLOC_CHECK_ARG(tap_facets[t] >= 0 && tap_facets[t] <= 3, "vit_forward: facet %d", tap_facets[t]);
+    ANYLOC_CHECK_ARG(t == 0 || tap_layers[t] >= tap_layers[t - 1], "vit_forward: tap layers must ascend");
+  }
+  const int D = c.dim, gh = (int)(img_h / c.patch), gw = (int)(img_w / c.patch), np = gh * gw, T = np + 1;
+  const int64_t M = batch * T;
+  VitWs w = carve(workspace, workspace_bytes, c, batch, img_h, img_w);
+  if (!workspace || w.bytes > workspace_bytes) {
+    set_error("vit_forward: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
+  const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;
+  const int64_t ldo = (int64_t)n_taps * D;
+  const int norm_taps = (flags & ANYLOC_VIT_NORM_TAPS) ? 1 : 0;
+  const int last_layer = tap_layers[n_taps - 1];
+  // does any tap need the block OUTPUT of the last executed layer?
+  bool last_needs_full = false;
+  for (int t = 0; t < n_taps; ++t)
+    if (tap_layers[t] == last_layer && tap_facets[t] == ANYLOC_FACET_TOKEN) last_needs_full = true;
+
+  // ---- patch embedding: conv 14x14 stride 14 == GEMM over gathered patches, + bias + pos ----
+  float* col = w.qkv;
+  ANYLOC_TRY(im2col(img, col, batch, (int)img_h, (int)img_w, c.patch, c.patch_k_pad, stream));
+  {
+    GemmProblem g{};
+    g.A = col; g.lda = c.patch_k_pad;
+    g.W = h->patch_w; g.ldw = c.patch_k_pad;
+    g.C = w.x; g.ldc = D;
+    g.M = batch * np; g.N = D; g.K = c.patch_k_pad;
+    g.bias = h->patch_b;
+    g.pos = pos;
+    g.patches = np;
+    g.tag = "vit_patch_embed_gemm";
+    ANYLOC_TRY(gemm_nt(g, EPI_PATCH, stream));
+  }
+  ANYLOC_TRY(cls_rows(w.x, h->cls, pos, batch, T, D, stream));
+
+  for (int l = 0; l <= last_layer; ++l) {
+    const anyloc_vit_block_weights& b = h->blocks[l];
+    const bool last = (l == last_layer);
+    ANYLOC_TRY(layernorm(w.x, w.y, b.norm1_w, b.norm1_b, M, D, 1e-6f, stream));
+    if (last && !last_needs_full) {
+      // only q/k/v taps remain: compute just the tapped thirds of the QKV projection
+      for (int t = 0; t < n_taps; ++t) {
+        if (tap_layers[t] != l) continue;
+        const int f = tap_facets[t];
+        ANYLOC_TRY(linear(w.y, D, b.qkv_w + (int64_t)f * D * D, D, b.qkv_b + (int64_t)f * D, w.qkv, D, M, D,
+                          EPI_STORE, nullptr, "vit_facet_gemm", stream));
+        ANYLOC_TRY(facet_rows(w.qkv, D, 0, out, ldo, t * D, batch, T, skip, rows_per_img, D, norm_taps, 1e-12f,
+                              stream));
+      }
+      break;
+    }
+    ANYLOC_TRY(linear(w.y, D, b.qkv_w, D, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
+    for (int t = 0; t < n_taps; ++t)
+      if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
+        ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
+                              norm_taps, 1e-12f, stream));
+    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream));
+    ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
+    ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
+    const int Hh = c.ffn_hidden;
+    if (c.ffn_kind == 0) {
+      ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr, "vit_fc1_gemm", stream));
+    } else {
+      ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, 2 * Hh, EPI_SWIGLU, nullptr, "vit_w12_gemm", stream));
+    }
+    ANYLOC_TRY(linear(w.h, Hh, b.fc2_w, Hh, b.fc2_b, w.x, D, M, D, EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
+    for (int t = 0; t < n_taps; ++t)
+      if (tap_layers[t] == l && tap_facets[t] == ANYLOC_FACET_TOKEN)
+        ANYLOC_TRY(facet_rows(w.x, D, 0, out, ldo, t * D, batch, T, skip, rows_per_img, D, norm_taps, 1e-12f, stream));
+  }
+  if (flags & ANYLOC_VIT_NORM_CONCAT)
+    ANYLOC_TRY(l2norm_rows(out, ldo, out, ldo, batch * rows_per_img, ldo, 1e-12f, stream));
+  return ANYLOC_OK;
+}
+
+}  // extern "C"

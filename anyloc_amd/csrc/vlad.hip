@@ -1,0 +1,484 @@
+// VLAD aggregation (hard + soft assignment) and the k-means iteration.
+//
+// replaces (reference utilities.py): VLAD.generate_res_vec :928-972 (the
+// [N,K,D] residual tensor is never materialised), VLAD.generate :819-890,
+// generate_multi :892-926, and the fast-pytorch-kmeans assign/update loop
+// reached from VLAD.fit :766,:786 and predict :849.
+//
+// Stages (all on the caller's stream):
+//   1. center_prep      chat_k = c_k / (||c_k|| + 1e-8)  (fpk cos_sim), zero-padded to 32 rows
+//   2. gemm_nt(+rowsq)  scores[n,k] = x_n . chat_k on fp32 MFMA; the same pass
+//                       accumulates ||x_n||^2 while staging the token tiles.
+//                       argmax_k is invariant to fpk's positive per-row scale
+//                       1/(||x_n|| + 1e-8), so tokens are used as passed.
+//   3. assign           label_n = first argmax_k scores[n,k];  nrm_n = max(||x_n||, 1e-12)
+//   4. accumulate       one block per (image, 256-column slice): K x 256 accumulators
+//                       in LDS, tokens streamed once with coalesced loads,
+//                       acc[label_n] += x_n / nrm_n - c_label   (sequential in n: deterministic)
+//   5. finalize         intra-norm of each cluster block, then the global L2 norm.
+// HBM-bound: algorithmic bytes per image = (N*D + 2*K*D) * 4.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+constexpr int SL = 256;   // feature columns per accumulate block
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// mode 0 (cosine): chat = c / (||c|| + 1e-8), cb = 0
+// mode 1 (euclid): chat = 2 c,                cb = -||c||^2   (argmax of 2ab - b^2; -a^2 is per-row constant)
+__global__ __launch_bounds__(256) void center_prep_kernel(const float* __restrict__ c, float* __restrict__ chat,
+                                                          float* __restrict__ cb, int K, int D, int mode) {
+  __shared__ float red[4];
+  const int k = blockIdx.x;
+  float* dst = chat + (int64_t)k * D;
+  if (k >= K) {
+    for (int i = threadIdx.x; i < D; i += 256) dst[i] = 0.f;
+    if (threadIdx.x == 0) cb[k] = 0.f;
+    return;
+  }
+  const float* src = c + (int64_t)k * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) ss += src[i] * src[i];
+  ss = block_sum256(ss, red);
+  if (mode == 0) {
+    const float den = sqrtf(ss) + 1e-8f;
+    for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i] / den;
+    if (threadIdx.x == 0) cb[k] = 0.f;
+  } else {
+    for (int i = threadIdx.x; i < D; i += 256) dst[i] = 2.0f * src[i];
+    if (threadIdx.x == 0) cb[k] = -ss;
+  }
+}
+
+// one thread per token: first argmax over k < K; row norm clamp
+__global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ scores, int kpad, int K,
+                                                     const float* __restrict__ rowsq, int64_t n,
+                                                     int* __restrict__ lab32, int64_t* __restrict__ lab64,
+                                                     float* __restrict__ nrm, int norm_descs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* s = scores + i * kpad;
+  float best = s[0];
+  int bi = 0;
+  for (int k = 1; k < K; ++k) {
+    const float v = s[k];
+    if (v > best) { best = v; bi = k; }
+  }
+  lab32[i] = bi;
+  if (lab64) lab64[i] = bi;
+  if (nrm) nrm[i] = norm_descs ? fmaxf(sqrtf(rowsq[i]), 1e-12f) : 1.0f;
+}
+
+// VLAD:   dst[img][k*D + d]  = sum_{n in img, label_n == k} (x[n,d]/nrm_n - c[k,d])
+// KMEANS: dst[chunk][k*D + d] = sum_{n in chunk, label_n == k} x[n,d]
+template <bool KMEANS>
+__global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets,
+                                                        int64_t chunk_rows, int64_t total, int D, int K,
+                                                        const int* __restrict__ lab, const float* __restrict__ nrm,
+                                                        const float* __restrict__ c, float* __restrict__ dst) {
+  extern __shared__ float acc[];   // [K][SL]
+  const int tid = threadIdx.x;
+  const int d = blockIdx.x * SL + tid;
+  const int64_t g = blockIdx.y;
+  int64_t n0, n1;
+  if (KMEANS) {
+    n0 = g * chunk_rows;
+    n1 = min(n0 + chunk_rows, total);
+  } else {
+    n0 = offsets[g];
+    n1 = offsets[g + 1];
+  }
+  for (int k = 0; k < K; ++k) acc[k * SL + tid] = 0.f;
+  const bool live = d < D;
+  const float* xp = x + (live ? d : 0);
+  int64_t n = n0;
+  for (; n + 8 <= n1; n += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = live ? xp[(n + u) * D] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = lab[n + u];
+      if (KMEANS) {
+        acc[k * SL + tid] += v[u];
+      } else {
+        const float cv = live ? c[(int64_t)k * D + d] : 0.f;
+        acc[k * SL + tid] += v[u] / nrm[n + u] - cv;
+      }
+    }
+  }
+  for (; n < n1; ++n) {
+    const float v = live ? xp[n * D] : 0.f;
+    const int k = lab[n];
+    if (KMEANS) {
+      acc[k * SL + tid] += v;
+    } else {
+      const float cv = live ? c[(int64_t)k * D + d] : 0.f;
+      acc[k * SL + tid] += v / nrm[n] - cv;
+    }
+  }
+  if (live) {
+    float* o = dst + g * (int64_t)K * D + d;
+    for (int k = 0; k < K; ++k) o[(int64_t)k * D] = acc[k * SL + tid];
+  }
+}
+
+// per image: optional intra-norm of each [D] block, then global norm of the [K*D] vector (in place)
+__global__ __launch_bounds__(1024) void vlad_finalize_kernel(float* __restrict__ v, int K, int D, int intra) {
+  __shared__ float knorm[256];
+  __shared__ float red[16];
+  float* p = v + (int64_t)blockIdx.x * K * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < K; k += 16) {
+    float ss = 0.f;
+    if (intra) {
+      for (int i = lane; i < D; i += 64) { const float t = p[(int64_t)k * D + i]; ss += t * t; }
+      ss = wave_sum(ss);
+    }
+    if (lane == 0) knorm[k] = intra ? fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+  }
+  __syncthreads();
+  const int total = K * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < total; i += 1024) {
+    const float t = p[i] / knorm[i / D];
+    ss += t * t;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red[w];
+  const float gn = fmaxf(sqrtf(tot), 1e-12f);
+  for (int i = threadIdx.x; i < total; i += 1024) p[i] = (p[i] / knorm[i / D]) / gn;
+}
+
+// sums[k,d] = sum over chunks of partial[chunk][k,d]  (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ part, int64_t n_chunks,
+                                                            int64_t kd, float* __restrict__ sums) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= kd) return;
+  float s = 0.f;
+  for (int64_t ch = 0; ch < n_chunks; ++ch) s += part[ch * kd + i];
+  sums[i] = s;
+}
+
+__global__ __launch_bounds__(256) void count_labels_kernel(const int* __restrict__ lab, int64_t n,
+                                                           unsigned* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[lab[i]], 1u);
+}
+__global__ void counts_to_float_kernel(const unsigned* __restrict__ cnt, float* __restrict__ out, int K) {
+  const int k = threadIdx.x;
+  if (k < K) out[k] = (float)cnt[k];
+}
+
+// soft assignment weights: w[n,k] = softmax_k(temp * cos(x_n, c_k)),  F.cosine_similarity eps 1e-8:
+//   cos = x.c / (max(||x||,eps) * max(||c||,eps));  scores hold x_n . c_k (raw centres)
+__global__ __launch_bounds__(256) void soft_weights_kernel(float* __restrict__ scores, int kpad, int K,
+                                                           const float* __restrict__ rowsq,
+                                                           const float* __restrict__ csq, int64_t n, float temp,
+                                                           float* __restrict__ nrm, int norm_descs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float* s = scores + i * kpad;
+  const float xn = fmaxf(sqrtf(rowsq[i]), 1e-8f);
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const float cs = temp * (s[k] / (xn * fmaxf(sqrtf(csq[k]), 1e-8f)));
+    s[k] = cs;
+    m = fmaxf(m, cs);
+  }
+  float z = 0.f;
+  for (int k = 0; k < K; ++k) { const float e = expf(s[k] - m); s[k] = e; z += e; }
+  for (int k = 0; k < K; ++k) s[k] /= z;
+  nrm[i] = norm_descs ? fmaxf(sqrtf(rowsq[i]), 1e-12f) : 1.0f;
+}
+
+__global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x, int D, float* __restrict__ out) {
+  __shared__ float red[4];
+  const float* r = x + (int64_t)blockIdx.x * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) ss += r[i] * r[i];
+  ss = block_sum256(ss, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = ss;
+}
+
+// reference quirk (utilities.py:881-884): block k = sum_q sum_c w[q,k] * (xhat_q - c_c).
+// One block per (image, 256-col slice); each thread owns one column d and K accumulators in LDS:
+//   acc[k] += w[q,k] * (xhat[q,d] - c[c,d])  for every c (direct double sum, as the reference computes it)
+__global__ __launch_bounds__(SL) void soft_accumulate_kernel(const float* __restrict__ x,
+                                                             const int64_t* __restrict__ offsets, int D, int K,
+                                                             int kpad, const float* __restrict__ w,
+                                                             const float* __restrict__ nrm,
+                                                             const float* __restrict__ c, float* __restrict__ dst) {
+  extern __shared__ float acc[];   // [K][SL] accumulators, then [K][SL] centre slice
+  float* cs = acc + K * SL;
+  const int tid = threadIdx.x;
+  const int d = blockIdx.x * SL + tid;
+  const bool live = d < D;
+  const int64_t g = blockIdx.y;
+  const int64_t n0 = offsets[g], n1 = offsets[g + 1];
+  for (int k = 0; k < K; ++k) {
+    acc[k * SL + tid] = 0.f;
+    cs[k * SL + tid] = live ? c[(int64_t)k * D + d] : 0.f;
+  }
+  for (int64_t n = n0; n < n1; ++n) {
+    const float xh = live ? x[n * D + d] / nrm[n] : 0.f;
+    const float* wr = w + n * kpad;
+    for (int cc = 0; cc < K; ++cc) {
+      const float r = xh - cs[cc * SL + tid];
+      for (int k = 0; k < K; ++k) acc[k * SL + tid] += wr[k] * r;
+    }
+  }
+  if (live) {
+    float* o = dst + g * (int64_t)K * D + d;
+    for (int k = 0; k < K; ++k) o[(int64_t)k * D] = acc[k * SL + tid];
+  }
+}
+
+inline int64_t kpad_of(int64_t K) { return (K + 31) / 32 * 32; }
+
+struct VladWs {
+  float *chat, *cb, *scores, *rowsq, *nrm;
+  int* lab32;
+  size_t bytes;
+};
+VladWs carve(void* ws, size_t cap, int64_t n, int64_t D, int64_t K) {
+  Arena a(ws, cap);
+  VladWs w;
+  const int64_t kp = kpad_of(K);
+  w.chat = a.take<float>(kp * D);
+  w.cb = a.take<float>(kp);
+  w.scores = a.take<float>((n > 0 ? n : 1) * kp);
+  w.rowsq = a.take<float>(n > 0 ? n : 1);
+  w.nrm = a.take<float>(n > 0 ? n : 1);
+  w.lab32 = a.take<int>(n > 0 ? n : 1);
+  w.bytes = a.off;
+  return w;
+}
+
+int run_scores(const float* x, int64_t n, int64_t D, const VladWs& w, int64_t K, bool with_bias, hipStream_t stream,
+               const char* tag) {
+  GemmProblem g{};
+  g.A = x; g.lda = D;
+  g.W = w.chat; g.ldw = D;
+  g.C = w.scores; g.ldc = kpad_of(K);
+  g.M = n; g.N = kpad_of(K); g.K = D;
+  g.bias = with_bias ? w.cb : nullptr;
+  g.rowsq = w.rowsq;
+  g.tag = tag;
+  return gemm_nt(g, EPI_STORE, stream);
+}
+
+}  // namespace
+}  // namespace anyloc
+
+using namespace anyloc;
+
+extern "C" {
+
+size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K) {
+  (void)n_img;
+  return carve(nullptr, 0, total_tokens, D, K).bytes + 256;
+}
+
+static int vlad_common_checks(const float* tokens, const int64_t* offsets, int64_t n_img, int64_t total, int64_t D,
+                              const float* centers, int64_t K, float* out) {
+  ANYLOC_CHECK_ARG(offsets && centers && out, "vlad: null pointer");
+  ANYLOC_CHECK_ARG(tokens || total == 0, "vlad: null tokens");
+  ANYLOC_CHECK_ARG(n_img >= 0 && total >= 0, "vlad: negative size");
+  ANYLOC_CHECK_ARG(K >= 1 && K <= 256, "vlad: num_clusters %lld outside [1,256]", (long long)K);
+  ANYLOC_CHECK_ARG(D >= 4 && D % 4 == 0, "vlad: desc_dim %lld must be a positive multiple of 4", (long long)D);
+  ANYLOC_CHECK_ARG(n_img < 65536ll * 32768, "vlad: too many images");
+  return ANYLOC_OK;
+}
+
+int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img, int64_t total_tokens, int64_t D,
+                     const float* centers, int64_t K, unsigned flags, float* out, int64_t* labels, void* workspace,
+                     size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_TRY(vlad_common_checks(tokens, offsets, n_img, total_tokens, D, centers, K, out));
+  if (n_img == 0) return ANYLOC_OK;
+  VladWs w = carve(workspace, workspace_bytes, total_tokens, D, K);
+  if (!workspace || w.bytes > workspace_bytes) {
+    set_error("vlad_hard: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  const int kp = (int)kpad_of(K);
+  if (total_tokens > 0) {
+    {
+      ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
+      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, 0);
+      ANYLOC_TRY(launch_status("center_prep_kernel"));
+    }
+    ANYLOC_TRY(run_scores(tokens, total_tokens, D, w, K, false, stream, "vlad_scores_gemm"));
+    {
+      ProfScope prof("vlad_assign", stream, 0.0, 4.0 * total_tokens * (kp + 4));
+      hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((total_tokens + 255) / 256)), dim3(256), 0, stream, w.scores,
+                         kp, (int)K, w.rowsq, total_tokens, w.lab32, labels, w.nrm,
+                         (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0);
+      ANYLOC_TRY(launch_status("assign_kernel"));
+    }
+  }
+  {
+    const size_t lds = (size_t)K * SL * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 256 * SL * (int)sizeof(float) / 2));
+      attr = true;
+    }
+    ANYLOC_CHECK_ARG(lds <= 128 * 1024, "vlad_hard: K=%lld needs %zu B of LDS (max 131072)", (long long)K, lds);
+    const double bytes = 4.0 * ((double)total_tokens * D + 2.0 * (double)n_img * K * D);
+    ProfScope prof("vlad_accumulate", stream, 2.0 * total_tokens * D, bytes);
+    // grid.y is limited to 65535: loop over image groups
+    for (int64_t i0 = 0; i0 < n_img; i0 += 65535) {
+      const int64_t cnt = std::min<int64_t>(65535, n_img - i0);
+      hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((D + SL - 1) / SL), (unsigned)cnt), dim3(SL), lds,
+                         stream, tokens, offsets + i0, (int64_t)0, total_tokens, (int)D, (int)K, w.lab32, w.nrm,
+                         centers, out + i0 * K * D);
+      ANYLOC_TRY(launch_status("accumulate_kernel"));
+    }
+  }
+  {
+    ProfScope prof("vlad_finalize", stream, 6.0 * n_img * K * D, 12.0 * n_img * K * D);
+    hipLaunchKernelGGL(vlad_finalize_kernel, dim3((unsigned)n_img), dim3(1024), 0, stream, out, (int)K, (int)D,
+                       (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0);
+    ANYLOC_TRY(launch_status("vlad_finalize_kernel"));
+  }
+  return ANYLOC_OK;
+}
+
+int anyloc_vlad_soft(const float* tokens, const int64_t* offsets, int64_t n_img, int64_t total_tokens, int64_t D,
+                     const float* centers, int64_t K, float soft_temp, unsigned flags, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_TRY(vlad_common_checks(tokens, offsets, n_img, total_tokens, D, centers, K, out));
+  if (n_img == 0) return ANYLOC_OK;
+  ANYLOC_CHECK_ARG(K <= 64, "vlad_soft: num_clusters %lld > 64 unsupported", (long long)K);
+  VladWs w = carve(workspace, workspace_bytes, total_tokens, D, K);
+  if (!workspace || w.bytes > workspace_bytes) {
+    set_error("vlad_soft: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  const int kp = (int)kpad_of(K);
+  if (total_tokens > 0) {
+    // raw centres padded with zero rows as the GEMM's W operand; cb holds ||c_k||^2
+    ANYLOC_HIP(hipMemsetAsync(w.chat, 0, sizeof(float) * kp * D, stream));
+    ANYLOC_HIP(hipMemcpyAsync(w.chat, centers, sizeof(float) * K * D, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(rowsq_kernel, dim3((unsigned)K), dim3(256), 0, stream, centers, (int)D, w.cb);
+    ANYLOC_TRY(launch_status("rowsq_kernel"));
+    ANYLOC_TRY(run_scores(tokens, total_tokens, D, w, K, false, stream, "vlad_soft_scores_gemm"));
+    hipLaunchKernelGGL(soft_weights_kernel, dim3((unsigned)((total_tokens + 255) / 256)), dim3(256), 0, stream,
+                       w.scores, kp, (int)K, w.rowsq, w.cb, total_tokens, soft_temp, w.nrm,
+                       (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0);
+    ANYLOC_TRY(launch_status("soft_weights_kernel"));
+  }
+  {
+    const size_t lds = (size_t)2 * K * SL * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(soft_accumulate_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * SL * (int)sizeof(float)));
+      attr = true;
+    }
+    ProfScope prof("vlad_soft_accumulate", stream, 2.0 * total_tokens * D * K * K, 4.0 * total_tokens * D);
+    for (int64_t i0 = 0; i0 < n_img; i0 += 65535) {
+      const int64_t cnt = std::min<int64_t>(65535, n_img - i0);
+      hipLaunchKernelGGL(soft_accumulate_kernel, dim3((unsigned)((D + SL - 1) / SL), (unsigned)cnt), dim3(SL), lds,
+                         stream, tokens, offsets + i0, (int)D, (int)K, kp, w.scores, w.nrm, centers,
+                         out + i0 * K * D);
+      ANYLOC_TRY(launch_status("soft_accumulate_kernel"));
+    }
+  }
+  hipLaunchKernelGGL(vlad_finalize_kernel, dim3((unsigned)n_img), dim3(1024), 0, stream, out, (int)K, (int)D,
+                     (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0);
+  return launch_status("vlad_finalize_kernel");
+}
+
+// ------------------------------------------------------------------ k-means
+static int64_t kmeans_chunk_rows(int64_t n) {
+  int64_t rows = (n + 2047) / 2048;       // at most 2048 chunks
+  return rows < 1024 ? 1024 : rows;
+}
+
+size_t anyloc_kmeans_workspace_bytes(int64_t n, int64_t D, int64_t K) {
+  size_t b = carve(nullptr, 0, n, D, K).bytes;
+  const int64_t rows = kmeans_chunk_rows(n), chunks = (n + rows - 1) / rows;
+  b += align_up((size_t)(chunks > 0 ? chunks : 1) * K * D * sizeof(float), 256);
+  b += align_up(256 * sizeof(unsigned), 256);
+  return b + 256;
+}
+
+int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* centers, int64_t K, int mode, float* sums,
+                       float* counts, int64_t* labels, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(x && centers && sums && counts, "kmeans_step: null pointer");
+  ANYLOC_CHECK_ARG(n > 0, "kmeans_step: no rows");
+  ANYLOC_CHECK_ARG(K >= 1 && K <= 256, "kmeans_step: K %lld outside [1,256]", (long long)K);
+  ANYLOC_CHECK_ARG(D >= 4 && D % 4 == 0, "kmeans_step: D %lld must be a positive multiple of 4", (long long)D);
+  ANYLOC_CHECK_ARG(mode == 0 || mode == 1, "kmeans_step: mode %d", mode);
+  const size_t need = anyloc_kmeans_workspace_bytes(n, D, K);
+  if (!workspace || need > workspace_bytes) {
+    set_error("kmeans_step: workspace %zu < %zu", workspace_bytes, need);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  VladWs w = carve(workspace, workspace_bytes, n, D, K);
+  Arena tail(static_cast<char*>(workspace) + w.bytes, workspace_bytes - w.bytes);
+  const int64_t rows = kmeans_chunk_rows(n), chunks = (n + rows - 1) / rows;
+  float* part = tail.take<float>(chunks * K * D);
+  unsigned* cnt = tail.take<unsigned>(256);
+  const int kp = (int)kpad_of(K);
+
+  hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, mode);
+  ANYLOC_TRY(launch_status("center_prep_kernel"));
+  ANYLOC_TRY(run_scores(x, n, D, w, K, mode == 1, stream, "kmeans_scores_gemm"));
+  {
+    ProfScope prof("kmeans_assign", stream, 0.0, 4.0 * n * (kp + 2));
+    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w.scores, kp, (int)K,
+                       w.rowsq, n, w.lab32, labels, (float*)nullptr, 0);
+    ANYLOC_TRY(launch_status("assign_kernel"));
+  }
+  {
+    const size_t lds = (size_t)K * SL * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      attr = true;
+    }
+    ANYLOC_CHECK_ARG(lds <= 128 * 1024, "kmeans_step: K=%lld needs %zu B of LDS", (long long)K, lds);
+    ProfScope prof("kmeans_accumulate", stream, 1.0 * n * D, 4.0 * ((double)n * D + (double)chunks * K * D));
+    hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((D + SL - 1) / SL), (unsigned)chunks), dim3(SL), lds,
+                       stream, x, (const int64_t*)nullptr, rows, n, (int)D, (int)K, w.lab32, (const float*)nullptr,
+                       (const float*)nullptr, part);
+    ANYLOC_TRY(launch_status("accumulate_kernel<kmeans>"));
+  }
+  {
+    ProfScope prof("kmeans_reduce", stream, 1.0 * chunks * K * D, 4.0 * (chunks + 1.0) * K * D);
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((K * D + 255) / 256)), dim3(256), 0, stream, part, chunks,
+                       K * D, sums);
+    ANYLOC_TRY(launch_status("reduce_chunks_kernel"));
+  }
+  ANYLOC_HIP(hipMemsetAsync(cnt, 0, 256 * sizeof(unsigned), stream));
+  hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w.lab32, n, cnt);
+  ANYLOC_TRY(launch_status("count_labels_kernel"));
+  hipLaunchKernelGGL(counts_to_float_kernel, dim3(1), dim3(256), 0, stream, cnt, counts, (int)K);
+  return launch_status("counts_to_float_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+"""``DinoV2ExtractFeatures`` -- the reference's extractor surface
+(reference ``utilities.py:216-288``; distilled copy ``demo/utilities.py:36-101``)
+on top of the hand-written HIP ViT forward (csrc/vit.hip).
+
+Differences from the reference that do not change results:
+  * no ``torch.hub`` download: weights are resolved by ``anyloc_amd.weights``;
+  * the forward stops at the hooked layer and computes only the requested
+    facet's third of that layer's QKV projection (the reference runs all
+    blocks + final norm + head and discards them);
+  * batches ``B > 1`` are processed in one launch sequence.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch.nn import functional as F
+
+from . import _lib, ops, weights
+from .synth import ARCH, PATCH, POS_GRID
+
+_DINO_V2_MODELS = ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14", "dinov2_vitg14")
+_DINO_FACETS = ("query", "key", "value", "token")
+INTERP_OFFSET = 0.1
+
+
+def interpolate_pos_embed(pos_embed, h_img, w_img):
+    """Positional table for an ``h_img x w_img`` input: [1, 1+37*37, D] ->
+    [1 + (h/14)*(w/14), D].  Input-independent, computed once per resolution on
+    the host exactly as facebookresearch/dinov2 ``interpolate_pos_encoding``
+    does: bicubic, align_corners=False, no antialias, ``scale_factor =
+    ((h/14 + 0.1)/37, (w/14 + 0.1)/37)``; skipped for the native square grid."""
+    pos_embed = pos_embed.detach().to("cpu", torch.float32)
+    n_tab = pos_embed.shape[1] - 1
+    gh, gw = h_img // PATCH, w_img // PATCH
+    if gh * gw == n_tab and h_img == w_img:
+        return pos_embed[0].contiguous()
+    m = int(math.sqrt(n_tab))
+    assert m * m == n_tab
+    dim = pos_embed.shape[-1]
+    grid = pos_embed[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=(float(gh + INTERP_OFFSET) / m, float(gw + INTERP_OFFSET) / m),
+                         mode="bicubic", antialias=False)
+    assert tuple(grid.shape[-2:]) == (gh, gw)
+    grid = grid.permute(0, 2, 3, 1).reshape(gh * gw, dim)
+    return torch.cat([pos_embed[0, :1], grid], dim=0).contiguous()
+
+
+class HipDinoV2:
+    """Device-resident DINOv2 weights + the C handle of the HIP forward."""
+
+    def __init__(self, name, state_dict, device, max_layer=None):
+        dim, depth, heads, ffn, hidden = ARCH[name]
+        have = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
+        depth = min(depth, have)
+        if max_layer is not None:
+            depth = min(depth, max_layer + 1)
+        self.name, self.dim, self.depth, self.heads, self.hidden = name, dim, depth, heads, hidden
+        self.ffn_kind = 0 if ffn == "mlp" else 1
+        self.device = device
+        dev = lambda t: t.detach().to(device, torch.float32).contiguous()
+        self._keep = []          # device tensors the C handle points into
+        def keep(t):
+            t = dev(t)
+            self._keep.append(t)
+            return t
+        self.pos_embed_host = state_dict["pos_embed"].detach().to("cpu", torch.float32)
+        self._pos_cache = {}
+        patch_w = keep(state_dict["patch_embed.proj.weight"].reshape(dim, 3 * PATCH * PATCH))
+        patch_b = keep(state_dict["patch_embed.proj.bias"])
+        cls = keep(state_dict["cls_token"].reshape(dim))
+        blocks = (_lib.VitBlockWeights * depth)()
+        for i in range(depth):
+            p = f"blocks.{i}."
+            if self.ffn_kind == 0:
+                fc1_w, fc1_b = state_dict[p + "mlp.fc1.weight"], state_dict[p + "mlp.fc1.bias"]
+                fc2_w, fc2_b = state_dict[p + "mlp.fc2.weight"], state_dict[p + "mlp.fc2.bias"]
+            else:
+                # SwiGLU: interleave gate / value rows in groups of 32 so that one wave's two
+                # 32-column MFMA blocks hold gate[c..c+31] and value[c..c+31] (EPI_SWIGLU)
+                w12, b12 = state_dict[p + "mlp.w12.weight"], state_dict[p + "mlp.w12.bias"]
+                fc1_w = torch.stack([w12[:hidden].reshape(hidden // 32, 32, dim),
+                                     w12[hidden:].reshape(hidden // 32, 32, dim)], 1).reshape(2 * hidden, dim)
+                fc1_b = torch.stack([b12[:hidden].reshape(hidden // 32, 32),
+                                     b12[hidden:].reshape(hidden // 32, 32)], 1).reshape(2 * hidden)
+                fc2_w, fc2_b = state_dict[p + "mlp.w3.weight"], state_dict[p + "mlp.w3.bias"]
+            vals = dict(
+                norm1_w=state_dict[p + "norm1.weight"], norm1_b=state_dict[p + "norm1.bias"],
+                qkv_w=state_dict[p + "attn.qkv.weight"], qkv_b=state_dict[p + "attn.qkv.bias"],
+                proj_w=state_dict[p + "attn.proj.weight"], proj_b=state_dict[p + "attn.proj.bias"],
+                ls1=state_dict[p + "ls1.gamma"],
+                norm2_w=state_dict[p + "norm2.weight"], norm2_b=state_dict[p + "norm2.bias"],
+                fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b, ls2=state_dict[p + "ls2.gamma"])
+            for f in _lib.BLOCK_FIELDS:
+                setattr(blocks[i], f, keep(vals[f]).data_ptr())
+        cfg = _lib.VitConfig(dim, depth, heads, self.ffn_kind, hidden, PATCH, 3 * PATCH * PATCH)
+        self._handle = C.c_void_p()
+        lib = _lib.load()
+        _lib.check(lib.anyloc_vit_create(C.byref(self._handle), C.byref(cfg), _lib.ptr(patch_w),
+                                         _lib.ptr(patch_b), _lib.ptr(cls), blocks), "anyloc_vit_create")
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.load().anyloc_vit_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def pos_table(self, H, W):
+        key = (H, W)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = interpolate_pos_embed(self.pos_embed_host, H, W).to(self.device)
+        return self._pos_cache[key]
+
+    @torch.no_grad()
+    def forward_taps(self, img, taps, use_cls=False, norm_taps=True, norm_concat=False):
+        """img [B,3,H,W] -> [B, N(+1), len(taps)*D]; taps = [(layer, facet_name), ...] ascending."""
+        if img.ndim != 4 or img.shape[1] != 3:
+            raise ValueError(f"expected an image batch [B,3,H,W], got {tuple(img.shape)}")
+        B, _, H, W = img.shape
+        assert H % PATCH == 0, f"Input image height {H} is not a multiple of patch height {PATCH}"
+        assert W % PATCH == 0, f"Input image width {W} is not a multiple of patch width: {PATCH}"
+        img = ops._f32c(img, self.device)
+        taps = sorted(taps, key=lambda t: t[0])
+        for layer, facet in taps:
+            if not 0 <= layer < self.depth:
+                raise IndexError(f"layer {layer} outside the {self.depth} loaded blocks")
+        n_taps = len(taps)
+        np_ = (H // PATCH) * (W // PATCH)
+        rows = np_ + 1 if use_cls else np_
+        out = torch.empty(B, rows, n_taps * self.dim, dtype=torch.float32, device=self.device)
+        if B == 0:
+            return out
+        lib = _lib.load()
+        ws_bytes = lib.anyloc_vit_workspace_bytes(self._handle, B, H, W)
+        ws = _lib.workspace(ws_bytes, self.device, "vit")
+        layers = (C.c_int32 * n_taps)(*[t[0] for t in taps])
+        facets = (C.c_int32 * n_taps)(*[ops.FACETS[t[1]] for t in taps])
+        flags = (ops.VIT_USE_CLS if use_cls else 0) | (ops.VIT_NORM_TAPS if norm_taps else 0) | \
+            (ops.VIT_NORM_CONCAT if norm_concat else 0)
+        _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
+                                          n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
+                                          ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")
+        return out
+
+
+class _NullHandle:
+    """Stands in for the forward-hook handle the reference keeps (``fh_handle``)."""
+    def remove(self):
+        pass
+
+
+class DinoV2ExtractFeatures:
+    """
+        Extract features from an intermediate layer in Dino-v2
+        (same constructor / call signature as reference ``utilities.py:219-288``).
+    """
+    def __init__(self, dino_model: str, layer: int, facet: str = "token", use_cls=False,
+                 norm_descs=True, device: str = "cpu") -> None:
+        if dino_model not in _DINO_V2_MODELS:
+            raise ValueError(f"dino_model must be one of {_DINO_V2_MODELS}")
+        if facet not in _DINO_FACETS:
+            raise ValueError(f"facet must be one of {_DINO_FACETS}")
+        self.vit_type: str = dino_model
+        self.device = torch.device(device)
+        gpu = _lib.require_gpu() if self.device.type != "cuda" else \
+            torch.device("cuda", self.device.index if self.device.index is not None
+                         else torch.cuda.current_device())
+        if self.device.type == "cuda":
+            _lib.require_gpu()
+        self._gpu = gpu
+        self.layer: int = layer
+        self.facet = facet
+        self.dino_model = HipDinoV2(dino_model, weights.resolve_state_dict(dino_model), gpu)
+        if not 0 <= layer < self.dino_model.depth:
+            raise IndexError(f"layer {layer} outside [0, {self.dino_model.depth})")
+        self.fh_handle = _NullHandle()
+        self.use_cls = use_cls
+        self.norm_descs = norm_descs
+        self._hook_out = None
+
+    def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        """
+            Parameters:
+            - img:   The input image batch [B, 3, H, W] (ImageNet-normalised,
+                     H and W multiples of 14).  Returns [B, N(+1), D] on the
+                     input's device.
+        """
+        res = self.dino_model.forward_taps(img, [(self.layer, self.facet)], use_cls=self.use_cls,
+                                           norm_taps=self.norm_descs)
+        return res if img.is_cuda else res.to(img.device)
+
+    def extract_multi(self, img: torch.Tensor, layers, facet=None, norm_concat=True) -> torch.Tensor:
+        """Additive API (one forward, several taps): per-layer facets, each L2-normalised when
+        ``norm_descs``, concatenated on the feature axis ("l n d -> n (l d)") and normalised
+        again -- the multi-layer pattern of reference ``scripts/dino_v2_vlad_viz.py:175-196``,
+        which spends one full forward per layer."""
+        facet = facet or self.facet
+        res = self.dino_model.forward_taps(img, [(l, facet) for l in layers], use_cls=self.use_cls,
+                                           norm_taps=self.norm_descs, norm_concat=norm_concat)
+        return res if img.is_cuda else res.to(img.device)
+
+    def __del__(self):
+        fh = getattr(self, "fh_handle", None)
+        if fh is not None:
+            fh.remove()

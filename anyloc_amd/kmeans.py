@@ -1,0 +1,98 @@
+"""``KMeans`` with the fast-pytorch-kmeans 0.1.6 surface the reference touches
+(``fpk.KMeans(K, mode=...)``, ``.fit``, ``.predict``, ``.centroids`` read AND
+assigned -- reference ``utilities.py:766,772,786-787,849``), iterating on the HIP
+assign+accumulate kernel (csrc/vlad.hip, ``anyloc_kmeans_step``).
+
+Host logic mirrors fpk's ``fit_predict``: init rows drawn with
+``np.random.choice(N, K, replace=False)`` from NumPy's *global* RNG, full-batch
+update ``c = sums / counts`` with empty clusters -> 0 (fpk: NaN -> 0), means not
+re-normalised, stop when ``sum((c_new - c)^2) <= tol`` or after ``max_iter``.
+
+Multi-GPU: rows are sharded over ranks; pass ``process_group`` and
+each iteration all-reduces the [K,D] sums and [K] counts (RCCL over xGMI),
+every rank then computes identical centroids.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def _local_step(x, centroids, mode, want_labels=False):
+    return ops.kmeans_step(x, centroids, mode, want_labels)
+
+
+class KMeans:
+    def __init__(self, n_clusters, max_iter=100, tol=1e-4, verbose=0, mode="euclidean",
+                 minibatch=None, process_group=None, step_fn=None):
+        if mode not in ("cosine", "euclidean"):
+            raise NotImplementedError(f"mode {mode!r}")
+        if minibatch is not None:
+            raise NotImplementedError("minibatch k-means is not used by the reference path")
+        self.n_clusters = n_clusters
+        self.max_iter = max_iter
+        self.tol = tol
+        self.verbose = verbose
+        self.mode = mode
+        self.minibatch = minibatch
+        self.centroids = None
+        self.n_iter_ = 0
+        self.process_group = process_group
+        self._step = step_fn or _local_step       # injectable for CPU tests of the host logic
+
+    # -- helpers ------------------------------------------------------------
+    def _to_dev(self, t):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(t)
+        if self._step is _local_step:
+            return ops._f32c(t, _lib.require_gpu())
+        return t.to(torch.float32)
+
+    def _all_reduce(self, *tensors):
+        if self.process_group is None:
+            return
+        import torch.distributed as dist
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+
+    # -- fpk surface -----------------------------------------------------------
+    def fit_predict(self, X, centroids=None):
+        home = X.device if isinstance(X, torch.Tensor) else torch.device("cpu")
+        x = self._to_dev(X)
+        n = x.shape[0]
+        if centroids is None:
+            if self.process_group is not None:
+                raise ValueError("sharded fit needs explicit initial centroids "
+                                 "(draw the init rows once and broadcast them)")
+            pick = np.random.choice(n, size=[self.n_clusters], replace=False)
+            c = x[torch.as_tensor(pick, device=x.device)].clone()
+        else:
+            c = self._to_dev(centroids).clone()
+        labels = None
+        for it in range(self.max_iter):
+            sums, counts, labels = self._step(x, c, self.mode, True)
+            self._all_reduce(sums, counts)
+            c_new = sums / counts[:, None]
+            c_new = torch.where(counts[:, None] > 0, c_new, torch.zeros_like(c_new))
+            err = ((c_new - c) ** 2).sum()
+            c = c_new
+            self.n_iter_ = it + 1
+            if self.verbose:
+                print(f"iter {it}: error {float(err):.3e}")
+            if float(err) <= self.tol:
+                break
+        self.centroids = c.to(home)
+        return labels.to(home)
+
+    def fit(self, X, centroids=None):
+        self.fit_predict(X, centroids)
+
+    def predict(self, X):
+        if self.centroids is None:
+            raise RuntimeError("KMeans.predict before fit / before centroids were assigned")
+        home = X.device if isinstance(X, torch.Tensor) else torch.device("cpu")
+        x = self._to_dev(X)
+        if x.shape[0] == 0:
+            return torch.empty(0, dtype=torch.int64, device=home)
+        _, _, labels = self._step(x, self._to_dev(self.centroids), self.mode, True)
+        return labels.to(home)

@@ -1,0 +1,187 @@
+"""Tensor-level wrappers over the C ABI (include/anyloc_hip.h).
+
+Every function takes torch tensors that already live on the ROCm device,
+enqueues the HIP kernels on torch's current stream and returns device tensors.
+No arithmetic of the hot path is done by torch here: torch only owns memory.
+"""
+import json
+
+import torch
+
+from . import _lib
+
+VLAD_NORM_DESCS = 1
+VLAD_INTRA_NORM = 2
+FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
+VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT = 1, 2, 4
+
+
+def _f32c(t, device=None):
+    if device is not None and t.device != device:
+        t = t.to(device, non_blocking=True)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.AnylocHipError("anyloc_amd.ops expects device tensors (got a CPU tensor)")
+
+
+def l2norm_rows(x, eps=1e-12, out=None):
+    """F.normalize(x, dim=-1) for a 2-D (or flattened-to-2-D) tensor."""
+    _need_cuda(x)
+    x = _f32c(x)
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    out = torch.empty_like(x2) if out is None else out
+    if x2.numel():
+        lib = _lib.load()
+        _lib.check(lib.anyloc_l2norm_rows(_lib.ptr(x2), _lib.ptr(out), x2.shape[0], x2.shape[1],
+                                          float(eps), _lib.stream_ptr()), "anyloc_l2norm_rows")
+    return out.reshape(shape)
+
+
+def gemm_nt(a, w, bias=None):
+    """a [M,K] @ w[N,K]^T (+ bias) on the fp32 MFMA kernel."""
+    _need_cuda(a, w, bias)
+    a, w = _f32c(a), _f32c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.anyloc_gemm_nt(_lib.ptr(a), K, _lib.ptr(w), K,
+                                  _lib.ptr(_f32c(bias)) if bias is not None else None,
+                                  _lib.ptr(out), N, M, N, K, _lib.stream_ptr()), "anyloc_gemm_nt")
+    return out
+
+
+def layernorm(x, weight, bias, eps=1e-6):
+    _need_cuda(x, weight, bias)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    x2 = x.reshape(-1, x.shape[-1])
+    _lib.check(_lib.load().anyloc_layernorm(_lib.ptr(x2), _lib.ptr(y), _lib.ptr(_f32c(weight)),
+                                            _lib.ptr(_f32c(bias)), x2.shape[0], x2.shape[1], float(eps),
+                                            _lib.stream_ptr()), "anyloc_layernorm")
+    return y
+
+
+def attention(qkv, heads):
+    """qkv [B, T, 3*D] -> [B, T, D]  (softmax((q/8) k^T) v per 64-wide head)."""
+    _need_cuda(qkv)
+    qkv = _f32c(qkv)
+    B, T, D3 = qkv.shape
+    out = torch.empty(B, T, D3 // 3, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().anyloc_attention(_lib.ptr(qkv), _lib.ptr(out), B, T, D3 // 3, heads,
+                                            _lib.stream_ptr()), "anyloc_attention")
+    return out
+
+
+def _offsets_for(tokens_list_or_tensor, device):
+    """-> (packed [total,D] device tensor, offsets int64 device tensor, n_img, D)."""
+    t = tokens_list_or_tensor
+    if isinstance(t, torch.Tensor):
+        if t.ndim == 2:
+            t = t[None]
+        assert t.ndim == 3, f"expected [n_img, n_tok, D], got {tuple(t.shape)}"
+        n_img, n_tok, D = t.shape
+        packed = _f32c(t, device).reshape(n_img * n_tok, D)
+        offsets = torch.arange(n_img + 1, dtype=torch.int64) * n_tok
+    else:
+        parts = [_f32c(torch.as_tensor(p), device) for p in t]
+        n_img = len(parts)
+        D = parts[0].shape[1] if n_img else 0
+        counts = [int(p.shape[0]) for p in parts]
+        packed = torch.cat(parts, 0) if n_img else torch.empty(0, 0, device=device)
+        offsets = torch.zeros(n_img + 1, dtype=torch.int64)
+        if n_img:
+            offsets[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int64), 0)
+    return packed, offsets.to(device), n_img, D
+
+
+def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0,
+         return_labels=False):
+    """VLAD descriptors of a batch of images.
+
+    tokens: device tensor [n_img, N, D] / [N, D], or a list of [N_i, D] tensors.
+    centers: [K, D].  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
+    device = _lib.require_gpu()
+    centers = _f32c(centers, device)
+    K, D = centers.shape
+    packed, offsets, n_img, Dt = _offsets_for(tokens, device)
+    if n_img and packed.numel() and Dt != D:
+        raise ValueError(f"descriptor dim {Dt} != cluster centre dim {D}")
+    total = packed.shape[0]
+    out = torch.empty(n_img, K * D, dtype=torch.float32, device=device)
+    labels = torch.empty(total, dtype=torch.int64, device=device) if (return_labels and mode == "hard") else None
+    lib = _lib.load()
+    flags = (VLAD_NORM_DESCS if norm_descs else 0) | (VLAD_INTRA_NORM if intra_norm else 0)
+    ws_bytes = lib.anyloc_vlad_workspace_bytes(total, n_img, D, K)
+    ws = _lib.workspace(ws_bytes, device, "vlad")
+    if mode == "hard":
+        _lib.check(lib.anyloc_vlad_hard(_lib.ptr(packed), _lib.ptr(offsets), n_img, total, D,
+                                        _lib.ptr(centers), K, flags, _lib.ptr(out), _lib.ptr(labels),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_vlad_hard")
+    elif mode == "soft":
+        _lib.check(lib.anyloc_vlad_soft(_lib.ptr(packed), _lib.ptr(offsets), n_img, total, D,
+                                        _lib.ptr(centers), K, float(soft_temp), flags, _lib.ptr(out),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_vlad_soft")
+    else:
+        raise ValueError(f"vlad mode {mode!r}")
+    return (out, labels) if return_labels else out
+
+
+def kmeans_step(x, centers, mode="cosine", want_labels=False):
+    """One assign + accumulate pass: returns (sums [K,D], counts [K], labels|None)."""
+    _need_cuda(x, centers)
+    x, centers = _f32c(x), _f32c(centers)
+    n, D = x.shape
+    K = centers.shape[0]
+    sums = torch.empty(K, D, dtype=torch.float32, device=x.device)
+    counts = torch.empty(K, dtype=torch.float32, device=x.device)
+    labels = torch.empty(n, dtype=torch.int64, device=x.device) if want_labels else None
+    lib = _lib.load()
+    ws_bytes = lib.anyloc_kmeans_workspace_bytes(n, D, K)
+    ws = _lib.workspace(ws_bytes, x.device, "kmeans")
+    _lib.check(lib.anyloc_kmeans_step(_lib.ptr(x), n, D, _lib.ptr(centers), K,
+                                      0 if mode == "cosine" else 1, _lib.ptr(sums), _lib.ptr(counts),
+                                      _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+               "anyloc_kmeans_step")
+    return sums, counts, labels
+
+
+def topk(queries, db, k, metric="ip", index_base=0):
+    """Exact top-k of db rows for every query: (dist [nq,k] f32, idx [nq,k] i64), best first."""
+    _need_cuda(queries, db)
+    queries, db = _f32c(queries), _f32c(db)
+    nq, dim = queries.shape
+    ndb = db.shape[0]
+    dist = torch.empty(nq, k, dtype=torch.float32, device=queries.device)
+    idx = torch.empty(nq, k, dtype=torch.int64, device=queries.device)
+    lib = _lib.load()
+    ws_bytes = lib.anyloc_topk_workspace_bytes(nq, ndb, dim, k)
+    ws = _lib.workspace(ws_bytes, queries.device, "topk")
+    _lib.check(lib.anyloc_topk(_lib.ptr(queries), nq, _lib.ptr(db), ndb, dim, k,
+                               0 if metric == "ip" else 1, index_base, _lib.ptr(dist), _lib.ptr(idx),
+                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_topk")
+    return dist, idx
+
+
+# ---- profiler ----------------------------------------------------------------
+def profile_enable(on=True):
+    _lib.check(_lib.load().anyloc_profile_enable(1 if on else 0), "anyloc_profile_enable")
+
+
+def profile_reset():
+    _lib.check(_lib.load().anyloc_profile_reset(), "anyloc_profile_reset")
+
+
+def profile_dump():
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.load().anyloc_profile_dump(buf, len(buf)), "anyloc_profile_dump")
+    return json.loads(buf.value.decode())

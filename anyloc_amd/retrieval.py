@@ -1,0 +1,123 @@
+"""``get_top_k_recall`` (reference ``utilities.py:390-469``) on the HIP top-k kernel,
+plus the database-sharded multi-GPU search of SURVEY 8(e).
+
+The faiss flat index (``IndexFlatIP`` / ``IndexFlatL2`` add + search,
+``utilities.py:439-450``) is replaced by csrc/topk.hip; the recall loop
+(``:453-468``) is tiny host-side set arithmetic and stays in NumPy as in the
+reference.
+"""
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def recalls_from_indices(top_k, indices, gt_pos, use_percentage=True, sub_sample_db=1,
+                         sub_sample_qu=1):
+    """Recall@k from retrieved indices (reference utilities.py:451-468)."""
+    indices = np.asarray(indices)
+    recalls = dict(zip(top_k, [0] * len(top_k)))
+    for i_qu, qu_retr in enumerate(indices):
+        for i_rec in top_k:
+            correct_retr = gt_pos[i_qu * sub_sample_qu]
+            if np.any(np.isin(qu_retr[:i_rec] * sub_sample_db, correct_retr)):
+                recalls[i_rec] += 1
+    if use_percentage:
+        for k in recalls:
+            recalls[k] /= len(indices)
+    return recalls
+
+
+def search(db, qu, k, method="cosine", norm_descs=True):
+    """Normalise (optionally) and search: returns device tensors (dist, idx)."""
+    dev = _lib.require_gpu()
+    db_d, qu_d = ops._f32c(db, dev), ops._f32c(qu, dev)
+    if norm_descs:
+        db_d, qu_d = ops.l2norm_rows(db_d), ops.l2norm_rows(qu_d)
+    if method == "cosine":
+        metric = "ip"
+    elif method == "l2":
+        metric = "l2"
+    else:
+        raise NotImplementedError(f"Method: {method}")
+    return ops.topk(qu_d, db_d, int(k), metric)
+
+
+def get_top_k_recall(top_k: List[int], db: torch.Tensor, qu: torch.Tensor, gt_pos: np.ndarray,
+                     method: str = "cosine", norm_descs: bool = True, use_gpu: bool = False,
+                     use_percentage: bool = True, sub_sample_db: int = 1,
+                     sub_sample_qu: int = 1) -> Tuple[np.ndarray, np.ndarray, dict]:
+    """
+        Given a database and query (or queries), get the top 'k' retrievals
+        (closest in database for each query) as indices (in database),
+        distances, and recalls.  Arguments and return values as in the
+        reference; ``use_gpu`` is accepted and ignored (the search always runs
+        on the GPU here).
+    """
+    db, qu = torch.as_tensor(db), torch.as_tensor(qu)
+    if len(qu.shape) == 1:
+        qu = qu.unsqueeze(0)
+    if method not in ("cosine", "l2"):
+        raise NotImplementedError(f"Method: {method}")
+    home = qu.device
+    distances, indices = search(db, qu, max(top_k), method, norm_descs)
+    distances, indices = distances.to(home), indices.to(home)
+    recalls = recalls_from_indices(top_k, indices.cpu().numpy(), gt_pos, use_percentage,
+                                   sub_sample_db, sub_sample_qu)
+    return distances, indices, recalls
+
+
+# ------------------------------------------------------------------ multi-GPU
+def merge_shard_topk(dists, idxs, k, metric="ip"):
+    """k-way merge of per-shard top-k lists (host).  ``dists``/``idxs``: lists of
+    [nq,k] arrays with GLOBAL indices.  Result is identical to one flat index over
+    the concatenated database; ties -> lower global index (as the kernel)."""
+    d = np.concatenate([np.asarray(x) for x in dists], axis=1)
+    i = np.concatenate([np.asarray(x) for x in idxs], axis=1)
+    key = -d if metric == "ip" else d
+    pad = i < 0
+    key = np.where(pad, np.inf, key)
+    tie = np.where(pad, np.iinfo(np.int64).max, i)
+    order = np.lexsort((tie, key), axis=1)[:, :k]
+    return np.take_along_axis(d, order, 1), np.take_along_axis(i, order, 1)
+
+
+def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_descs=True,
+                   group=None, search_fn=None):
+    """Database-sharded retrieval, one process per GPU.
+
+    Every rank owns ``db_shard`` (rows ``shard_base ...`` of the global database)
+    and a slice ``qu_local`` of the queries.  Step 1: all-gather the query
+    descriptors (RCCL over xGMI) so each rank holds all queries; step 2: local
+    top-k on the shard with global indices; step 3: gather the [nq,k] lists on
+    rank 0 and merge on the host.  Returns (dist, idx) numpy arrays on rank 0,
+    (None, None) elsewhere.  ``search_fn`` is injectable for CPU tests of the
+    collective / merge logic."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [torch.zeros(1, dtype=torch.int64, device=qu_local.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([qu_local.shape[0]], dtype=torch.int64,
+                                         device=qu_local.device), group=group)
+    counts = [int(c) for c in counts]
+    mx = max(counts)
+    padded = torch.zeros(mx, qu_local.shape[1], dtype=torch.float32, device=qu_local.device)
+    padded[:qu_local.shape[0]] = qu_local
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded, group=group)
+    qu_all = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0)
+    if search_fn is None:
+        d, i = search(db_shard, qu_all, k, method, norm_descs)
+        i = torch.where(i >= 0, i + shard_base, i)
+    else:
+        d, i = search_fn(db_shard, qu_all, k, method, norm_descs, shard_base)
+    out_d = [torch.empty_like(d) for _ in range(world)] if rank == 0 else None
+    out_i = [torch.empty_like(i) for _ in range(world)] if rank == 0 else None
+    dist.gather(d, out_d, dst=0, group=group)
+    dist.gather(i, out_i, dst=0, group=group)
+    if rank != 0:
+        return None, None
+    return merge_shard_topk([x.cpu().numpy() for x in out_d], [x.cpu().numpy() for x in out_i], k,
+                            "ip" if method == "cosine" else "l2")

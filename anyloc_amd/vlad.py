@@ -1,0 +1,272 @@
+"""``VLAD`` -- the reference's aggregation class (reference ``utilities.py:624-1008``;
+distilled copy ``demo/utilities.py``) with every arithmetic step on the HIP
+kernels of csrc/vlad.hip.  Same constructor, attributes, methods, prints,
+asserts and cache-file protocol as the reference; CPU tensors in -> CPU tensors
+out (the reference's callers pass ``ret.cpu()`` and call ``.numpy()`` on the
+result), device tensors in -> device tensors out (additive fast path).
+"""
+import os
+from typing import List, Union
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .kmeans import KMeans
+
+
+def _as_tensor(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x).to(torch.float32)
+    return x
+
+
+class VLAD:
+    """
+        An implementation of VLAD algorithm given database and query
+        descriptors (constructor arguments as in the reference):
+        num_clusters, desc_dim, intra_norm, norm_descs, dist_mode
+        ('euclidean' | 'cosine'), vlad_mode ('soft' | 'hard'), soft_temp,
+        cache_dir.
+    """
+    def __init__(self, num_clusters: int, desc_dim: Union[int, None] = None,
+                 intra_norm: bool = True, norm_descs: bool = True, dist_mode: str = "cosine",
+                 vlad_mode: str = "hard", soft_temp: float = 1.0,
+                 cache_dir: Union[str, None] = None) -> None:
+        self.num_clusters = num_clusters
+        self.desc_dim = desc_dim
+        self.intra_norm = intra_norm
+        self.norm_descs = norm_descs
+        self.mode = dist_mode
+        self.vlad_mode = str(vlad_mode).lower()
+        assert self.vlad_mode in ['soft', 'hard']
+        self.soft_temp = soft_temp
+        # Set in the training phase
+        self.c_centers = None
+        self.kmeans = None
+        # Set the caching
+        self.cache_dir = cache_dir
+        if self.cache_dir is not None:
+            self.cache_dir = os.path.abspath(os.path.expanduser(self.cache_dir))
+            if not os.path.exists(self.cache_dir):
+                os.makedirs(self.cache_dir)
+                print(f"Created cache directory: {self.cache_dir}")
+            else:
+                print("Warning: Cache directory already exists: " f"{self.cache_dir}")
+        else:
+            print("VLAD caching is disabled.")
+
+    # ---------------------------------------------------------------- caches
+    def can_use_cache_vlad(self):
+        """True iff the cache directory exists and holds ``c_centers.pt``."""
+        if self.cache_dir is None:
+            return False
+        if not os.path.exists(self.cache_dir):
+            return False
+        return os.path.exists(f"{self.cache_dir}/c_centers.pt")
+
+    def can_use_cache_ids(self, cache_ids: Union[List[str], str, None],
+                          only_residuals: bool = False) -> bool:
+        """True iff every cache id has ``<id>_r.pt`` and (unless
+        ``only_residuals``) ``<id>_l.pt`` (hard) / ``<id>_s.pt`` (soft)."""
+        if not self.can_use_cache_vlad():
+            return False
+        if cache_ids is None:
+            return False
+        if isinstance(cache_ids, str):
+            cache_ids = [cache_ids]
+        for cache_id in cache_ids:
+            if not os.path.exists(f"{self.cache_dir}/{cache_id}_r.pt"):
+                return False
+            if self.vlad_mode == "hard" and not os.path.exists(
+                    f"{self.cache_dir}/{cache_id}_l.pt") and not only_residuals:
+                return False
+            if self.vlad_mode == "soft" and not os.path.exists(
+                    f"{self.cache_dir}/{cache_id}_s.pt") and not only_residuals:
+                return False
+        return True
+
+    # ------------------------------------------------------------ vocabulary
+    def fit(self, train_descs: Union[np.ndarray, torch.Tensor, None]):
+        """Build (or restore from ``cache_dir/c_centers.pt``) the cluster centres."""
+        self.kmeans = KMeans(self.num_clusters, mode=self.mode)
+        if self.can_use_cache_vlad():
+            print("Using cached cluster centers")
+            self.c_centers = torch.load(f"{self.cache_dir}/c_centers.pt")
+            self.kmeans.centroids = self.c_centers
+            if self.desc_dim is None:
+                self.desc_dim = self.c_centers.shape[1]
+                print(f"Desc dim set to {self.desc_dim}")
+        else:
+            if train_descs is None:
+                raise ValueError("No training descriptors given")
+            train_descs = _as_tensor(train_descs)
+            if self.desc_dim is None:
+                self.desc_dim = train_descs.shape[1]
+            home = train_descs.device
+            x = ops._f32c(train_descs, _lib.require_gpu())
+            if self.norm_descs:
+                x = ops.l2norm_rows(x)
+            self.kmeans.fit(x)
+            self.kmeans.centroids = self.kmeans.centroids.to(home)
+            self.c_centers = self.kmeans.centroids
+            if self.cache_dir is not None:
+                print("Caching cluster centers")
+                torch.save(self.c_centers, f"{self.cache_dir}/c_centers.pt")
+
+    def fit_and_generate(self, train_descs: Union[np.ndarray, torch.Tensor]) -> torch.Tensor:
+        """``fit`` on [num_imgs, num_descs, desc_dim] then VLADs of every image."""
+        train_descs = _as_tensor(train_descs)
+        self.fit(train_descs.reshape(-1, train_descs.shape[-1]))
+        return self.generate_multi(train_descs)
+
+    # ------------------------------------------------------------- generation
+    def _check_fitted(self):
+        assert self.kmeans is not None
+        assert self.c_centers is not None
+
+    def _centers_dev(self):
+        dev = _lib.require_gpu()
+        c = self.c_centers
+        cached = getattr(self, "_c_dev", None)
+        if cached is None or cached[0] is not c:
+            self._c_dev = (c, ops._f32c(c, dev))
+        return self._c_dev[1]
+
+    def _cached_paths(self, cache_id):
+        base = f"{self.cache_dir}/{cache_id}"
+        return base + "_r.pt", base + "_l.pt", base + "_s.pt"
+
+    def _from_cache(self, cache_id):
+        """Rebuild one VLAD from ``<id>_r.pt`` (+ ``_l`` / ``_s``) exactly as the reference
+        does when a cache hit occurs (utilities.py:843-847, :864-868, :951-954): a restore path,
+        not the hot path -- the stored [N,K,D] residual tensor is reduced with torch on the GPU."""
+        r_path, l_path, s_path = self._cached_paths(cache_id)
+        dev = _lib.require_gpu()
+        residuals = torch.load(r_path).to(dev, torch.float32)       # [N,K,D]
+        K, D = self.num_clusters, self.desc_dim
+        un_vlad = torch.zeros(K, D, device=dev)
+        if self.vlad_mode == "hard":
+            labels = torch.load(l_path).to(dev) if os.path.isfile(l_path) else None
+            if labels is None:
+                return None
+            picked = residuals[torch.arange(residuals.shape[0], device=dev), labels]   # [N,D]
+            un_vlad.index_add_(0, labels, picked)
+        else:
+            soft = torch.load(s_path).to(dev, torch.float32) if os.path.isfile(s_path) else None
+            if soft is None:
+                return None
+            # reference quirk: block k sums w[q,k] * residual over ALL clusters c (utilities.py:881-884)
+            un_vlad = torch.einsum("qk,qd->kd", soft, residuals.sum(1))
+        if self.intra_norm:
+            un_vlad = ops.l2norm_rows(un_vlad)
+        return ops.l2norm_rows(un_vlad.reshape(1, K * D))[0].cpu()
+
+    def _write_cache(self, cache_id, descs_home):
+        """Store what the reference stores when ``cache_id`` is given and the cache dir is valid
+        (utilities.py:850-852, :876-878, :963-970): residuals [N,K,D], labels / soft weights."""
+        r_path, l_path, s_path = self._cached_paths(cache_id)
+        cid_dir = f"{self.cache_dir}/" f"{os.path.split(cache_id)[0]}"
+        if not os.path.isdir(cid_dir):
+            os.makedirs(cid_dir)
+            print(f"Created directory: {cid_dir}")
+        dev = _lib.require_gpu()
+        x = ops._f32c(descs_home, dev)
+        xh = ops.l2norm_rows(x) if self.norm_descs else x
+        c = self._centers_dev()
+        if not os.path.isfile(r_path):
+            torch.save((xh[:, None, :] - c[None, :, :]).cpu(), r_path)
+        if self.vlad_mode == "hard":
+            if not os.path.isfile(l_path):
+                torch.save(self.kmeans.predict(x).cpu(), l_path)
+        elif not os.path.isfile(s_path):
+            cos = torch.nn.functional.cosine_similarity(x[:, None, :], c[None, :, :], dim=2)
+            torch.save(torch.softmax(self.soft_temp * cos, dim=1).cpu(), s_path)
+
+    def _generate_batch(self, multi_query):
+        """[n_img,N,D] tensor or list of [N_i,D] -> [n_img, K*D] on the inputs' device."""
+        first = multi_query[0] if not isinstance(multi_query, torch.Tensor) else multi_query
+        first = _as_tensor(first)
+        home = first.device
+        if not isinstance(multi_query, torch.Tensor):
+            multi_query = [_as_tensor(q) for q in multi_query]
+        out = ops.vlad(multi_query, self._centers_dev(), mode=self.vlad_mode,
+                       norm_descs=self.norm_descs, intra_norm=self.intra_norm,
+                       soft_temp=self.soft_temp)
+        return out if home.type == "cuda" else out.to(home)
+
+    def generate(self, query_descs: Union[np.ndarray, torch.Tensor],
+                 cache_id: Union[str, None] = None) -> torch.Tensor:
+        """VLAD of one image: [n_q, desc_dim] -> [num_clusters * desc_dim]."""
+        self._check_fitted()
+        if self.desc_dim is None:
+            self.desc_dim = self.c_centers.shape[1]
+        if cache_id is not None and self.can_use_cache_vlad():
+            r_path, _, _ = self._cached_paths(cache_id)
+            if os.path.isfile(r_path):
+                res = self._from_cache(cache_id)
+                if res is not None:
+                    return res
+            if query_descs is not None:
+                self._write_cache(cache_id, _as_tensor(query_descs))
+        if query_descs is None:
+            raise ValueError(f"no descriptors given and no usable cache for {cache_id!r}")
+        return self._generate_batch(_as_tensor(query_descs)[None])[0]
+
+    def generate_multi(self, multi_query: Union[np.ndarray, torch.Tensor, list],
+                       cache_ids: Union[List[str], None] = None) -> Union[torch.Tensor, list]:
+        """VLADs of several images ([n_imgs, n_kpts, d] tensor or a list of
+        [n_kpts_i, d]); one batched launch when no cache ids are involved."""
+        self._check_fitted()
+        if cache_ids is None or all(c is None for c in cache_ids) or not self.can_use_cache_vlad():
+            if len(multi_query) == 0:
+                return torch.empty(0, self.num_clusters * (self.desc_dim or 0))
+            if isinstance(multi_query, np.ndarray):
+                multi_query = torch.from_numpy(multi_query).to(torch.float32)
+            return self._generate_batch(multi_query)
+        res = [self.generate(q, c) for (q, c) in zip(multi_query, cache_ids)]
+        try:
+            res = torch.stack(res)
+        except TypeError:
+            try:
+                res = np.stack(res)
+            except TypeError:
+                pass
+        return res
+
+    def generate_res_vec(self, query_descs: Union[np.ndarray, torch.Tensor],
+                         cache_id: Union[str, None] = None) -> torch.Tensor:
+        """Residual tensor [n_q, n_c, d] = normalise(q)[:,None,:] - c_centers[None] (reference
+        utilities.py:928-972).  Kept for surface parity: the HIP VLAD path never materialises
+        it; this method does, on request, with a broadcast subtraction on the device."""
+        self._check_fitted()
+        if cache_id is not None and self.can_use_cache_vlad() and \
+                os.path.isfile(f"{self.cache_dir}/{cache_id}_r.pt"):
+            return torch.load(f"{self.cache_dir}/{cache_id}_r.pt")
+        query_descs = _as_tensor(query_descs)
+        home = query_descs.device
+        x = ops._f32c(query_descs, _lib.require_gpu())
+        if self.norm_descs:
+            x = ops.l2norm_rows(x)
+        residuals = (x[:, None, :] - self._centers_dev()[None, :, :]).to(home)
+        if cache_id is not None and self.can_use_cache_vlad():
+            cid_dir = f"{self.cache_dir}/" f"{os.path.split(cache_id)[0]}"
+            if not os.path.isdir(cid_dir):
+                os.makedirs(cid_dir)
+                print(f"Created directory: {cid_dir}")
+            torch.save(residuals, f"{self.cache_dir}/{cache_id}_r.pt")
+        return residuals
+
+    def generate_multi_res_vec(self, multi_query: Union[np.ndarray, torch.Tensor, list],
+                               cache_ids: Union[List[str], None] = None) -> Union[torch.Tensor, list]:
+        if cache_ids is None:
+            cache_ids = [None] * len(multi_query)
+        res = [self.generate_res_vec(q, c) for (q, c) in zip(multi_query, cache_ids)]
+        try:
+            res = torch.stack(res)
+        except (TypeError, RuntimeError):
+            try:
+                res = np.stack(res)
+            except (TypeError, ValueError):
+                pass
+        return res

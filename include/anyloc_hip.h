@@ -1,0 +1,204 @@
+/*
+ * anyloc_hip.h -- C ABI of libanyloc_hip.so: hand-written HIP (gfx950 / CDNA4)
+ * kernels for the AnyLoc-VLAD-DINOv2 hot path.
+ *
+ * The reference (AnyLoc/AnyLoc) is 100 % Python; its "operator boundary" for
+ * this path is the class surface of utilities.py.  Each entry point below
+ * names the reference interface (file:line under the reference tree) whose
+ * arithmetic it replaces.  The Python host in anyloc_amd/ binds these with
+ * ctypes (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-owned memory unless the
+ *     parameter is documented "host"; the library never returns memory it
+ *     allocated; sizes are explicit; tensors are dense row-major fp32 unless
+ *     stated; indices / labels are int64 (the reference's torch.long).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     work is enqueued on it; no call synchronises the device.
+ *   - scratch space is caller-provided: query the size with the matching
+ *     *_workspace_bytes() and pass a buffer at least that large.
+ *   - return value: 0 on success, a negative anyloc_status otherwise;
+ *     anyloc_last_error() returns a thread-local description of the last
+ *     failure.  No C++ exception crosses the ABI.
+ */
+#ifndef ANYLOC_HIP_H
+#define ANYLOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANYLOC_ABI_VERSION 1
+
+typedef enum anyloc_status {
+  ANYLOC_OK = 0,
+  ANYLOC_ERR_INVALID_ARG = -1,   /* bad shape / null pointer / unsupported value */
+  ANYLOC_ERR_WORKSPACE = -2,     /* workspace too small */
+  ANYLOC_ERR_HIP = -3,           /* a HIP runtime call or kernel launch failed */
+  ANYLOC_ERR_UNSUPPORTED = -4    /* valid request this build cannot serve */
+} anyloc_status;
+
+int anyloc_version(void);
+const char* anyloc_last_error(void);
+
+/* ---------------------------------------------------------------- rows ---
+ * out[r,:] = x[r,:] / max(||x[r,:]||_2, eps)      (torch F.normalize, eps 1e-12)
+ * replaces: F.normalize calls at utilities.py:283, :436-437, :785, :960.
+ * x and out may alias. */
+int anyloc_l2norm_rows(const float* x, float* out, int64_t rows, int64_t dim,
+                       float eps, void* stream);
+
+/* ------------------------------------------------------------- matmul ----
+ * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N] when bias != NULL): the fp32 MFMA GEMM
+ * all dense contractions of the path run on (torch Linear layout: both
+ * operands K-contiguous).  lda/ldw/ldc are row strides in floats.  Requires
+ * K % 4 == 0 and 16-byte aligned rows.  Exposed for tests/benchmarks. */
+int anyloc_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw,
+                   const float* bias, float* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, void* stream);
+
+/* Building blocks of the ViT forward, exposed for unit tests:
+ * LayerNorm over the last dim (eps as given; DINOv2 uses 1e-6) and multi-head
+ * self-attention softmax((q/8) k^T) v with head_dim 64 on a packed QKV buffer
+ * [B*T, 3*D] (q | k | v, heads contiguous) -> out [B*T, D]. */
+int anyloc_layernorm(const float* x, float* y, const float* weight, const float* bias,
+                     int64_t rows, int64_t dim, float eps, void* stream);
+int anyloc_attention(const float* qkv, float* out, int64_t batch, int64_t tokens,
+                     int64_t dim, int64_t heads, void* stream);
+
+/* --------------------------------------------------------------- VLAD ----
+ * Hard-assignment VLAD of `n_img` images in one call.
+ * replaces: VLAD.generate / generate_multi / generate_res_vec (hard mode),
+ *   utilities.py:819-861, :888-890, :892-926, :928-972.
+ *   tokens   [total_tokens, D]   patch descriptors of all images, packed
+ *   offsets  [n_img + 1] int64   image i owns token rows offsets[i]..offsets[i+1]
+ *                                 (ragged images allowed, empty images allowed)
+ *   centers  [K, D]              raw k-means centroids (c_centers)
+ *   out      [n_img, K*D]        normalised VLAD descriptors
+ *   labels   [total_tokens] int64 or NULL: hard assignment of every token
+ * flags: ANYLOC_VLAD_NORM_DESCS re-normalises tokens before the residual
+ *   (utilities.py:959-960); ANYLOC_VLAD_INTRA_NORM normalises each cluster
+ *   block (:859-860).  Labels are argmax_k of the fast-pytorch-kmeans cosine
+ *   score of the tokens as passed (:849) -- ties -> lowest k. */
+#define ANYLOC_VLAD_NORM_DESCS 1u
+#define ANYLOC_VLAD_INTRA_NORM 2u
+size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img,
+                                   int64_t D, int64_t K);
+int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
+                     int64_t total_tokens, int64_t D, const float* centers,
+                     int64_t K, unsigned flags, float* out, int64_t* labels,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Soft-assignment VLAD with the reference's summation (utilities.py:862-887):
+ * block k = sum_q sum_c softmax(temp*cos(x_q,c))[q,k] * (xhat_q - c_c). */
+int anyloc_vlad_soft(const float* tokens, const int64_t* offsets, int64_t n_img,
+                     int64_t total_tokens, int64_t D, const float* centers,
+                     int64_t K, float soft_temp, unsigned flags, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------ k-means ----
+ * One fast-pytorch-kmeans iteration (cosine or euclidean mode):
+ *   labels[n] = argmax_k sim(x_n, c_k);  sums[k,:] = sum_{labels[n]==k} x_n;
+ *   counts[k] = #{n : labels[n]==k}.
+ * replaces: fpk KMeans.fit_predict loop body reached from VLAD.fit,
+ *   utilities.py:766, :786 (and predict at :849).  The division by counts, the
+ *   NaN->0 rule, the tolerance test and (multi-GPU) the all-reduce of
+ *   sums/counts are done by the host (anyloc_amd/kmeans.py).
+ *   mode 0 = cosine (rows/(norm+1e-8)), 1 = euclidean (2ab - a^2 - b^2). */
+size_t anyloc_kmeans_workspace_bytes(int64_t n, int64_t D, int64_t K);
+int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* centers,
+                       int64_t K, int mode, float* sums, float* counts,
+                       int64_t* labels, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* -------------------------------------------------------------- top-k ----
+ * Exact brute-force search of `nq` queries against `ndb` database rows.
+ * replaces: faiss IndexFlatIP / IndexFlatL2 add + search,
+ *   utilities.py:439-450 (called from get_top_k_recall).
+ *   metric 0: inner product, best = largest;  1: squared L2, best = smallest.
+ *   dist [nq,k] fp32 and idx [nq,k] int64, best first; idx = index_base + row.
+ *   If k > ndb the tail is padded with idx -1 (faiss behaviour).
+ *   Ties are broken towards the lower database index. */
+size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k);
+int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb,
+                int64_t dim, int64_t k, int metric, int64_t index_base,
+                float* dist, int64_t* idx, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- ViT ----
+ * DINOv2 ViT forward with early exit at the last tapped layer.
+ * replaces: DinoV2ExtractFeatures.__call__, utilities.py:263-285 (the hub
+ *   model forward at :269, the hooked facet at :270-281, F.normalize at :283).
+ * Weights are caller-owned device tensors in torch Linear layout
+ * ([out,in] row-major), handed over once at creation; the handle stores the
+ * pointers, it does not copy.  */
+typedef struct anyloc_vit anyloc_vit_t;
+
+typedef struct anyloc_vit_block_weights {
+  const float *norm1_w, *norm1_b;       /* [D] */
+  const float *qkv_w, *qkv_b;           /* [3D,D], [3D] */
+  const float *proj_w, *proj_b;         /* [D,D], [D] */
+  const float *ls1;                     /* [D] LayerScale gamma */
+  const float *norm2_w, *norm2_b;       /* [D] */
+  /* ffn_kind 0 (mlp):   fc1 [H,D],[H]; fc2 [D,H],[D]
+   * ffn_kind 1 (swiglu): fc1 = w12 with rows pair-interleaved per 64 outputs
+   *   (32 gate rows then the 32 matching value rows) [2H,D],[2H]; fc2 = w3 */
+  const float *fc1_w, *fc1_b;
+  const float *fc2_w, *fc2_b;
+  const float *ls2;                     /* [D] */
+} anyloc_vit_block_weights;
+
+typedef struct anyloc_vit_config {
+  int32_t dim;          /* D: 384 / 768 / 1024 / 1536 */
+  int32_t depth;        /* number of blocks supplied */
+  int32_t heads;        /* head_dim must be 64 */
+  int32_t ffn_kind;     /* 0 = mlp (exact GELU), 1 = swiglu */
+  int32_t ffn_hidden;   /* H */
+  int32_t patch;        /* 14 */
+  int32_t patch_k_pad;  /* row length of patch_w (3*14*14=588 padded to a multiple of 4; zeros) */
+} anyloc_vit_config;
+
+int anyloc_vit_create(anyloc_vit_t** out, const anyloc_vit_config* cfg /*host*/,
+                      const float* patch_w /*[D,patch_k_pad]*/, const float* patch_b,
+                      const float* cls_token /*[D]*/,
+                      const anyloc_vit_block_weights* blocks /*host array [depth]*/);
+void anyloc_vit_destroy(anyloc_vit_t* h);
+
+/* facets (reference _DINO_FACETS, utilities.py:218) */
+#define ANYLOC_FACET_QUERY 0
+#define ANYLOC_FACET_KEY 1
+#define ANYLOC_FACET_VALUE 2
+#define ANYLOC_FACET_TOKEN 3
+/* forward flags */
+#define ANYLOC_VIT_USE_CLS 1u        /* keep the CLS row (utilities.py:270-273) */
+#define ANYLOC_VIT_NORM_TAPS 2u      /* L2-normalise each tap (utilities.py:282-283) */
+#define ANYLOC_VIT_NORM_CONCAT 4u    /* L2-normalise the concatenated taps again
+                                        (scripts/dino_v2_vlad_viz.py:175-196) */
+
+size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch,
+                                  int64_t img_h, int64_t img_w);
+/*   img  [B,3,H,W]  ImageNet-normalised, H and W multiples of 14
+ *   pos  [1+N, D]   positional table already interpolated for (H,W), row 0 = CLS
+ *   tap_layers / tap_facets: host arrays of n_taps entries, layers ascending
+ *   out  [B, N (+1 with USE_CLS), n_taps*D]  taps concatenated on the feature axis */
+int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch,
+                       int64_t img_h, int64_t img_w, const float* pos,
+                       int32_t n_taps, const int32_t* tap_layers,
+                       const int32_t* tap_facets, unsigned flags, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Name and average device time (ms, HIP events on the launch stream) of the
+ * kernels issued by the most recent call with profiling enabled; used by
+ * bench.py for the live roofline figure.  enable: 0/1. */
+int anyloc_profile_enable(int enable);
+int anyloc_profile_reset(void);
+/* writes up to `cap` bytes of a JSON object {"kernel": {"calls":n,"ms":t,"flops":f,"bytes":b}, ...} */
+int anyloc_profile_dump(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANYLOC_HIP_H */

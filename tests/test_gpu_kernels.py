@@ -1,0 +1,86 @@
+"""Unit parity of the HIP building blocks against fp64 / torch references (GPU box only).
+Called through the C ABI (anyloc_amd.ops -> ctypes -> libanyloc_hip.so)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from anyloc_amd import _lib
+    _lib.load()
+    return torch.device("cuda")
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (129, 384, 588), (1000, 32, 96), (64, 17, 40),
+                                   (257, 130, 36), (1, 128, 4), (4240, 1536, 1536), (530, 8192, 1536)])
+def test_gemm_nt(dev, M, N, K):
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)          # asymmetric operands: a transposed C would fail
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().T + bias.double()
+    out = ops.gemm_nt(a.to(dev), w.to(dev), bias.to(dev)).cpu()
+    assert out.shape == (M, N)
+    # fp32 fma chain vs fp64: error ~ 1e-7 * sum|a||b|
+    bound = 4e-7 * (a.abs().double() @ w.abs().double().T) + 1e-6
+    assert bool(((out.double() - ref).abs() <= bound).all()), _rel(out, ref)
+    out2 = ops.gemm_nt(a.to(dev), w.to(dev)).cpu()
+    assert bool(((out2.double() - (ref - bias.double())).abs() <= bound).all())
+
+
+def test_gemm_identity_is_exact(dev):
+    """A = I picks rows of W exactly (catches operand/accumulator layout swaps)."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(160, 192, generator=g)
+    eye = torch.eye(192)
+    out = ops.gemm_nt(eye.to(dev), w.to(dev)).cpu()     # [192,160] = W^T
+    assert torch.equal(out, w.T.contiguous())
+
+
+@pytest.mark.parametrize("rows,dim", [(7, 384), (529, 1536), (3, 49152), (5, 10), (2, 6)])
+def test_l2norm_rows(dev, rows, dim):
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(rows + dim)
+    x = torch.randn(rows, dim, generator=g) * 3
+    x[0] = 0                                            # zero row stays zero (eps clamp)
+    out = ops.l2norm_rows(x.to(dev)).cpu()
+    ref = torch.nn.functional.normalize(x.double(), dim=-1)
+    assert _rel(out, ref) < 5e-7
+    assert torch.equal(out[0], torch.zeros(dim))
+
+
+@pytest.mark.parametrize("rows,dim", [(11, 384), (530, 1536), (9, 1024)])
+def test_layernorm(dev, rows, dim):
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(rows * dim)
+    x = torch.randn(rows, dim, generator=g) * 2 + 0.5
+    w, b = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    out = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6).cpu()
+    ref = torch.nn.functional.layer_norm(x.double(), (dim,), w.double(), b.double(), 1e-6)
+    assert float((out.double() - ref).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("B,T,heads", [(2, 257, 6), (1, 530, 24), (3, 33, 2), (1, 128, 1), (2, 1370, 2)])
+def test_attention(dev, B, T, heads):
+    from anyloc_amd import ops
+    D = heads * 64
+    g = torch.Generator().manual_seed(B * T + heads)
+    qkv = torch.randn(B, T, 3 * D, generator=g) * 1.5
+    qkv[0, 3, :D] *= 6.0      # a spiky query/key pair: forces the running-max rescale path
+    qkv[0, T - 2, D:2 * D] *= 6.0
+    out = ops.attention(qkv.to(dev), heads).cpu()
+    q, k, v = qkv.double().reshape(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q * 0.125) @ k.transpose(-2, -1), dim=-1)
+    ref = (a @ v).transpose(1, 2).reshape(B, T, D)
+    assert float((out.double() - ref).abs().max()) < 2e-5, float((out.double() - ref).abs().max())
+    assert _rel(out, ref) < 5e-6

@@ -1,0 +1,186 @@
+"""Parity of the HIP VLAD / k-means / top-k path (through the C ABI) against the golden
+vectors recorded from the reference and against the CPU oracle on seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from anyloc_amd import synth
+from oracle import faiss_flat, vlad_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+VLAD_RTOL = 1e-5      # north_star: VLAD descriptors within 1e-5 relative (L2-relative, fp32)
+
+
+def l2rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def check_labels(lab, lab_ref, x, centers, gap_tol=1e-6):
+    """Cluster ids bit-exact; a differing id is tolerated only if the oracle's top-2 cosine
+    gap for that token is below fp32 resolution (SURVEY section 7 'Argmax bit-exactness')."""
+    lab, lab_ref = torch.as_tensor(lab).cpu().long(), torch.as_tensor(lab_ref).cpu().long()
+    bad = (lab != lab_ref).nonzero().flatten()
+    if len(bad) == 0:
+        return 0
+    sc = vlad_ref.fpk_cosine_scores(x.reshape(-1, x.shape[-1])[bad].cpu(), centers.cpu())
+    top2 = sc.topk(2, dim=1)[0]
+    gap = top2[:, 0] - top2[:, 1]
+    assert float(gap.max()) < gap_tol, f"{len(bad)} label flips, largest oracle gap {float(gap.max()):.3e}"
+    return len(bad)
+
+
+@pytest.mark.parametrize("tag", ["c2_n529_d1536_k32", "c5_n1369_d1024_k64"])
+def test_vlad_hard_golden(golden_dir, tag):
+    from anyloc_amd import ops
+    g = np.load(os.path.join(golden_dir, f"vlad_{tag}.npz"))
+    x = synth.clustered_tokens(int(g["n_img"]), int(g["N"]), int(g["D"]), n_modes=int(g["K"]) + 5,
+                               seed=int(g["seed"]))
+    centers = torch.from_numpy(g["centers"])
+    out, lab = ops.vlad(x.to(DEV), centers.to(DEV), return_labels=True)
+    assert check_labels(lab.reshape(x.shape[0], -1), g["labels"].astype(np.int64), x, centers) == 0
+    for i in range(x.shape[0]):
+        assert l2rel(out[i], g["vlads"][i]) < VLAD_RTOL
+    xr = x * torch.from_numpy(g["scale"])[:, :, None]
+    out_r = ops.vlad(xr.to(DEV), centers.to(DEV))
+    for i in range(x.shape[0]):
+        assert l2rel(out_r[i], g["vlads_raw"][i]) < VLAD_RTOL
+    # unused clusters are exact zero blocks (reference utilities.py:840,854-861)
+    K, D = centers.shape
+    used = set(g["labels"][0].tolist())
+    for k in range(K):
+        if k not in used:
+            assert float(out[0, k * D:(k + 1) * D].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("K,D,N", [(8, 384, 256), (32, 1536, 529), (64, 1024, 300), (5, 64, 77), (128, 128, 500)])
+def test_vlad_hard_vs_oracle_flags_and_ragged(K, D, N):
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(K * D + N)
+    x = synth.clustered_tokens(4, N, D, n_modes=K, seed=K + N) * (0.5 + torch.rand(4, N, 1, generator=g))
+    centers = 0.7 * synth.clustered_tokens(1, K, D, n_modes=K, seed=K + N)[0] + 0.01 * torch.randn(K, D, generator=g)
+    for norm_descs, intra in ((True, True), (False, True), (True, False)):
+        out, lab = ops.vlad(x.to(DEV), centers.to(DEV), norm_descs=norm_descs, intra_norm=intra,
+                            return_labels=True)
+        for i in range(4):
+            v, l = vlad_ref.vlad_hard(x[i], centers, norm_descs, intra)
+            check_labels(lab[i * N:(i + 1) * N], l, x[i], centers)
+            assert l2rel(out[i], v) < VLAD_RTOL
+    # ragged list with an empty image and a single-token image
+    parts = [x[0, :N // 2], x[1, :0], x[2, :1], x[3]]
+    out = ops.vlad([p.to(DEV) for p in parts], centers.to(DEV))
+    assert out.shape == (4, K * D)
+    assert float(out[1].abs().max()) == 0.0
+    for i in (0, 2, 3):
+        assert l2rel(out[i], vlad_ref.vlad_hard(parts[i], centers)[0]) < VLAD_RTOL
+
+
+def test_vlad_soft_vs_oracle():
+    from anyloc_amd import ops
+    K, D, N = 8, 384, 256
+    x = synth.clustered_tokens(2, N, D, n_modes=K, seed=3)
+    g = torch.Generator().manual_seed(9)
+    centers = 0.7 * synth.clustered_tokens(1, K, D, n_modes=K, seed=3)[0] + 0.01 * torch.randn(K, D, generator=g)
+    for temp in (1.0, 7.5):
+        out = ops.vlad(x.to(DEV), centers.to(DEV), mode="soft", soft_temp=temp)
+        for i in range(2):
+            ref = vlad_ref.vlad_soft(x[i], centers, temp)[0]
+            assert l2rel(out[i], ref) < 5e-5, l2rel(out[i], ref)
+
+
+def test_kmeans_golden_and_oracle(golden_dir):
+    from anyloc_amd import kmeans as hk
+    g = np.load(os.path.join(golden_dir, "kmeans_n20000_d64_k16.npz"))
+    x = synth.clustered_tokens(1, int(g["n"]), int(g["D"]), n_modes=int(g["K"]), seed=int(g["seed"]), noise=0.6)[0]
+    km = hk.KMeans(int(g["K"]), mode="cosine")
+    xn = torch.nn.functional.normalize(x)
+    labels = km.fit_predict(xn.to(DEV), centroids=xn[torch.from_numpy(g["init_idx"])].to(DEV))
+    assert km.n_iter_ == int(g["iters"])
+    assert l2rel(km.centroids, g["centers"]) < 1e-5
+    ref_lab = vlad_ref.hard_labels(xn, torch.from_numpy(g["centers"]))
+    assert int((labels.cpu() != ref_lab).sum()) <= 2
+    # euclidean mode + empty clusters vs the oracle, one step
+    from anyloc_amd import ops
+    from oracle.fpk_kmeans import KMeans as RefKM
+    c = torch.cat([x[:5], 50 + torch.zeros(2, x.shape[1])])      # two centres nobody picks
+    sums, counts, lab = ops.kmeans_step(x.to(DEV), c.to(DEV), "euclidean", True)
+    ref_lab = RefKM.euc_sim(x, c).max(dim=-1)[1]
+    assert int((lab.cpu() != ref_lab).sum()) <= 2
+    onehot = (ref_lab[None] == torch.arange(7)[:, None]).float()
+    assert torch.equal(counts.cpu(), onehot.sum(-1))
+    assert l2rel(sums, onehot.double() @ x.double()) < 1e-6
+    assert float(counts[5:].sum()) == 0.0
+
+
+def test_vlad_fit_surface_matches_reference_semantics(golden_dir, capsys):
+    """utilities.VLAD.fit -> generate_multi on CPU tensors (the reference's calling convention)."""
+    import utilities
+    g = np.load(os.path.join(golden_dir, "kmeans_n20000_d64_k16.npz"))
+    x = synth.clustered_tokens(1, int(g["n"]), int(g["D"]), n_modes=int(g["K"]), seed=int(g["seed"]), noise=0.6)[0]
+    utilities.seed_everything(42)
+    v = utilities.VLAD(int(g["K"]), None, cache_dir=None)
+    v.fit(x)                                   # draws its init rows from NumPy's global RNG (seed 42)
+    assert v.desc_dim == int(g["D"]) and v.c_centers.device.type == "cpu"
+    assert v.kmeans.n_iter_ == int(g["iters"])
+    assert l2rel(v.c_centers, g["centers"]) < 1e-5
+    out = v.generate_multi(x[:600].reshape(3, 200, -1))
+    assert out.device.type == "cpu" and out.shape == (3, int(g["K"]) * int(g["D"]))
+    for i in range(3):
+        ref = vlad_ref.vlad_hard(x[i * 200:(i + 1) * 200], torch.from_numpy(g["centers"]))[0]
+        assert l2rel(out[i], ref) < 2e-5
+    single = v.generate(x[:200])
+    assert torch.equal(single, out[0])
+    assert torch.equal(v.kmeans.predict(x[:50]), vlad_ref.hard_labels(x[:50], v.c_centers))
+
+
+@pytest.mark.parametrize("nq,ndb,dim,k,metric", [(9, 103, 64, 12, "ip"), (9, 103, 64, 12, "l2"),
+                                                  (33, 5000, 128, 20, "ip"), (4, 7, 32, 20, "ip"),
+                                                  (4, 7, 32, 20, "l2"), (3, 40000, 64, 5, "ip"),
+                                                  (17, 9000, 3072, 20, "ip")])
+def test_topk_vs_oracle(nq, ndb, dim, k, metric):
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(nq + ndb + dim)
+    db = torch.nn.functional.normalize(torch.randn(ndb, dim, generator=g))
+    qu = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g))
+    if ndb > 50:
+        db[40] = db[7]                      # exact duplicate: tie -> lower index first
+        qu[0] = db[7]
+    d, i = ops.topk(qu.to(DEV), db.to(DEV), k, metric)
+    d_ref, i_ref = faiss_flat.flat_search(qu, db, k, metric)
+    d, i = d.cpu(), i.cpu()
+    kk = min(k, ndb)
+    assert torch.equal(i[:, kk:], i_ref[:, kk:])                # -1 padding when k > ndb
+    mism = (i[:, :kk] != i_ref[:, :kk])
+    if mism.any():
+        # only near-ties may swap: the reference distances at the swapped ranks must agree to fp32 noise
+        gap = (d_ref[:, :kk][mism] - d[:, :kk][mism]).abs().max()
+        assert float(gap) < 1e-5, float(gap)
+    np.testing.assert_allclose(d[:, :kk].numpy(), d_ref[:, :kk].numpy(), rtol=0, atol=2e-6 if metric == "ip" else 1e-5)
+    if ndb > 50:
+        assert i[0, 0] == 7 and i[0, 1] == 40
+    d2, i2 = ops.topk(qu.to(DEV), db.to(DEV), k, metric, index_base=1000)
+    assert torch.equal(torch.where(i2.cpu() >= 0, i2.cpu() - 1000, i2.cpu()), i)
+
+
+def test_get_top_k_recall_surface():
+    import utilities
+    g = torch.Generator().manual_seed(5)
+    db = torch.randn(60, 96, generator=g)
+    qu = db[:10] + 0.3 * torch.randn(10, 96, generator=g)
+    gt = np.empty(10, dtype=object)
+    for q in range(10):
+        gt[q] = np.array([q])
+    top_k = [1, 5, 10]
+    for method in ("cosine", "l2"):
+        d, i, r = utilities.get_top_k_recall(top_k, db, qu, gt, method=method)
+        d0, i0, r0 = vlad_ref.top_k_recall(top_k, db, qu, gt, method=method)
+        assert d.device.type == "cpu" and d.shape == (10, 10) and i.dtype == torch.int64
+        assert torch.equal(i, i0) and r == r0
+        np.testing.assert_allclose(d.numpy(), d0.numpy(), atol=1e-5)
+    d, i, r = utilities.get_top_k_recall([1], db, qu[0], gt)       # 1-D query (utilities.py:433-434)
+    assert i.shape == (1, 1)
+    with pytest.raises(NotImplementedError):
+        utilities.get_top_k_recall([1], db, qu, gt, method="manhattan")

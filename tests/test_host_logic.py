@@ -1,0 +1,157 @@
+"""Host-side logic of the product that needs no GPU: recall arithmetic, shard merge,
+VLAD constructor / cache protocol / error behaviour, k-means iteration control, positional
+table, weight resolution, import-time seeding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from anyloc_amd import extractor, kmeans as hip_kmeans, retrieval, synth, weights
+from oracle import dinov2_ref, faiss_flat, fpk_kmeans, vlad_ref
+
+
+def test_import_seeds_rngs(capsys):
+    import importlib
+    import utilities
+    importlib.reload(utilities)
+    out = capsys.readouterr().out
+    assert "Seed set to: 42" in out
+    a = np.random.rand(3)
+    np.random.seed(42)
+    assert np.array_equal(a, np.random.rand(3))
+    for name in ("DinoV2ExtractFeatures", "VLAD", "get_top_k_recall", "seed_everything", "reduce_pca",
+                 "CustomDataset", "to_np", "od_down_links"):
+        assert hasattr(utilities, name)
+
+
+def test_recalls_match_oracle_rule():
+    rng = np.random.RandomState(0)
+    idx = rng.randint(0, 50, size=(17, 20))
+    gt = np.empty(17, dtype=object)
+    for i in range(17):
+        gt[i] = rng.randint(0, 50, size=rng.randint(0, 4))
+    top_k = [1, 5, 10, 20]
+    a = retrieval.recalls_from_indices(top_k, idx, gt)
+    b = vlad_ref.recalls_from_indices(top_k, idx, gt)
+    assert a == b
+    a2 = retrieval.recalls_from_indices(top_k, idx[:8], gt, use_percentage=False, sub_sample_db=2,
+                                        sub_sample_qu=2)
+    b2 = vlad_ref.recalls_from_indices(top_k, idx[:8], gt, False, 2, 2)
+    assert a2 == b2
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_shard_merge_equals_flat_index(metric):
+    g = torch.Generator().manual_seed(3)
+    db = torch.randn(103, 16, generator=g)
+    db[40] = db[7]                       # exact tie across shards -> lower index first
+    qu = torch.randn(9, 16, generator=g)
+    k = 12
+    d_ref, i_ref = faiss_flat.flat_search(qu, db, k, metric)
+    bounds = [0, 30, 31, 80, 103]
+    ds, is_ = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        d, i = faiss_flat.flat_search(qu, db[a:b], k, metric)
+        ds.append(d.numpy())
+        is_.append(np.where(i.numpy() >= 0, i.numpy() + a, -1))
+    d, i = retrieval.merge_shard_topk(ds, is_, k, metric)
+    assert np.array_equal(i, i_ref.numpy())
+    # per-shard GEMMs block differently on the CPU: distances agree to rounding
+    np.testing.assert_allclose(d, d_ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_vlad_ctor_cache_protocol(tmp_path, capsys):
+    import utilities
+    v = utilities.VLAD(4, cache_dir=None)
+    assert "VLAD caching is disabled." in capsys.readouterr().out
+    assert (v.num_clusters, v.desc_dim, v.intra_norm, v.norm_descs, v.mode, v.vlad_mode, v.soft_temp) == \
+        (4, None, True, True, "cosine", "hard", 1.0)
+    assert v.c_centers is None and v.kmeans is None and v.cache_dir is None
+    assert not v.can_use_cache_vlad() and not v.can_use_cache_ids(["a"])
+    with pytest.raises(AssertionError):
+        utilities.VLAD(4, vlad_mode="medium")
+    with pytest.raises(AssertionError):
+        v.generate(torch.zeros(3, 8))                 # not fitted (reference utilities.py:948-949)
+    cdir = tmp_path / "cache"
+    v2 = utilities.VLAD(4, cache_dir=str(cdir))
+    assert "Created cache directory" in capsys.readouterr().out and cdir.is_dir()
+    assert not v2.can_use_cache_vlad()
+    with pytest.raises(ValueError, match="No training descriptors given"):
+        v2.fit(None)
+    c = torch.randn(4, 8)
+    torch.save(c, str(cdir / "c_centers.pt"))
+    v3 = utilities.VLAD(4, cache_dir=str(cdir))
+    assert "Warning: Cache directory already exists" in capsys.readouterr().out
+    v3.fit(None)                                       # restore path: no kernel involved
+    out = capsys.readouterr().out
+    assert "Using cached cluster centers" in out and "Desc dim set to 8" in out
+    assert torch.equal(v3.c_centers, c) and v3.desc_dim == 8 and torch.equal(v3.kmeans.centroids, c)
+    assert v3.can_use_cache_vlad()
+    assert not v3.can_use_cache_ids(["img0"])
+    torch.save(torch.zeros(3, 4, 8), str(cdir / "img0_r.pt"))
+    assert v3.can_use_cache_ids("img0", only_residuals=True) and not v3.can_use_cache_ids("img0")
+    torch.save(torch.zeros(3, dtype=torch.long), str(cdir / "img0_l.pt"))
+    assert v3.can_use_cache_ids(["img0"]) and not v3.can_use_cache_ids(["img0", "img1"])
+    assert not v3.can_use_cache_ids(None)
+
+
+def test_kmeans_host_loop_matches_fpk():
+    """The iteration control (init draw, update, NaN->0, tolerance) with the device step
+    replaced by the oracle's assign rule must reproduce fast-pytorch-kmeans exactly."""
+    def step(x, c, mode, want_labels):
+        sim = fpk_kmeans.KMeans.cos_sim(x, c) if mode == "cosine" else fpk_kmeans.KMeans.euc_sim(x, c)
+        lab = sim.max(dim=-1)[1]
+        onehot = (lab[None, :] == torch.arange(c.shape[0])[:, None]).to(x.dtype)
+        return onehot @ x, onehot.sum(-1), lab
+    for mode in ("cosine", "euclidean"):
+        x = synth.clustered_tokens(1, 3000, 32, n_modes=6, seed=5, noise=0.5)[0]
+        np.random.seed(42)
+        ref = fpk_kmeans.KMeans(9, mode=mode)         # 9 > 6 modes: exercises empty clusters
+        lab_ref = ref.fit_predict(x)
+        np.random.seed(42)
+        km = hip_kmeans.KMeans(9, mode=mode, step_fn=step)
+        lab = km.fit_predict(x)
+        assert km.n_iter_ == ref.n_iter_
+        assert torch.equal(km.centroids, ref.centroids)
+        assert torch.equal(lab, lab_ref)
+        assert torch.equal(km.predict(x[:50]), ref.predict(x[:50]))
+
+
+def test_pos_table_matches_oracle():
+    sd = synth.synthetic_state_dict("dinov2_vits14", 0, depth=1)
+    for h, w in ((224, 224), (322, 322), (224, 308), (518, 518), (518, 490)):
+        a = extractor.interpolate_pos_embed(sd["pos_embed"], h, w)
+        b = dinov2_ref.interpolate_pos_embed(sd["pos_embed"], h, w)[0]
+        assert a.shape == (1 + (h // 14) * (w // 14), 384)
+        assert torch.equal(a, b)
+
+
+def test_weight_resolution(tmp_path, monkeypatch):
+    weights.unregister_state_dict()
+    monkeypatch.delenv("ANYLOC_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setenv("ANYLOC_DINOV2_WEIGHTS", str(tmp_path))
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path / "hub"))
+    monkeypatch.setattr(torch.hub, "load_state_dict_from_url",
+                        lambda *a, **k: (_ for _ in ()).throw(OSError("offline")))
+    with pytest.raises(FileNotFoundError):
+        weights.resolve_state_dict("dinov2_vits14")
+    with pytest.raises(ValueError):
+        weights.resolve_state_dict("dinov2_vitx14")
+    sd = synth.synthetic_state_dict("dinov2_vits14", 3, depth=1)
+    torch.save(sd, str(tmp_path / "dinov2_vits14_pretrain.pth"))
+    got = weights.resolve_state_dict("dinov2_vits14")
+    assert torch.equal(got["cls_token"], sd["cls_token"])
+    weights.register_state_dict("dinov2_vits14", {"x": 1})
+    assert weights.resolve_state_dict("dinov2_vits14") == {"x": 1}
+    weights.unregister_state_dict()
+
+
+def test_synthetic_state_dict_loads_into_hub_layout():
+    for name in ("dinov2_vits14", "dinov2_vitg14"):
+        sd = synth.synthetic_state_dict(name, 0, depth=2)
+        m = dinov2_ref.DinoVisionTransformer(name)
+        missing = [k for k in sd if k not in m.state_dict()]
+        assert not missing
+        for k, v in sd.items():
+            assert tuple(m.state_dict()[k].shape) == tuple(v.shape), k
