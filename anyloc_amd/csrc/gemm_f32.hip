@@ -9,29 +9,31 @@
 // Design (CDNA4, wave64):
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain) at 64
 //     FLOP/clk/SIMD = 157.3 TFLOP/s chip peak -- the governing roofline.
-//   * block tile BM x BN x 32, 4 waves; each wave owns (BM/WM) x (BN/WN) as
-//     32x32 MFMA blocks held in accumulator registers.
+//   * block tile BM x BN x BK, WM x WN waves; each wave owns (BM/WM) x (BN/WN)
+//     as 32x32 MFMA blocks held in accumulator registers.
 //   * both operands are K-contiguous (torch Linear layout).  Global -> register
 //     -> LDS staging with coalesced 128-byte row segments (8 lanes x float4);
 //     loads of K-slab t+1 are issued before the MFMAs of slab t and written to
 //     the other LDS buffer afterwards (one barrier per slab).
-//   * LDS rows are padded to 36 floats: the per-lane ds_read_b128 fragment
+//   * LDS rows are padded to BK+4 floats: the per-lane ds_read_b128 fragment
 //     reads (row = lane&31, 16-byte column = lane>>5) hit 16 distinct 16-byte
 //     slots per 16-lane group -> conflict-free.
+//   * fragments of k-step s+1 are read from LDS into a second register set
+//     before the MFMAs of step s are issued (LDS latency hidden behind 8-32
+//     MFMAs of 64 cycles each).
 //   * k-permutation: a lane's float4 holds k = 8s + 4*(lane>>5) + j, and MFMA
 //     number j consumes element j of both operands, so A and W see the same k
 //     in the same lane half; every k is consumed exactly once.
 //   * block id -> tile: XCD-aware (block b runs on XCD b % 8, each XCD has a
 //     private 4 MiB L2) + grouped ordering so co-resident blocks of one XCD
 //     share A row-panels and W column-panels.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace anyloc {
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
 
 __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int nb = tiles_m * tiles_n;
@@ -53,13 +55,19 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool ROWSQ>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tiles_m, int tiles_n) {
+// KFULL: K is a multiple of BK (no tail predicate in the staging loads)
+template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem p, int tiles_m, int tiles_n) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int LDS_LD = BK + 4;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int A_LD4 = BM / 32;  // float4 per thread per K-slab (BM*BK/4/256)
-  constexpr int W_LD4 = BN / 32;
-  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int LPR = BK / 4;            // lanes per staged row (float4 each)
+  constexpr int RPP = NT / LPR;          // rows staged per pass
+  constexpr int A_LD4 = BM / RPP;        // float4 per thread per K-slab
+  constexpr int W_LD4 = BN / RPP;
+  constexpr int KS = BK / 8;             // k-steps per slab (8 k per step: 4 MFMAs per block pair)
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   static_assert(EPI != EPI_SWIGLU || NI == 2, "swiglu pairs the two 32-col blocks of a wave");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,19 +80,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tile
   tile_coords(blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
 
-  // ---- staging coordinates: 8 lanes cover one 128-byte row segment ----
-  const int kq = tid & 7, r0 = tid >> 3;
+  // ---- staging coordinates: LPR lanes cover one BK*4-byte row segment ----
+  const int kq = tid % LPR, r0 = tid / LPR;
   const float* a_src[A_LD4];
   const float* w_src[W_LD4];
 #pragma unroll
   for (int i = 0; i < A_LD4; ++i) {
-    int64_t row = m0 + r0 + 32 * i;
+    int64_t row = m0 + r0 + RPP * i;
     row = row < p.M ? row : p.M - 1;
     a_src[i] = p.A + row * p.lda + 4 * kq;
   }
 #pragma unroll
   for (int i = 0; i < W_LD4; ++i) {
-    int64_t row = n0 + r0 + 32 * i;
+    int64_t row = n0 + r0 + RPP * i;
     row = row < p.N ? row : p.N - 1;
     w_src[i] = p.W + row * p.ldw + 4 * kq;
   }
@@ -108,22 +116,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tile
 
   auto fetch = [&](int kt) {
     const int64_t k = (int64_t)kt * BK;
-    const bool ok = (k + 4 * kq) < p.K;   // K % 4 == 0: a float4 is all-in or all-out
+    if constexpr (KFULL) {
 #pragma unroll
-    for (int i = 0; i < A_LD4; ++i) ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_src[i] + k) : zero4;
+      for (int i = 0; i < A_LD4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k);
 #pragma unroll
-    for (int i = 0; i < W_LD4; ++i) rw[i] = ok ? *reinterpret_cast<const f32x4*>(w_src[i] + k) : zero4;
+      for (int i = 0; i < W_LD4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_src[i] + k);
+    } else {
+      const bool ok = (k + 4 * kq) < p.K;   // K % 4 == 0: a float4 is all-in or all-out
+#pragma unroll
+      for (int i = 0; i < A_LD4; ++i) ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_src[i] + k) : zero4;
+#pragma unroll
+      for (int i = 0; i < W_LD4; ++i) rw[i] = ok ? *reinterpret_cast<const f32x4*>(w_src[i] + k) : zero4;
+    }
   };
   auto stash = [&](int buf) {
     float* ad = As + buf * BM * LDS_LD + st_off;
     float* wd = Ws + buf * BN * LDS_LD + st_off;
 #pragma unroll
     for (int i = 0; i < A_LD4; ++i) {
-      *reinterpret_cast<f32x4*>(ad + 32 * i * LDS_LD) = ra[i];
+      *reinterpret_cast<f32x4*>(ad + RPP * i * LDS_LD) = ra[i];
       if (ROWSQ) rsq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
     }
 #pragma unroll
-    for (int i = 0; i < W_LD4; ++i) *reinterpret_cast<f32x4*>(wd + 32 * i * LDS_LD) = rw[i];
+    for (int i = 0; i < W_LD4; ++i) *reinterpret_cast<f32x4*>(wd + RPP * i * LDS_LD) = rw[i];
   };
 
   fetch(0);
@@ -131,25 +146,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tile
   __syncthreads();
 
   const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
+  f32x4 af[2][MI], bf[2][NI];
+  auto load_frags = [&](const float* Ab, const float* Wb, int s, int set) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[set][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDS_LD + 8 * s);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const f32x4*>(Wb + ni * 32 * LDS_LD + 8 * s);
+  };
+
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) fetch(kt + 1);
     const float* Ab = As + buf * BM * LDS_LD + wm * TM * LDS_LD + frag_off;
     const float* Wb = Ws + buf * BN * LDS_LD + wn * TN * LDS_LD + frag_off;
+    load_frags(Ab, Wb, 0, 0);
+    if (kt + 1 < nk) fetch(kt + 1);
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      f32x4 af[MI], bf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDS_LD + 8 * s);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(Wb + ni * 32 * LDS_LD + 8 * s);
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) load_frags(Ab, Wb, s + 1, (s + 1) & 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][mi][j], bf[s & 1][ni][j], acc[mi][ni], 0, 0, 0);
     }
     if (kt + 1 < nk) stash(buf ^ 1);
     __syncthreads();
@@ -160,10 +180,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tile
 #pragma unroll
       for (int i = 0; i < A_LD4; ++i) {
         float v = rsq[i];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        const int64_t row = m0 + r0 + 32 * i;
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+        const int64_t row = m0 + r0 + RPP * i;
         if (kq == 0 && row < p.M) p.rowsq[row] = v;
       }
     }
@@ -222,11 +241,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem p, int tile
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool ROWSQ>
-int launch(const GemmProblem& p, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL>
+int launch_cfg(const GemmProblem& p, hipStream_t stream) {
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI, ROWSQ>;
+  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, BK, OCC, EPI, ROWSQ, KFULL>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -236,8 +255,40 @@ int launch(const GemmProblem& p, hipStream_t stream) {
   const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
   const double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
   ProfScope prof(p.tag ? p.tag : "gemm_nt", stream, flops, bytes);
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, stream, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_nt_kernel");
+}
+
+// tile configuration of the wide (ViT / retrieval) GEMMs; ANYLOC_GEMM_CFG selects an
+// alternative at run time (micro-benchmarks only)
+int gemm_cfg() {
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("ANYLOC_GEMM_CFG");
+    cfg = e ? atoi(e) : 0;
+  }
+  return cfg;
+}
+
+template <int EPI, bool KFULL>
+int launch_wide(const GemmProblem& p, hipStream_t stream) {
+  switch (gemm_cfg()) {
+    case 1:  // 256x128, 4 waves of 128x64, one block per CU
+      return launch_cfg<256, 128, 2, 2, 32, 1, EPI, false, KFULL>(p, stream);
+    case 2:  // 256x128, 8 waves of 64x64, one block per CU
+      return launch_cfg<256, 128, 4, 2, 32, 2, EPI, false, KFULL>(p, stream);
+    case 3:  // 128x128, BK=16, three blocks per CU
+      return launch_cfg<128, 128, 2, 2, 16, 3, EPI, false, KFULL>(p, stream);
+    case 4:  // 256x256, 8 waves of 128x64 (swiglu-compatible), one block per CU
+      return launch_cfg<256, 256, 2, 4, 16, 2, EPI, false, KFULL>(p, stream);
+    default:  // 128x128, 4 waves of 64x64, two blocks per CU
+      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
+  }
+}
+
+template <int EPI>
+int launch_wide_k(const GemmProblem& p, hipStream_t stream) {
+  return (p.K % 32 == 0) ? launch_wide<EPI, true>(p, stream) : launch_wide<EPI, false>(p, stream);
 }
 
 }  // namespace
@@ -255,23 +306,23 @@ int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream) {
   const bool narrow = p.N <= 32;
   switch (epilogue) {
     case EPI_STORE:
-      if (p.rowsq) {
-        return narrow ? launch<128, 32, 4, 1, EPI_STORE, true>(p, stream)
-                      : launch<128, 128, 2, 2, EPI_STORE, true>(p, stream);
+      if (narrow) {
+        return p.rowsq ? launch_cfg<128, 32, 4, 1, 32, 2, EPI_STORE, true, false>(p, stream)
+                       : launch_cfg<128, 32, 4, 1, 32, 2, EPI_STORE, false, false>(p, stream);
       }
-      return narrow ? launch<128, 32, 4, 1, EPI_STORE, false>(p, stream)
-                    : launch<128, 128, 2, 2, EPI_STORE, false>(p, stream);
+      if (p.rowsq) return launch_cfg<128, 128, 2, 2, 32, 2, EPI_STORE, true, false>(p, stream);
+      return launch_wide_k<EPI_STORE>(p, stream);
     case EPI_GELU:
-      return launch<128, 128, 2, 2, EPI_GELU, false>(p, stream);
+      return launch_wide_k<EPI_GELU>(p, stream);
     case EPI_LS_RESID:
       ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_nt: LS_RESID needs gamma and resid");
-      return launch<128, 128, 2, 2, EPI_LS_RESID, false>(p, stream);
+      return launch_wide_k<EPI_LS_RESID>(p, stream);
     case EPI_SWIGLU:
       ANYLOC_CHECK_ARG(p.N % 64 == 0, "gemm_nt: SWIGLU needs N %% 64 == 0");
-      return launch<128, 128, 2, 2, EPI_SWIGLU, false>(p, stream);
+      return launch_wide_k<EPI_SWIGLU>(p, stream);
     case EPI_PATCH:
       ANYLOC_CHECK_ARG(p.pos && p.patches > 0, "gemm_nt: PATCH needs pos and patches");
-      return launch<128, 128, 2, 2, EPI_PATCH, false>(p, stream);
+      return launch_wide_k<EPI_PATCH>(p, stream);
     default:
       set_error("gemm_nt: unknown epilogue %d", epilogue);
       return ANYLOC_ERR_INVALID_ARG;

@@ -1,0 +1,60 @@
+"""TEST INFRASTRUCTURE: run the product's HOST logic on a GPU-less machine by replacing the
+device entry points (anyloc_amd.ops / HipDinoV2) with the CPU oracle.  Used only by CPU tests
+that drive the reference's unmodified scripts through our ``utilities`` surface; it proves the
+plumbing (argument conventions, caching, return types), not the kernels."""
+import torch
+from torch.nn import functional as F
+
+from oracle import dinov2_ref, faiss_flat, fpk_kmeans, vlad_ref
+
+
+class OracleDinoV2:
+    def __init__(self, name, state_dict, device, max_layer=None):
+        have = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
+        self.model = dinov2_ref.DinoVisionTransformer(name)
+        self.model.blocks = self.model.blocks[:have]
+        self.model.load_state_dict(state_dict, strict=True)
+        self.model.eval()
+        self.dim, self.depth = self.model.embed_dim, have
+        self.device = torch.device("cpu")
+
+    @torch.no_grad()
+    def forward_taps(self, img, taps, use_cls=False, norm_taps=True, norm_concat=False):
+        assert img.shape[-2] % 14 == 0 and img.shape[-1] % 14 == 0
+        outs = [dinov2_ref.extract_facet(self.model, img.cpu().float(), l, f, use_cls, norm_taps) for l, f in taps]
+        out = torch.cat(outs, dim=-1)
+        return F.normalize(out, dim=-1) if norm_concat else out
+
+
+def install(monkeypatch):
+    from anyloc_amd import _lib, extractor, kmeans, ops
+    cpu = torch.device("cpu")
+    monkeypatch.setattr(_lib, "require_gpu", lambda: cpu)
+    monkeypatch.setattr(ops, "l2norm_rows", lambda x, eps=1e-12, out=None: F.normalize(x.float(), dim=-1, eps=eps))
+
+    def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0, return_labels=False):
+        parts = list(tokens) if not isinstance(tokens, torch.Tensor) else list(tokens if tokens.ndim == 3 else tokens[None])
+        outs, labs = [], []
+        for t in parts:
+            t = torch.as_tensor(t).float()
+            if mode == "hard":
+                v, l = vlad_ref.vlad_hard(t, centers.float(), norm_descs, intra_norm)
+                labs.append(l)
+            else:
+                v, _ = vlad_ref.vlad_soft(t, centers.float(), soft_temp, norm_descs, intra_norm)
+            outs.append(v)
+        out = torch.stack(outs) if outs else torch.empty(0, centers.numel())
+        return (out, torch.cat(labs) if labs else None) if return_labels else out
+
+    def kmeans_step(x, c, mode="cosine", want_labels=False):
+        sim = fpk_kmeans.KMeans.cos_sim(x, c) if mode == "cosine" else fpk_kmeans.KMeans.euc_sim(x, c)
+        lab = sim.max(dim=-1)[1]
+        onehot = (lab[None, :] == torch.arange(c.shape[0])[:, None]).to(x.dtype)
+        return onehot @ x, onehot.sum(-1), lab
+
+    monkeypatch.setattr(ops, "vlad", vlad)
+    monkeypatch.setattr(ops, "kmeans_step", kmeans_step)
+    monkeypatch.setattr(kmeans, "_local_step", kmeans_step)
+    monkeypatch.setattr(ops, "topk", lambda q, db, k, metric="ip", index_base=0:
+                        faiss_flat.flat_search(q.float(), db.float(), k, metric))
+    monkeypatch.setattr(extractor, "HipDinoV2", OracleDinoV2)

@@ -10,6 +10,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    import torch
+    # the CPU oracle runs many small ops: more threads than ~16 only adds contention
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
