@@ -28,6 +28,7 @@
 //     private 4 MiB L2) + grouped ordering so co-resident blocks of one XCD
 //     share A row-panels and W column-panels.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -50,13 +51,27 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
   tn = within / gm;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Same load hidden from hipcc's s_waitcnt bookkeeping (ABL bit 4): hipcc drains vmcnt to 0 before the
+// first LDS write of a slab even when newer loads are in flight behind it, which defeats a prefetch
+// distance of two slabs.  The caller places its own counted s_waitcnt before the first consumer.
+__device__ __forceinline__ void buf_load16_hidden(f32x4& dst, u32x4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
   return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
 // KFULL: K is a multiple of BK (no tail predicate in the staging loads)
-template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL>
+// ABL: timing-only ablations for tools/microbench_gemm.py (results are WRONG when != 0):
+//      bit 0 = no global->LDS staging inside the K loop, bit 1 = no barrier, bit 2 = s_setprio around MFMAs
+template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem p, int tiles_m, int tiles_n) {
   constexpr int NT = 64 * WM * WN;
   constexpr int LDS_LD = BK + 4;
@@ -82,20 +97,26 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
 
   // ---- staging coordinates: LPR lanes cover one BK*4-byte row segment ----
   const int kq = tid % LPR, r0 = tid / LPR;
-  const float* a_src[A_LD4];
-  const float* w_src[W_LD4];
+  // Operands are read with buffer loads: wave-uniform descriptor at the tile origin (SGPRs), a
+  // per-thread 32-bit byte offset that never changes (VGPR) and the K-slab offset as the scalar
+  // offset -- no per-slab 64-bit address arithmetic, nothing for the waitcnt pass to trip over.
+  unsigned a_off[A_LD4], w_off[W_LD4];
 #pragma unroll
   for (int i = 0; i < A_LD4; ++i) {
     int64_t row = m0 + r0 + RPP * i;
-    row = row < p.M ? row : p.M - 1;
-    a_src[i] = p.A + row * p.lda + 4 * kq;
+    row = (row < p.M ? row : p.M - 1) - m0;
+    a_off[i] = (unsigned)((row * p.lda + 4 * kq) * 4);
   }
 #pragma unroll
   for (int i = 0; i < W_LD4; ++i) {
     int64_t row = n0 + r0 + RPP * i;
-    row = row < p.N ? row : p.N - 1;
-    w_src[i] = p.W + row * p.ldw + 4 * kq;
+    row = (row < p.N ? row : p.N - 1) - n0;
+    w_off[i] = (unsigned)((row * p.ldw + 4 * kq) * 4);
   }
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W + n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
   const int st_off = r0 * LDS_LD + 4 * kq;
 
   f32x16 acc[MI][NI];
@@ -111,39 +132,65 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   for (int i = 0; i < A_LD4; ++i) rsq[i] = 0.0f;
 
   const int nk = (int)((p.K + BK - 1) / BK);
-  f32x4 ra[A_LD4], rw[W_LD4];
+  // two staging register sets: slab j travels in set j&1.  With PF2 (ABL bit 3) the loads of slab
+  // t+2 are issued while slab t is computed (slab t+1 is still in flight / in registers), which
+  // doubles the tolerated global-load latency; otherwise slab t+1 is fetched during slab t.
+  constexpr bool PF2 = (ABL & 8) != 0;
+  constexpr bool HIDDEN = (ABL & 16) != 0;       // requires KFULL
+  static_assert(!HIDDEN || KFULL, "hidden loads have no K-tail predicate");
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  f32x4 ra[2][A_LD4], rw[2][W_LD4];
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  auto fetch = [&](int kt) {
-    const int64_t k = (int64_t)kt * BK;
-    if constexpr (KFULL) {
+  auto fetch = [&](int kt, auto setc) {
+    constexpr int S = decltype(setc)::value;
+    const unsigned kb = (unsigned)kt * (BK * 4);          // byte offset of the slab (scalar)
+    if constexpr (HIDDEN) {
+      // raw buffer descriptor words: base[31:0], base[47:32] (stride 0), num_records, flags
+      const uint64_t ab = reinterpret_cast<uint64_t>(p.A + m0 * p.lda), wb = reinterpret_cast<uint64_t>(p.W + n0 * p.ldw);
+      const u32x4 ar = {(unsigned)ab, (unsigned)(ab >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+      const u32x4 wr = {(unsigned)wb, (unsigned)(wb >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
 #pragma unroll
-      for (int i = 0; i < A_LD4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k);
+      for (int i = 0; i < A_LD4; ++i) buf_load16_hidden(ra[S][i], ar, a_off[i], kb);
 #pragma unroll
-      for (int i = 0; i < W_LD4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_src[i] + k);
+      for (int i = 0; i < W_LD4; ++i) buf_load16_hidden(rw[S][i], wr, w_off[i], kb);
+    } else if constexpr (KFULL) {
+#pragma unroll
+      for (int i = 0; i < A_LD4; ++i) ra[S][i] = buf_load16(a_rsrc, a_off[i], kb);
+#pragma unroll
+      for (int i = 0; i < W_LD4; ++i) rw[S][i] = buf_load16(w_rsrc, w_off[i], kb);
     } else {
-      const bool ok = (k + 4 * kq) < p.K;   // K % 4 == 0: a float4 is all-in or all-out
+      const bool ok = ((int64_t)kt * BK + 4 * kq) < p.K;   // K % 4 == 0: a float4 is all-in or all-out
 #pragma unroll
-      for (int i = 0; i < A_LD4; ++i) ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_src[i] + k) : zero4;
+      for (int i = 0; i < A_LD4; ++i) ra[S][i] = ok ? buf_load16(a_rsrc, a_off[i], kb) : zero4;
 #pragma unroll
-      for (int i = 0; i < W_LD4; ++i) rw[i] = ok ? *reinterpret_cast<const f32x4*>(w_src[i] + k) : zero4;
+      for (int i = 0; i < W_LD4; ++i) rw[S][i] = ok ? buf_load16(w_rsrc, w_off[i], kb) : zero4;
     }
   };
-  auto stash = [&](int buf) {
-    float* ad = As + buf * BM * LDS_LD + st_off;
-    float* wd = Ws + buf * BN * LDS_LD + st_off;
+  auto stash = [&](auto setc) {           // set S holds the slab whose LDS buffer is S
+    constexpr int S = decltype(setc)::value;
+    float* ad = As + S * BM * LDS_LD + st_off;
+    float* wd = Ws + S * BN * LDS_LD + st_off;
 #pragma unroll
     for (int i = 0; i < A_LD4; ++i) {
-      *reinterpret_cast<f32x4*>(ad + RPP * i * LDS_LD) = ra[i];
-      if (ROWSQ) rsq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
+      *reinterpret_cast<f32x4*>(ad + RPP * i * LDS_LD) = ra[S][i];
+      if (ROWSQ)
+        rsq[i] += ra[S][i][0] * ra[S][i][0] + ra[S][i][1] * ra[S][i][1] + ra[S][i][2] * ra[S][i][2] +
+                  ra[S][i][3] * ra[S][i][3];
     }
 #pragma unroll
-    for (int i = 0; i < W_LD4; ++i) *reinterpret_cast<f32x4*>(wd + RPP * i * LDS_LD) = rw[i];
+    for (int i = 0; i < W_LD4; ++i) *reinterpret_cast<f32x4*>(wd + RPP * i * LDS_LD) = rw[S][i];
   };
 
-  fetch(0);
-  stash(0);
+  fetch(0, I0{});
+  if constexpr (HIDDEN) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  stash(I0{});
   __syncthreads();
+  if (PF2 && nk > 1) fetch(1, I1{});
 
   const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
   f32x4 af[2][MI], bf[2][NI];
@@ -154,15 +201,24 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
     for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const f32x4*>(Wb + ni * 32 * LDS_LD + 8 * s);
   };
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const float* Ab = As + buf * BM * LDS_LD + wm * TM * LDS_LD + frag_off;
-    const float* Wb = Ws + buf * BN * LDS_LD + wn * TN * LDS_LD + frag_off;
+  auto slab = [&](int kt, auto curc) {
+    constexpr int CUR = decltype(curc)::value;          // LDS buffer (and register set) of slab kt
+    using Cur = std::integral_constant<int, CUR>;
+    using Nxt = std::integral_constant<int, CUR ^ 1>;
+    const float* Ab = As + CUR * BM * LDS_LD + wm * TM * LDS_LD + frag_off;
+    const float* Wb = Ws + CUR * BN * LDS_LD + wn * TN * LDS_LD + frag_off;
     load_frags(Ab, Wb, 0, 0);
-    if (kt + 1 < nk) fetch(kt + 1);
+    if (!(ABL & 1)) {
+      if (PF2) {
+        if (kt + 2 < nk) fetch(kt + 2, Cur{});
+      } else {
+        if (kt + 1 < nk) fetch(kt + 1, Nxt{});
+      }
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s + 1 < KS) load_frags(Ab, Wb, s + 1, (s + 1) & 1);
+      if (ABL & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -170,9 +226,23 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][mi][j], bf[s & 1][ni][j], acc[mi][ni], 0, 0, 0);
+      if (ABL & 4) __builtin_amdgcn_s_setprio(0);
     }
-    if (kt + 1 < nk) stash(buf ^ 1);
-    __syncthreads();
+    if (!(ABL & 1) && kt + 1 < nk) {
+      if constexpr (HIDDEN) {
+        // loads retire in order: slab kt+1 has landed once at most the (A_LD4+W_LD4) loads of slab
+        // kt+2 issued behind it are outstanding
+        if (PF2 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD4 + W_LD4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stash(Nxt{});
+    }
+    if (!(ABL & 2)) __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    slab(kt, I0{});
+    if (kt + 1 < nk) slab(kt + 1, I1{});
   }
 
   if (ROWSQ) {
@@ -241,11 +311,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL>
+template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL, int ABL = 0>
 int launch_cfg(const GemmProblem& p, hipStream_t stream) {
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
   const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, BK, OCC, EPI, ROWSQ, KFULL>;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, BK, OCC, EPI, ROWSQ, KFULL, ABL>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -281,6 +351,29 @@ int launch_wide(const GemmProblem& p, hipStream_t stream) {
       return launch_cfg<128, 128, 2, 2, 16, 3, EPI, false, KFULL>(p, stream);
     case 4:  // 256x256, 8 waves of 128x64 (swiglu-compatible), one block per CU
       return launch_cfg<256, 256, 2, 4, 16, 2, EPI, false, KFULL>(p, stream);
+    // 5..8: timing-only ablations of the default tile (plain-store epilogue only; results are wrong)
+    case 5:
+    case 6:
+    case 7:
+    case 8:
+      if constexpr (EPI == EPI_STORE && KFULL) {
+        const int c = gemm_cfg();
+        if (c == 5) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 1>(p, stream);
+        if (c == 6) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 2>(p, stream);
+        if (c == 7) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 3>(p, stream);
+        return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 4>(p, stream);
+      }
+      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
+    case 10:  // default tile, loads issued two slabs ahead
+      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 8>(p, stream);
+    case 11:  // 256x256 tile (8 waves of 128x64), loads two slabs ahead
+      return launch_cfg<256, 256, 2, 4, 16, 2, EPI, false, KFULL, 8>(p, stream);
+    case 12:  // default tile, loads two slabs ahead with hand-counted vmcnt
+      if constexpr (KFULL) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 24>(p, stream);
+      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
+    case 13:  // default tile, loads one slab ahead with hand-counted vmcnt
+      if constexpr (KFULL) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 16>(p, stream);
+      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
     default:  // 128x128, 4 waves of 64x64, two blocks per CU
       return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
   }
