@@ -48,16 +48,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
   }
 
-  // ---- K/V staging: 16 lanes cover one 256-byte head row ----
+  // ---- K/V staging: 16 lanes cover one 256-byte head row.  Buffer loads: descriptor = this image's
+  // QKV rows (num_records = T rows, so keys past T read as zeros), constant per-thread byte offset,
+  // key-tile offset as the scalar offset ----
   const int sr = tid >> 4, sc = tid & 15;
+  const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(base), 0, (int)((int64_t)T * ld * 4), 0x00020000);
+  unsigned kv_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) kv_off[i] = (unsigned)(((int64_t)(sr + 16 * i) * ld + h * HD + 4 * sc) * 4);
+  const unsigned k_col = (unsigned)D * 4, v_col = (unsigned)D * 8, tile_bytes = (unsigned)(KT * ld * 4);
   f32x4 rk[2], rv[2];
   auto fetch = [&](int kt) {
+    const unsigned so = (unsigned)kt * tile_bytes;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int key = min(kt * KT + sr + 16 * i, T - 1);
-      const float* p = base + (int64_t)key * ld + h * HD + 4 * sc;
-      rk[i] = *reinterpret_cast<const f32x4*>(p + D);
-      rv[i] = *reinterpret_cast<const f32x4*>(p + 2 * D);
+      rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_off[i] + k_col, so, 0));
+      rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_off[i] + v_col, so, 0));
     }
   };
   auto stash = [&](int buf) {

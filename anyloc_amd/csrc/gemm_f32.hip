@@ -12,7 +12,10 @@
 //   * block tile BM x BN x BK, WM x WN waves; each wave owns (BM/WM) x (BN/WN)
 //     as 32x32 MFMA blocks held in accumulator registers.
 //   * both operands are K-contiguous (torch Linear layout).  Global -> register
-//     -> LDS staging with coalesced 128-byte row segments (8 lanes x float4);
+//     -> LDS staging with coalesced 128-byte row segments (8 lanes x float4),
+//     issued as buffer loads (descriptor at the tile origin in SGPRs, constant
+//     per-thread byte offset, K-slab offset as the scalar offset: no per-slab
+//     64-bit address arithmetic -- worth +10 % over flat global loads here);
 //     loads of K-slab t+1 are issued before the MFMAs of slab t and written to
 //     the other LDS buffer afterwards (one barrier per slab).
 //   * LDS rows are padded to BK+4 floats: the per-lane ds_read_b128 fragment
@@ -54,13 +57,6 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-}
-
-// Same load hidden from hipcc's s_waitcnt bookkeeping (ABL bit 4): hipcc drains vmcnt to 0 before the
-// first LDS write of a slab even when newer loads are in flight behind it, which defeats a prefetch
-// distance of two slabs.  The caller places its own counted s_waitcnt before the first consumer.
-__device__ __forceinline__ void buf_load16_hidden(f32x4& dst, u32x4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
 __device__ __forceinline__ float gelu_erf(float v) {
@@ -136,8 +132,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   // t+2 are issued while slab t is computed (slab t+1 is still in flight / in registers), which
   // doubles the tolerated global-load latency; otherwise slab t+1 is fetched during slab t.
   constexpr bool PF2 = (ABL & 8) != 0;
-  constexpr bool HIDDEN = (ABL & 16) != 0;       // requires KFULL
-  static_assert(!HIDDEN || KFULL, "hidden loads have no K-tail predicate");
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   f32x4 ra[2][A_LD4], rw[2][W_LD4];
@@ -146,16 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   auto fetch = [&](int kt, auto setc) {
     constexpr int S = decltype(setc)::value;
     const unsigned kb = (unsigned)kt * (BK * 4);          // byte offset of the slab (scalar)
-    if constexpr (HIDDEN) {
-      // raw buffer descriptor words: base[31:0], base[47:32] (stride 0), num_records, flags
-      const uint64_t ab = reinterpret_cast<uint64_t>(p.A + m0 * p.lda), wb = reinterpret_cast<uint64_t>(p.W + n0 * p.ldw);
-      const u32x4 ar = {(unsigned)ab, (unsigned)(ab >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-      const u32x4 wr = {(unsigned)wb, (unsigned)(wb >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-#pragma unroll
-      for (int i = 0; i < A_LD4; ++i) buf_load16_hidden(ra[S][i], ar, a_off[i], kb);
-#pragma unroll
-      for (int i = 0; i < W_LD4; ++i) buf_load16_hidden(rw[S][i], wr, w_off[i], kb);
-    } else if constexpr (KFULL) {
+    if constexpr (KFULL) {
 #pragma unroll
       for (int i = 0; i < A_LD4; ++i) ra[S][i] = buf_load16(a_rsrc, a_off[i], kb);
 #pragma unroll
@@ -184,10 +169,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   };
 
   fetch(0, I0{});
-  if constexpr (HIDDEN) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  }
   stash(I0{});
   __syncthreads();
   if (PF2 && nk > 1) fetch(1, I1{});
@@ -229,13 +210,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
       if (ABL & 4) __builtin_amdgcn_s_setprio(0);
     }
     if (!(ABL & 1) && kt + 1 < nk) {
-      if constexpr (HIDDEN) {
-        // loads retire in order: slab kt+1 has landed once at most the (A_LD4+W_LD4) loads of slab
-        // kt+2 issued behind it are outstanding
-        if (PF2 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD4 + W_LD4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
       stash(Nxt{});
     }
     if (!(ABL & 2)) __syncthreads();
@@ -368,12 +342,6 @@ int launch_wide(const GemmProblem& p, hipStream_t stream) {
       return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 8>(p, stream);
     case 11:  // 256x256 tile (8 waves of 128x64), loads two slabs ahead
       return launch_cfg<256, 256, 2, 4, 16, 2, EPI, false, KFULL, 8>(p, stream);
-    case 12:  // default tile, loads two slabs ahead with hand-counted vmcnt
-      if constexpr (KFULL) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 24>(p, stream);
-      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
-    case 13:  // default tile, loads one slab ahead with hand-counted vmcnt
-      if constexpr (KFULL) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 16>(p, stream);
-      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
     default:  // 128x128, 4 waves of 64x64, two blocks per CU
       return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
   }
