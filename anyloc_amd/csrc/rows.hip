@@ -1,6 +1,8 @@
 // Row-wise HBM-bound kernels: L2 normalisation, LayerNorm, patch gather (im2col),
 // CLS row, facet slice (+ F.normalize).  One 256-thread block per row, float4
 // coalesced accesses; rows are re-read from L1/L2 for the second pass.
+#include <cmath>
+
 #include "common.hpp"
 
 namespace anyloc {
@@ -130,7 +132,34 @@ __global__ __launch_bounds__(256) void facet_rows_kernel(const float* __restrict
   }
 }
 
+// uint8 HWC -> float CHW, centre crop, (x/255 - mean)/std : ToTensor + Normalize + CenterCrop
+// (reference dvgl_benchmark/datasets_ws.py:20-23, scripts/dino_v2_vlad.py:173-176)
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ img,
+                                                            float* __restrict__ out, int H, int W, int y0, int x0,
+                                                            int Ho, int Wo, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2) {
+  const int64_t b = blockIdx.z;
+  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= Wo) return;
+  const unsigned char* px = img + ((b * H + (y0 + y)) * (int64_t)W + (x0 + x)) * 3;
+  float* o = out + (b * 3 * Ho + y) * (int64_t)Wo + x;
+  const int64_t plane = (int64_t)Ho * Wo;
+  o[0] = ((float)px[0] / 255.0f - m0) / s0;
+  o[plane] = ((float)px[1] / 255.0f - m1) / s1;
+  o[2 * plane] = ((float)px[2] / 255.0f - m2) / s2;
+}
+
 }  // namespace
+
+int preprocess_u8(const unsigned char* img, float* out, int64_t batch, int H, int W, int Ho, int Wo, const float* mean,
+                  const float* stdv, hipStream_t stream) {
+  // torchvision center_crop: top = int(round((H - th) / 2.0)) with Python's round-half-to-even
+  const int y0 = (int)nearbyint((H - Ho) / 2.0), x0 = (int)nearbyint((W - Wo) / 2.0);
+  ProfScope prof("preprocess_u8", stream, 6.0 * batch * Ho * Wo, (double)batch * (3.0 * H * W + 12.0 * Ho * Wo));
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3((Wo + 255) / 256, Ho, (unsigned)batch), dim3(256), 0, stream, img, out,
+                     H, W, y0, x0, Ho, Wo, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+  return launch_status("preprocess_u8_kernel");
+}
 
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int64_t dim, float eps,
                 hipStream_t stream) {
@@ -175,6 +204,19 @@ int facet_rows(const float* src, int64_t lds_, int coff, float* out, int64_t ldo
 }
 
 }  // namespace anyloc
+
+extern "C" int anyloc_preprocess_u8(const unsigned char* img_hwc, int64_t batch, int64_t height, int64_t width,
+                                    int64_t crop_h, int64_t crop_w, const float* mean3, const float* std3,
+                                    float* out, void* stream) {
+  ANYLOC_CHECK_ARG(img_hwc && out && mean3 && std3, "preprocess_u8: null pointer");
+  ANYLOC_CHECK_ARG(batch > 0 && batch < 65536 && height > 0 && width > 0 && height < 65536,
+                   "preprocess_u8: bad batch/size");
+  ANYLOC_CHECK_ARG(crop_h > 0 && crop_w > 0 && crop_h <= height && crop_w <= width,
+                   "preprocess_u8: crop %lldx%lld outside image %lldx%lld", (long long)crop_h, (long long)crop_w,
+                   (long long)height, (long long)width);
+  return anyloc::preprocess_u8(img_hwc, out, batch, (int)height, (int)width, (int)crop_h, (int)crop_w, mean3, std3,
+                               static_cast<hipStream_t>(stream));
+}
 
 extern "C" int anyloc_l2norm_rows(const float* x, float* out, int64_t rows, int64_t dim, float eps, void* stream) {
   return anyloc::l2norm_rows(x, dim, out, dim, rows, dim, eps, static_cast<hipStream_t>(stream));

@@ -62,23 +62,35 @@ __global__ __launch_bounds__(256) void center_prep_kernel(const float* __restric
   }
 }
 
-// one thread per token: first argmax over k < K; row norm clamp
+// 32 lanes per token (coalesced score reads): lane j scans columns j, j+32, ... then a 5-step
+// shuffle arg-max; ties -> lowest column (torch.max / fpk max_sim return the first maximum)
 __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ scores, int kpad, int K,
                                                      const float* __restrict__ rowsq, int64_t n,
                                                      int* __restrict__ lab32, int64_t* __restrict__ lab64,
                                                      float* __restrict__ nrm, int norm_descs) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float* s = scores + i * kpad;
-  float best = s[0];
-  int bi = 0;
-  for (int k = 1; k < K; ++k) {
-    const float v = s[k];
-    if (v > best) { best = v; bi = k; }
+  const int64_t tok = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int j = threadIdx.x & 31;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (tok < n) {
+    const float* s = scores + tok * kpad;
+    for (int c = j; c < K; c += 32) {
+      const float v = s[c];
+      if (v > best) { best = v; bi = c; }
+    }
   }
-  lab32[i] = bi;
-  if (lab64) lab64[i] = bi;
-  if (nrm) nrm[i] = norm_descs ? fmaxf(sqrtf(rowsq[i]), 1e-12f) : 1.0f;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (tok < n && j == 0) {
+    if (bi == 0x7fffffff) bi = 0;      // a row of NaN scores: no comparison ever succeeds
+    lab32[tok] = bi;
+    if (lab64) lab64[tok] = bi;
+    if (nrm) nrm[tok] = norm_descs ? fmaxf(sqrtf(rowsq[tok]), 1e-12f) : 1.0f;
+  }
 }
 
 // VLAD:   dst[img][k*D + d]  = sum_{n in img, label_n == k} (x[n,d]/nrm_n - c[k,d])
@@ -87,8 +99,9 @@ template <bool KMEANS>
 __global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict__ x, const int64_t* __restrict__ offsets,
                                                         int64_t chunk_rows, int64_t total, int D, int K,
                                                         const int* __restrict__ lab, const float* __restrict__ nrm,
-                                                        const float* __restrict__ c, float* __restrict__ dst) {
-  extern __shared__ float acc[];   // [K][SL]
+                                                        const float* __restrict__ c, float* __restrict__ dst,
+                                                        unsigned* __restrict__ cnt_part) {
+  extern __shared__ float acc[];   // [K][SL] (+ [K] label histogram for the k-means column-slice 0)
   const int tid = threadIdx.x;
   const int d = blockIdx.x * SL + tid;
   const int64_t g = blockIdx.y;
@@ -133,6 +146,15 @@ __global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict_
     float* o = dst + g * (int64_t)K * D + d;
     for (int k = 0; k < K; ++k) o[(int64_t)k * D] = acc[k * SL + tid];
   }
+  if (KMEANS && blockIdx.x == 0 && cnt_part) {
+    // per-chunk label histogram (LDS atomics), reduced over chunks in a fixed order afterwards
+    unsigned* hist = reinterpret_cast<unsigned*>(acc + K * SL);
+    for (int k = tid; k < K; k += SL) hist[k] = 0u;
+    __syncthreads();
+    for (int64_t i = n0 + tid; i < n1; i += SL) atomicAdd(&hist[lab[i]], 1u);
+    __syncthreads();
+    for (int k = tid; k < K; k += SL) cnt_part[g * K + k] = hist[k];
+  }
 }
 
 // per image: optional intra-norm of each [D] block, then global norm of the [K*D] vector (in place)
@@ -176,14 +198,13 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
   sums[i] = s;
 }
 
-__global__ __launch_bounds__(256) void count_labels_kernel(const int* __restrict__ lab, int64_t n,
-                                                           unsigned* __restrict__ cnt) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) atomicAdd(&cnt[lab[i]], 1u);
-}
-__global__ void counts_to_float_kernel(const unsigned* __restrict__ cnt, float* __restrict__ out, int K) {
+__global__ void reduce_counts_kernel(const unsigned* __restrict__ cnt_part, int64_t n_chunks, int K,
+                                     float* __restrict__ counts) {
   const int k = threadIdx.x;
-  if (k < K) out[k] = (float)cnt[k];
+  if (k >= K) return;
+  unsigned long long t = 0;
+  for (int64_t ch = 0; ch < n_chunks; ++ch) t += cnt_part[ch * K + k];
+  counts[k] = (float)t;
 }
 
 // soft assignment weights: w[n,k] = softmax_k(temp * cos(x_n, c_k)),  F.cosine_similarity eps 1e-8:
@@ -328,7 +349,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     ANYLOC_TRY(run_scores(tokens, total_tokens, D, w, K, false, stream, "vlad_scores_gemm"));
     {
       ProfScope prof("vlad_assign", stream, 0.0, 4.0 * total_tokens * (kp + 4));
-      hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((total_tokens + 255) / 256)), dim3(256), 0, stream, w.scores,
+      hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((total_tokens + 7) / 8)), dim3(256), 0, stream, w.scores,
                          kp, (int)K, w.rowsq, total_tokens, w.lab32, labels, w.nrm,
                          (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0);
       ANYLOC_TRY(launch_status("assign_kernel"));
@@ -350,7 +371,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
       const int64_t cnt = std::min<int64_t>(65535, n_img - i0);
       hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((D + SL - 1) / SL), (unsigned)cnt), dim3(SL), lds,
                          stream, tokens, offsets + i0, (int64_t)0, total_tokens, (int)D, (int)K, w.lab32, w.nrm,
-                         centers, out + i0 * K * D);
+                         centers, out + i0 * K * D, (unsigned*)nullptr);
       ANYLOC_TRY(launch_status("accumulate_kernel"));
     }
   }
@@ -420,7 +441,7 @@ size_t anyloc_kmeans_workspace_bytes(int64_t n, int64_t D, int64_t K) {
   size_t b = carve(nullptr, 0, n, D, K).bytes;
   const int64_t rows = kmeans_chunk_rows(n), chunks = (n + rows - 1) / rows;
   b += align_up((size_t)(chunks > 0 ? chunks : 1) * K * D * sizeof(float), 256);
-  b += align_up(256 * sizeof(unsigned), 256);
+  b += align_up((size_t)(chunks > 0 ? chunks : 1) * K * sizeof(unsigned), 256);
   return b + 256;
 }
 
@@ -441,7 +462,7 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
   Arena tail(static_cast<char*>(workspace) + w.bytes, workspace_bytes - w.bytes);
   const int64_t rows = kmeans_chunk_rows(n), chunks = (n + rows - 1) / rows;
   float* part = tail.take<float>(chunks * K * D);
-  unsigned* cnt = tail.take<unsigned>(256);
+  unsigned* cnt_part = tail.take<unsigned>(chunks * K);
   const int kp = (int)kpad_of(K);
 
   hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, mode);
@@ -449,23 +470,23 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
   ANYLOC_TRY(run_scores(x, n, D, w, K, mode == 1, stream, "kmeans_scores_gemm"));
   {
     ProfScope prof("kmeans_assign", stream, 0.0, 4.0 * n * (kp + 2));
-    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w.scores, kp, (int)K,
+    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, stream, w.scores, kp, (int)K,
                        w.rowsq, n, w.lab32, labels, (float*)nullptr, 0);
     ANYLOC_TRY(launch_status("assign_kernel"));
   }
   {
-    const size_t lds = (size_t)K * SL * sizeof(float);
+    const size_t lds = (size_t)K * SL * sizeof(float) + (size_t)K * sizeof(unsigned);
     static bool attr = false;
     if (!attr) {
       ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 129 * 1024));
       attr = true;
     }
-    ANYLOC_CHECK_ARG(lds <= 128 * 1024, "kmeans_step: K=%lld needs %zu B of LDS", (long long)K, lds);
+    ANYLOC_CHECK_ARG(lds <= 129 * 1024, "kmeans_step: K=%lld needs %zu B of LDS", (long long)K, lds);
     ProfScope prof("kmeans_accumulate", stream, 1.0 * n * D, 4.0 * ((double)n * D + (double)chunks * K * D));
     hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((D + SL - 1) / SL), (unsigned)chunks), dim3(SL), lds,
                        stream, x, (const int64_t*)nullptr, rows, n, (int)D, (int)K, w.lab32, (const float*)nullptr,
-                       (const float*)nullptr, part);
+                       (const float*)nullptr, part, cnt_part);
     ANYLOC_TRY(launch_status("accumulate_kernel<kmeans>"));
   }
   {
@@ -474,11 +495,8 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
                        K * D, sums);
     ANYLOC_TRY(launch_status("reduce_chunks_kernel"));
   }
-  ANYLOC_HIP(hipMemsetAsync(cnt, 0, 256 * sizeof(unsigned), stream));
-  hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w.lab32, n, cnt);
-  ANYLOC_TRY(launch_status("count_labels_kernel"));
-  hipLaunchKernelGGL(counts_to_float_kernel, dim3(1), dim3(256), 0, stream, cnt, counts, (int)K);
-  return launch_status("counts_to_float_kernel");
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(256), 0, stream, cnt_part, chunks, (int)K, counts);
+  return launch_status("reduce_counts_kernel");
 }
 
 }  // extern "C"

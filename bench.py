@@ -163,8 +163,17 @@ def main():
         gt_timed = gt[warm * B:total_steps * B]
         rec = retrieval.recalls_from_indices([1, 5, 10], idx_all, gt_timed)
     else:
+        # merged lists are ordered rank-major within a step; rank r's query j of step i depicts global
+        # database row r*N_DB + i*B + j (its own shard's place)
         idx_all = np.concatenate([r[1] for r in results])
-        rec = None
+        gt_timed = np.empty(len(idx_all), dtype=object)
+        n = 0
+        for i in range(warm, total_steps):
+            for r in range(world):
+                for j in range(B):
+                    gt_timed[n] = np.array([r * N_DB + i * B + j])
+                    n += 1
+        rec = retrieval.recalls_from_indices([1, 5, 10], idx_all, gt_timed)
 
     # ---------------- roofline of the dominant kernel --------------------------------------
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])

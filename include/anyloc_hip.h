@@ -51,6 +51,19 @@ const char* anyloc_last_error(void);
 int anyloc_l2norm_rows(const float* x, float* out, int64_t rows, int64_t dim,
                        float eps, void* stream);
 
+/* ------------------------------------------------------------ ingest ----
+ * uint8 HWC images -> float32 CHW model input in one pass: centre crop to
+ * crop_h x crop_w (torchvision rule: top = round_half_even((H - crop_h) / 2)),
+ * x / 255, (x - mean[c]) / std[c].
+ * replaces: ToTensor + Normalize (dvgl_benchmark/datasets_ws.py:20-23) and the
+ *   CenterCrop to multiples of 14 (scripts/dino_v2_vlad.py:173-176,
+ *   demo/anyloc_vlad_generate.py:179-181) that precede the extractor.
+ *   img_hwc [B,H,W,3] uint8 (device), mean3/std3: HOST arrays of 3 floats,
+ *   out [B,3,crop_h,crop_w] float32 (device). */
+int anyloc_preprocess_u8(const unsigned char* img_hwc, int64_t batch, int64_t height,
+                         int64_t width, int64_t crop_h, int64_t crop_w,
+                         const float* mean3, const float* std3, float* out, void* stream);
+
 /* ------------------------------------------------------------- matmul ----
  * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N] when bias != NULL): the fp32 MFMA GEMM
  * all dense contractions of the path run on (torch Linear layout: both

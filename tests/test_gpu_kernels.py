@@ -85,3 +85,21 @@ def test_attention(dev, B, T, heads):
     ref = (a @ v).transpose(1, 2).reshape(B, T, D)
     assert float((out.double() - ref).abs().max()) < 2e-5, float((out.double() - ref).abs().max())
     assert _rel(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (333, 481), (126, 155)])
+def test_preprocess_u8_matches_totensor_normalize_centercrop(dev, H, W):
+    """uint8 HWC -> float CHW ingest == ToTensor + Normalize + CenterCrop(h//14*14, w//14*14), bit-exact."""
+    from anyloc_amd import preprocess, synth
+    g = torch.Generator().manual_seed(H + W)
+    u8 = torch.randint(0, 256, (3, H, W, 3), generator=g, dtype=torch.uint8)
+    out = preprocess.images_to_input(u8).cpu()
+    x = u8.permute(0, 3, 1, 2).float().div(255)
+    mean = torch.tensor(synth.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(synth.IMAGENET_STD).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    th, tw = H // 14 * 14, W // 14 * 14
+    t, l = int(round((H - th) / 2.0)), int(round((W - tw) / 2.0))
+    ref = x[..., t:t + th, l:l + tw]
+    assert out.shape == ref.shape
+    assert torch.equal(out, ref)
