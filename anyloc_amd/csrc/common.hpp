@@ -116,4 +116,22 @@ int facet_rows(const float* src, int64_t lds_, int coff, float* out, int64_t ldo
 int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads,
               hipStream_t stream);
 
+// single-pass fused VLAD / k-means (vlad_fused.hip)
+struct FusedArgs {
+  const float* x;          // [total, D] tokens / rows
+  const int64_t* offsets;  // VLAD: [units+1] token offsets (device); k-means: null
+  int64_t chunk_rows;      // k-means: rows per unit
+  int64_t total;           // total rows
+  int D, K;
+  const float* chat;       // [32, D] fpk-normalised centres (rows >= K are zero)
+  const float* cbias;      // [32] additive score bias (euclidean mode) or zeros
+  const float* centers;    // [K, D] raw centres (VLAD residual) or null
+  float* out;              // VLAD: [units, K*D]; k-means: [units, K, D] partial sums
+  unsigned* cnt_part;      // k-means: [units, K] label counts; VLAD: null
+  int64_t* lab64;          // optional [total] labels
+  int norm_descs, intra;
+};
+bool fused_supported(int64_t D, int64_t K);
+int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream);
+
 }  // namespace anyloc

@@ -5,7 +5,11 @@
 // generate_multi :892-926, and the fast-pytorch-kmeans assign/update loop
 // reached from VLAD.fit :766,:786 and predict :849.
 //
-// Stages (all on the caller's stream):
+// Default path (K <= 32 and D in {384, 768, 1024, 1536}): center_prep + ONE fused single-pass
+// kernel (vlad_fused.hip).  This file holds the general two-pass path used for every other shape
+// (and with ANYLOC_VLAD_TWO_PASS=1), the soft-assignment variant and the k-means wrappers.
+//
+// Two-pass stages (all on the caller's stream):
 //   1. center_prep      chat_k = c_k / (||c_k|| + 1e-8)  (fpk cos_sim), zero-padded to 32 rows
 //   2. gemm_nt(+rowsq)  scores[n,k] = x_n . chat_k on fp32 MFMA; the same pass
 //                       accumulates ||x_n||^2 while staging the token tiles.
@@ -18,6 +22,7 @@
 //   5. finalize         intra-norm of each cluster block, then the global L2 norm.
 // HBM-bound: algorithmic bytes per image = (N*D + 2*K*D) * 4.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -273,6 +278,16 @@ __global__ __launch_bounds__(SL) void soft_accumulate_kernel(const float* __rest
 
 inline int64_t kpad_of(int64_t K) { return (K + 31) / 32 * 32; }
 
+// ANYLOC_VLAD_TWO_PASS=1 selects the two-pass path even where the fused kernel applies (A/B tests)
+inline bool two_pass_forced() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ANYLOC_VLAD_TWO_PASS");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 struct VladWs {
   float *chat, *cb, *scores, *rowsq, *nrm;
   int* lab32;
@@ -340,6 +355,22 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     return ANYLOC_ERR_WORKSPACE;
   }
   const int kp = (int)kpad_of(K);
+  if (fused_supported(D, K) && !two_pass_forced()) {
+    // single-pass fused kernel (vlad_fused.hip): tokens are read from HBM once
+    {
+      ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
+      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, 0);
+      ANYLOC_TRY(launch_status("center_prep_kernel"));
+    }
+    FusedArgs fa{};
+    fa.x = tokens; fa.offsets = offsets; fa.total = total_tokens;
+    fa.D = (int)D; fa.K = (int)K;
+    fa.chat = w.chat; fa.cbias = w.cb; fa.centers = centers;
+    fa.out = out; fa.lab64 = labels;
+    fa.norm_descs = (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0;
+    fa.intra = (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0;
+    return vlad_fused(fa, n_img, false, stream);
+  }
   if (total_tokens > 0) {
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
@@ -467,6 +498,22 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
 
   hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, mode);
   ANYLOC_TRY(launch_status("center_prep_kernel"));
+  if (fused_supported(D, K) && !two_pass_forced()) {
+    FusedArgs fa{};
+    fa.x = x; fa.chunk_rows = rows; fa.total = n;
+    fa.D = (int)D; fa.K = (int)K;
+    fa.chat = w.chat; fa.cbias = w.cb;
+    fa.out = part; fa.cnt_part = cnt_part; fa.lab64 = labels;
+    ANYLOC_TRY(vlad_fused(fa, chunks, true, stream));
+    {
+      ProfScope prof("kmeans_reduce", stream, 1.0 * chunks * K * D, 4.0 * (chunks + 1.0) * K * D);
+      hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((K * D + 255) / 256)), dim3(256), 0, stream, part,
+                         chunks, K * D, sums);
+      ANYLOC_TRY(launch_status("reduce_chunks_kernel"));
+    }
+    hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(256), 0, stream, cnt_part, chunks, (int)K, counts);
+    return launch_status("reduce_counts_kernel");
+  }
   ANYLOC_TRY(run_scores(x, n, D, w, K, mode == 1, stream, "kmeans_scores_gemm"));
   {
     ProfScope prof("kmeans_assign", stream, 0.0, 4.0 * n * (kp + 2));

@@ -1,0 +1,319 @@
+// Single-pass fused VLAD / k-means kernel: tokens are read from HBM exactly once.
+//
+// replaces (reference utilities.py): kmeans.predict :849 + generate_res_vec :959-962 + the
+// per-cluster sums / intra-norm / global norm of VLAD.generate :854-861,:889 (VLAD mode), and the
+// assign + update body of fast-pytorch-kmeans' fit loop reached from VLAD.fit :786 (k-means mode).
+//
+// One 1024-thread workgroup (16 waves, one per CU) owns a *unit*: an image (VLAD) or a chunk of
+// rows (k-means).  It walks the unit's tokens in tiles of 16:
+//   stage   16 x D tile: coalesced buffer loads (rows past the unit read as 0) -> VGPR -> LDS,
+//           issued one tile ahead of its use
+//   score   waves 0-7: S[16 x 32] partials over their D/8 slice on v_mfma_f32_16x16x4_f32
+//           (A = tile from LDS, B = fpk-normalised centres from L2); the A fragments also give the
+//           row norms ||x_n||
+//   assign  512 threads: sum of the 8 partials in fixed order, first-arg-max over k by shuffles
+//   gather  all 1024 threads: thread (k = tid/32, j = tid%32) owns columns 4j + 128m of cluster
+//           k in REGISTERS; for every token of the tile assigned to k it adds x/||x|| - c_k
+//           (VLAD) or x (k-means).  Every (k, d) has exactly one owner and tokens are visited
+//           in order: no atomics, deterministic.
+// VLAD mode finishes in the same launch: per-cluster L2 norm by a 32-lane shuffle reduction
+// (one cluster = half a wave), global norm by a block reduction, one coalesced store.
+// HBM bound: algorithmic bytes per image = (N*D + 2*K*D) * 4; LDS: 16*(D+4)*4 + 16 KiB + small.
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+constexpr int TT = 16;       // tokens per tile
+constexpr int NTH = 1024;    // threads per workgroup
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes of one half wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// NV = D / 128: float4 columns per owner thread (and 16-wide k-groups per scoring wave)
+template <int NV, bool KMEANS>
+__global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
+  constexpr int D = NV * 128;
+  constexpr int LD = D + 4;                  // padded LDS row: conflict-free ds_read_b128 of A fragments
+  constexpr int NF = (NV + 1) / 2;           // staged float4 per thread per tile (4*D/1024 = NV/2)
+  constexpr int SW = 8;                      // scoring waves 0-7: each contracts a D/8 slice
+  constexpr int NG = NV;                     // 16-wide k-groups per scoring wave
+  // vmcnt retires in order PER WAVE: a wave that has the HBM loads of the next tile in flight
+  // stalls on them at its next L2 load.  So the scoring waves (0-7) issue their share of the
+  // next tile only AFTER their scoring loop, the other waves (8-15) at the top of the iteration;
+  // all 16 waves stage 1/16 of the tile and are owners in the gather phase.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;                         // [TT][LD]
+  float* part = tile + TT * LD;              // [SW][TT][32] score partials
+  float* rsqp = part + SW * TT * 32;         // [SW][TT] row sum-of-squares partials
+  float* nrm = rsqp + SW * TT;               // [TT]
+  int* lab = reinterpret_cast<int*>(nrm + TT);   // [TT]
+  float* red = reinterpret_cast<float*>(lab + TT);   // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t unit = blockIdx.x;
+  int64_t n0, n1;
+  if (KMEANS) {
+    n0 = unit * a.chunk_rows;
+    n1 = min(n0 + a.chunk_rows, a.total);
+  } else {
+    n0 = a.offsets[unit];
+    n1 = a.offsets[unit + 1];
+  }
+  const int64_t nrows = n1 - n0;
+  const int ntiles = (int)((nrows + TT - 1) / TT);
+
+  // ---- staging: thread owns float4 slots f = tid + 1024*i of the [16][D/4] tile ----
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + n0 * D), 0, (int)min<int64_t>(nrows * D * 4, 0x7fffffff), 0x00020000);
+  f32x4 stg[NF];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // thread owns float4 slots f = tid + 1024*i of the [16][D/4] tile; slot -> (row, column) is
+  // recomputed where needed (constant divisor) to save registers
+  const bool scorer = wave < 8;
+  auto fetch = [&](int t) {
+    const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int f = tid + NTH * i, row = f / (D / 4), c4 = f - row * (D / 4);
+      stg[i] = (f < TT * (D / 4)) ? bload16(x_rsrc, (unsigned)((row * D + 4 * c4) * 4), so) : zero4;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int f = tid + NTH * i, row = f / (D / 4), c4 = f - row * (D / 4);
+      if (f < TT * (D / 4)) *reinterpret_cast<f32x4*>(tile + row * LD + 4 * c4) = stg[i];
+    }
+  };
+
+  // ---- owner coordinates: cluster k = tid / 32, columns 4*j + 128*m ----
+  const int ok_ = tid >> 5, oj = tid & 31;
+  f32x4 acc[NV];
+#pragma unroll
+  for (int m = 0; m < NV; ++m) acc[m] = zero4;
+  unsigned my_count = 0;
+  const bool k_live = ok_ < a.K;
+  // raw centres of this owner's cluster (VLAD residual): descriptor over [K, D], constant lane offset
+  const __amdgpu_buffer_rsrc_t cen_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(KMEANS ? a.chat : a.centers), 0, (KMEANS ? 32 : a.K) * D * 4, 0x00020000);
+  const unsigned cen_off = (unsigned)((ok_ * D + 4 * oj) * 4);
+
+  // ---- scoring coordinates (waves < SW): D/SW slice, 16x16x4 MFMA fragments ----
+  const int sw = wave & (SW - 1);
+  const int fr = lane & 15, fq = lane >> 4;            // fragment row / k-quad
+  const __amdgpu_buffer_rsrc_t c_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.chat), 0, 32 * D * 4, 0x00020000);
+  const unsigned b_off0 = (unsigned)(((fr)*D + sw * (D / SW) + 4 * fq) * 4);
+  const unsigned b_off1 = (unsigned)(((16 + fr) * D + sw * (D / SW) + 4 * fq) * 4);
+  const float* a_frag = tile + fr * LD + sw * (D / SW) + 4 * fq;
+
+  if (ntiles > 0) {
+    fetch(0);
+    stash();
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    if (!scorer && t + 1 < ntiles) fetch(t + 1);
+    const int valid = (int)min<int64_t>(TT, nrows - (int64_t)t * TT);
+
+    if (wave < SW) {
+      // ---- scores: S[16 tokens][32 centres] over this wave's D/SW slice; the same A fragments
+      //      give the row sum-of-squares for free ----
+      f32x4 s0 = zero4, s1 = zero4;
+      float rs = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a_frag + 16 * g);
+        const f32x4 b0 = bload16(c_rsrc, b_off0, (unsigned)(64 * g));
+        const f32x4 b1 = bload16(c_rsrc, b_off1, (unsigned)(64 * g));
+        if (!KMEANS) rs += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b0[e], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b1[e], s1, 0, 0, 0);
+        }
+      }
+      // C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + reg
+      float* p = part + sw * (TT * 32) + (4 * fq) * 32 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r * 32] = s0[r];
+        p[r * 32 + 16] = s1[r];
+      }
+      if (!KMEANS) {
+        rs += __shfl_xor(rs, 16, 64);      // the four k-quads of token row fr
+        rs += __shfl_xor(rs, 32, 64);
+        if (fq == 0) rsqp[sw * TT + fr] = rs;
+      }
+      if (t + 1 < ntiles) fetch(t + 1);    // only now: the B-operand loads above are retired
+    }
+    __syncthreads();
+
+    if (tid < 512) {
+      // ---- assign: fixed-order sum of the SW partials, first arg-max over k < K ----
+      const int row = tid >> 5, k = tid & 31;
+      float s = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < SW; ++w2) s += part[w2 * (TT * 32) + row * 32 + k];
+      if (!KMEANS && k == 0) {
+        float q = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < SW; ++w2) q += rsqp[w2 * TT + row];
+        nrm[row] = a.norm_descs ? fmaxf(sqrtf(q), 1e-12f) : 1.0f;
+      }
+      s += a.cbias[k];
+      float best = (k < a.K) ? s : -INFINITY;
+      int bi = (k < a.K && best == best) ? k : 0x7fffffff;
+      if (!(best == best)) best = -INFINITY;          // NaN score never wins
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (k == 0) {
+        if (bi == 0x7fffffff) bi = 0;
+        const bool live = row < valid;
+        lab[row] = live ? bi : -1;
+        if (live && a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
+      }
+    }
+    __syncthreads();
+
+    // ---- gather: owners add their tokens (in order) ----
+    if (k_live) {
+      const float* tp = tile + 4 * oj;
+      unsigned mine = 0;                                // bit n: token n of the tile is assigned to my cluster
+#pragma unroll
+      for (int n = 0; n < TT; n += 4) {
+        const i32x4_t q = *reinterpret_cast<const i32x4_t*>(lab + n);   // int vector: may alias lab[]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine |= (q[e] == ok_ ? 1u : 0u) << (n + e);
+      }
+      for (int n = 0; n < TT; ++n) {
+        if (!((mine >> n) & 1u)) continue;
+        const float* rp = tp + n * LD;
+        if (KMEANS) {
+#pragma unroll
+          for (int m = 0; m < NV; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 128 * m);
+            acc[m][0] += v[0]; acc[m][1] += v[1]; acc[m][2] += v[2]; acc[m][3] += v[3];
+          }
+          if (oj == 0) ++my_count;
+        } else {
+          const float inv = 1.0f / nrm[n];          // x * (1/||x||): within 1 ulp of F.normalize's x / ||x||
+#pragma unroll
+          for (int m = 0; m < NV; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 128 * m);
+            const f32x4 c = bload16(cen_rsrc, cen_off, (unsigned)(512 * m));
+            acc[m][0] += v[0] * inv - c[0];
+            acc[m][1] += v[1] * inv - c[1];
+            acc[m][2] += v[2] * inv - c[2];
+            acc[m][3] += v[3] * inv - c[3];
+            // keep at most four column groups in flight: the 128-VGPR budget of a 1024-thread
+            // workgroup cannot hold all NV loads at once next to the accumulators
+            if ((m & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) stash();
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if (KMEANS) {
+    if (k_live) {
+      float* o = a.out + (unit * a.K + ok_) * (int64_t)D + 4 * oj;
+#pragma unroll
+      for (int m = 0; m < NV; ++m) *reinterpret_cast<f32x4*>(o + 128 * m) = acc[m];
+      if (oj == 0) a.cnt_part[unit * a.K + ok_] = my_count;
+    }
+    return;
+  }
+  // VLAD: intra-norm of each cluster block (its 32 owners = half a wave), then the global norm
+  float ss = 0.f;
+#pragma unroll
+  for (int m = 0; m < NV; ++m) ss += acc[m][0] * acc[m][0] + acc[m][1] * acc[m][1] + acc[m][2] * acc[m][2] + acc[m][3] * acc[m][3];
+  ss = half_wave_sum(ss);
+  if (a.intra) {
+    const float kn = fmaxf(sqrtf(ss), 1e-12f);
+    ss = 0.f;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      acc[m][0] /= kn; acc[m][1] /= kn; acc[m][2] /= kn; acc[m][3] /= kn;
+      ss += acc[m][0] * acc[m][0] + acc[m][1] * acc[m][1] + acc[m][2] * acc[m][2] + acc[m][3] * acc[m][3];
+    }
+    ss = half_wave_sum(ss);
+  }
+  if (oj == 0) red[ok_] = k_live ? ss : 0.f;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) tot += red[k];
+  const float gn = fmaxf(sqrtf(tot), 1e-12f);
+  if (k_live) {
+    float* o = a.out + (unit * a.K + ok_) * (int64_t)D + 4 * oj;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      f32x4 v = acc[m];
+      v[0] /= gn; v[1] /= gn; v[2] /= gn; v[3] /= gn;
+      *reinterpret_cast<f32x4*>(o + 128 * m) = v;
+    }
+  }
+}
+
+template <int NV, bool KMEANS>
+int launch_fused(const FusedArgs& a, int64_t units, hipStream_t stream) {
+  constexpr int D = NV * 128;
+  constexpr int SW = 8;
+  const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + 32);
+  auto kern = vlad_fused_kernel<NV, KMEANS>;
+  static bool attr = false;
+  if (!attr) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    attr = true;
+  }
+  const double bytes = 4.0 * ((double)a.total * D + 2.0 * (double)units * a.K * D);
+  ProfScope prof(KMEANS ? "kmeans_fused" : "vlad_fused", stream, 2.0 * a.total * D * 32, bytes);
+  hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(NTH), lds, stream, a);
+  return launch_status("vlad_fused_kernel");
+}
+
+}  // namespace
+
+bool fused_supported(int64_t D, int64_t K) {
+  return K >= 1 && K <= 32 && (D == 384 || D == 768 || D == 1024 || D == 1536);
+}
+
+int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream) {
+  if (units <= 0) return ANYLOC_OK;
+  ANYLOC_CHECK_ARG(units < (1ll << 31), "vlad_fused: too many units");
+#define ANYLOC_FUSED_CASE(NV)                                                      \
+  case NV * 128:                                                                   \
+    return kmeans ? launch_fused<NV, true>(a, units, stream) : launch_fused<NV, false>(a, units, stream);
+  switch (a.D) {
+    ANYLOC_FUSED_CASE(3)
+    ANYLOC_FUSED_CASE(6)
+    ANYLOC_FUSED_CASE(8)
+    ANYLOC_FUSED_CASE(12)
+    default:
+      set_error("vlad_fused: unsupported D=%d", a.D);
+      return ANYLOC_ERR_UNSUPPORTED;
+  }
+#undef ANYLOC_FUSED_CASE
+}
+
+}  // namespace anyloc

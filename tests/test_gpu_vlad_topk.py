@@ -121,6 +121,28 @@ def test_kmeans_golden_and_oracle(golden_dir):
     assert float(counts[5:].sum()) == 0.0
 
 
+@pytest.mark.parametrize("n,D,K,mode", [(5003, 384, 16, "cosine"), (3000, 1536, 32, "cosine"),
+                                        (2500, 768, 7, "euclidean"), (17, 1024, 3, "cosine")])
+def test_kmeans_step_fused_path_vs_oracle(n, D, K, mode):
+    """Shapes served by the single-pass fused kernel (D in {384,768,1024,1536}, K <= 32): one
+    assign + accumulate step against the fast-pytorch-kmeans rule, incl. ragged last tile / chunk."""
+    from anyloc_amd import ops
+    from oracle.fpk_kmeans import KMeans as RefKM
+    x = synth.clustered_tokens(1, n, D, n_modes=max(K - 1, 2), seed=n + K, noise=0.5)[0]
+    g = torch.Generator().manual_seed(K)
+    x = x * (0.5 + torch.rand(n, 1, generator=g))
+    c = x[torch.randperm(n, generator=g)[:K]].clone() + 0.01 * torch.randn(K, D, generator=g)
+    sums, counts, lab = ops.kmeans_step(x.to(DEV), c.to(DEV), mode, True)
+    sim = RefKM.cos_sim(x, c) if mode == "cosine" else RefKM.euc_sim(x, c)
+    ref_lab = sim.max(dim=-1)[1]
+    flips = check_labels(lab, ref_lab, x, c) if mode == "cosine" else int((lab.cpu() != ref_lab).sum())
+    assert flips <= 1
+    lab_c = lab.cpu()
+    onehot = (lab_c[None] == torch.arange(K)[:, None]).double()
+    assert torch.equal(counts.cpu(), onehot.sum(-1).float())
+    assert l2rel(sums, onehot @ x.double()) < 1e-6
+
+
 def test_vlad_fit_surface_matches_reference_semantics(golden_dir, capsys):
     """utilities.VLAD.fit -> generate_multi on CPU tensors (the reference's calling convention)."""
     import utilities
