@@ -122,10 +122,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       lsum += __shfl_xor(lsum, 32, 64);
       l_run = l_run * alpha + lsum;
       m_run = m_new;
-      if (!__all(alpha == 1.0f)) {   // the running max rarely moves after the first tiles (x * 1.0f is exact)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-      }
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
       // O^T[d][q] += sum_key V[key][d] * P[q][key]:  A = V^T (rows = d), B = P^T (sacc)
       const float* vp = &Vs[buf][4 * h2][ql];
 #pragma unroll

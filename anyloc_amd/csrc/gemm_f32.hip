@@ -349,6 +349,11 @@ int launch_wide(const GemmProblem& p, hipStream_t stream) {
 
 template <int EPI>
 int launch_wide_k(const GemmProblem& p, hipStream_t stream) {
+  // Few-row problems (B = 1 as the reference's scripts call the extractor: M = 530): a 128x128 grid
+  // would not even give every CU one block -- halve the tile height (64x128, 2x2 waves of 32x64).
+  const int64_t tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (gemm_cfg() == 0 && tiles128 < 256 && p.K % 32 == 0)
+    return launch_cfg<64, 128, 2, 2, 32, 2, EPI, false, true>(p, stream);
   return (p.K % 32 == 0) ? launch_wide<EPI, true>(p, stream) : launch_wide<EPI, false>(p, stream);
 }
 
