@@ -97,7 +97,9 @@ def main():
     sd = synth.synthetic_state_dict(MODEL, seed=0, device=str(dev))
     weights.register_state_dict(MODEL, sd)
     ext = utilities.DinoV2ExtractFeatures(MODEL, LAYER, FACET, device=str(dev))
-    n_places = total_steps * B
+    # distinct places: one block of B per step, at most ~1024 (longer runs cycle through the blocks)
+    n_blocks = min(total_steps, max(1, 1024 // B))
+    n_places = n_blocks * B
     db_img, qu_img, gt = synth.synthetic_places(n_places, n_places, HW, HW, seed=42 + rank, device=str(dev))
     vlad = utilities.VLAD(K_CLUSTERS, None, cache_dir=None)
     # vocabulary: k-means (HIP assign+update kernel) on the tokens of the first database images
@@ -118,7 +120,8 @@ def main():
     results = []
 
     def step(i):
-        imgs = qu_img[i * B:(i + 1) * B]
+        blk = i % n_blocks
+        imgs = qu_img[blk * B:(blk + 1) * B]
         tokens = ext(imgs)                                   # [B,529,1536] on device
         q = vlad.generate_multi(tokens)                      # [B,49152]
         if world == 1:
@@ -160,7 +163,10 @@ def main():
     # Recall@1 of the timed queries (rank 0's share): query i depicts place i of its own rank
     if world == 1:
         idx_all = torch.cat([r[1] for r in results]).cpu().numpy()
-        gt_timed = gt[warm * B:total_steps * B]
+        gt_timed = np.empty(len(idx_all), dtype=object)
+        for n, i in enumerate(range(warm, total_steps)):
+            for j in range(B):
+                gt_timed[n * B + j] = np.array([(i % n_blocks) * B + j])
         rec = retrieval.recalls_from_indices([1, 5, 10], idx_all, gt_timed)
     else:
         # merged lists are ordered rank-major within a step; rank r's query j of step i depicts global
@@ -171,7 +177,7 @@ def main():
         for i in range(warm, total_steps):
             for r in range(world):
                 for j in range(B):
-                    gt_timed[n] = np.array([r * N_DB + i * B + j])
+                    gt_timed[n] = np.array([r * N_DB + (i % n_blocks) * B + j])
                     n += 1
         rec = retrieval.recalls_from_indices([1, 5, 10], idx_all, gt_timed)
 
@@ -241,7 +247,7 @@ def cpu_baseline_and_parity(sd, qu_img, vlad, db, ext, budget_s, warm, B):
     cores = threads
     centers = vlad.c_centers.cpu()
     db_slice = db[:2000].cpu()
-    imgs = qu_img[warm * B:(warm + 1) * B].cpu()
+    imgs = qu_img[:B].cpu()
     t_used, n_done = 0.0, 0
     toks, vl = [], []
     t_all0 = time.perf_counter()
