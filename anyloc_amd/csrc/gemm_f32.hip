@@ -214,9 +214,43 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
     }
     if (!(ABL & 2)) __syncthreads();
   };
-  for (int kt = 0; kt < nk; kt += 2) {
-    slab(kt, I0{});
-    if (kt + 1 < nk) slab(kt + 1, I1{});
+  if constexpr ((ABL & 32) != 0) {
+    // Chunked summation for very long contractions (retrieval: K = 49 152): every 64 slabs (2048 k)
+    // the running accumulators are folded into a second set, so the fp32 rounding error grows with
+    // sqrt(2048) + sqrt(K/2048) instead of sqrt(K) (measured 1e-5 -> 2e-6 on unit-norm VLADs).
+    f32x16 tot[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.0f;
+    for (int kt = 0; kt < nk; kt += 2) {
+      slab(kt, I0{});
+      if (kt + 1 < nk) slab(kt + 1, I1{});
+      if ((kt & 63) == 62) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              tot[mi][ni][r] += acc[mi][ni][r];
+              acc[mi][ni][r] = 0.0f;
+            }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += tot[mi][ni][r];
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {
+      slab(kt, I0{});
+      if (kt + 1 < nk) slab(kt + 1, I1{});
+    }
   }
 
   if (ROWSQ) {
@@ -377,6 +411,8 @@ int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream) {
                        : launch_cfg<128, 32, 4, 1, 32, 2, EPI_STORE, false, false>(p, stream);
       }
       if (p.rowsq) return launch_cfg<128, 128, 2, 2, 32, 2, EPI_STORE, true, false>(p, stream);
+      if (p.K >= 8192 && p.K % 32 == 0 && gemm_cfg() == 0)      // long contraction: chunked summation
+        return launch_cfg<128, 128, 2, 2, 32, 2, EPI_STORE, false, true, 32>(p, stream);
       return launch_wide_k<EPI_STORE>(p, stream);
     case EPI_GELU:
       return launch_wide_k<EPI_GELU>(p, stream);
