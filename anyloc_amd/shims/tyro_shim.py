@@ -61,8 +61,20 @@ def _add(parser, cls, prefix, defaults, registry):
         elif origin in (list, typing.List):
             (elem,) = typing.get_args(base) or (str,)
             parser.add_argument(flag, nargs="+", type=_conv(elem), **kw)
-        elif origin is dict:
-            parser.add_argument(flag, type=str, **kw)
+        elif origin is dict or base is dict:
+            # a dict field with a default becomes one flag per key (tyro: --db-samples.st-lucia 1)
+            dflt = default if isinstance(default, dict) else {}
+            for key, val in dflt.items():
+                parser.add_argument(f"{flag}.{str(key).replace('_', '-')}", dest=f"{name}.{key}",
+                                    type=type(val) if val is not None else str, default=val)
+            registry[name] = ("dict", list(dflt.keys()))
+            continue
+        elif origin in (tuple, typing.Tuple):
+            targs = [t for t in typing.get_args(base) if t is not Ellipsis] or [str]
+            parser.add_argument(flag, nargs=len(typing.get_args(base)) if Ellipsis not in typing.get_args(base) else "+",
+                                type=_conv(targs[0]), **kw)
+            registry[name] = ("tuple", None)
+            continue
         else:
             conv = _conv(base)
             if optional:
@@ -77,7 +89,15 @@ def _build(cls, prefix, ns, registry):
     for f in dataclasses.fields(cls):
         name = prefix + f.name
         kind, sub = registry[name]
-        kwargs[f.name] = _build(sub, name + ".", ns, registry) if kind == "dataclass" else getattr(ns, name)
+        if kind == "dataclass":
+            kwargs[f.name] = _build(sub, name + ".", ns, registry)
+        elif kind == "dict":
+            kwargs[f.name] = {k: getattr(ns, f"{name}.{k}") for k in sub}
+        elif kind == "tuple":
+            v = getattr(ns, name)
+            kwargs[f.name] = tuple(v) if isinstance(v, list) else v
+        else:
+            kwargs[f.name] = getattr(ns, name)
     return cls(**kwargs)
 
 

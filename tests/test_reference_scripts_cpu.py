@@ -64,6 +64,32 @@ def test_dino_v2_vlad_script_unmodified(cpu_backend, tmp_path, capsys):
     assert "c_centers.pt" in pts and any(f.endswith("_r.pt") for f in pts) and any(f.endswith("_l.pt") for f in pts)
 
 
+def test_global_vocab_script_unmodified(cpu_backend, tmp_path, capsys):
+    """scripts/dino_v2_global_vocab_vlad.py (the caller of VLAD.fit that builds the shared
+    vocabularies): vocabulary from a pool of datasets' database images ->
+    c_centers.pt cache -> VLADs -> recall, unmodified, incl. the dict-valued --db-samples.* flags."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import make_synth_dataset
+    data = tmp_path / "data"
+    make_synth_dataset.write(str(data), "st_lucia", n_db=5, n_qu=2, h=112, w=112, seed=1)
+    make_synth_dataset.write(str(data), "pitts30k", n_db=4, n_qu=2, h=112, w=112, seed=2)
+    cache, vcache = tmp_path / "cache", tmp_path / "vlad_cache"
+    try:
+        launcher.main([os.path.join(REF, "scripts", "dino_v2_global_vocab_vlad.py"),
+                       "--prog.data-vg-dir", str(data), "--prog.cache-dir", str(cache),
+                       "--prog.vg-dataset-name", "st_lucia", "--model-type", "dinov2_vits14",
+                       "--desc-layer", "9", "--desc-facet", "value", "--num-clusters", "4",
+                       "--vlad-cache-dir", str(vcache), "--db-samples.st-lucia", "1",
+                       "--db-samples.pitts30k", "2", "--exp-id", "g1", "--top-k-vals", "1", "2"])
+    except SystemExit as e:
+        assert e.code in (0, None)
+    out = capsys.readouterr().out
+    assert "Traceback" not in out and "Unhandled exception" not in out, out[-3000:]
+    assert "R@1" in out and "END" in out
+    centers = torch.load(str(vcache / "c_centers.pt"))
+    assert tuple(centers.shape) == (4, 384) and centers.dtype == torch.float32 and centers.device.type == "cpu"
+
+
 def test_demo_vlad_generate_unmodified(cpu_backend, tmp_path, capsys, monkeypatch):
     from PIL import Image
     in_dir, out_dir = tmp_path / "imgs", tmp_path / "out"
