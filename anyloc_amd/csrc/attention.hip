@@ -11,6 +11,8 @@
 // holds 16 keys of ONE query: the online-softmax max/sum are in-register plus
 // one lane^32 exchange, the running rescale of O^T is a per-lane scalar, and
 // the probabilities are already in B-operand layout for O^T += V^T * P^T.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace anyloc {
@@ -21,8 +23,15 @@ constexpr int HD = 64;        // head dim
 constexpr int KT = 32;        // keys per tile
 constexpr int KLD = HD + 4;   // padded K row (ds_read_b128 conflict-free)
 
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           int T, int D, float scale) {
+// WB = waves (32-query tiles) per workgroup; FASTEXP = v_exp_f32-based exponential
+// PRELOAD: read the whole K fragment set and the whole V column set of a tile into registers before
+//          the MFMA chains that consume them (2 waves/SIMD instead of 3, but no LDS wait inside a chain)
+template <int WB, bool FASTEXP, bool PRELOAD>
+__global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int T, int D, float scale) {
+  constexpr int NT = 64 * WB;
+  constexpr int RPP = NT / 16;          // K/V rows staged per pass (16 lanes per 256-byte row)
+  constexpr int NLD = KT / RPP;         // staging passes per tile
   __shared__ __attribute__((aligned(16))) float Ks[2][KT][KLD];
   __shared__ __attribute__((aligned(16))) float Vs[2][KT][HD];
 
@@ -31,7 +40,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int64_t b = blockIdx.z;
   const int64_t ld = 3 * (int64_t)D;
   const float* base = qkv + b * T * ld;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * WB) + wave * 32;
   const int ql = lane & 31, h2 = lane >> 5;
   const bool wave_active = q0 < T;
 
@@ -54,24 +63,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int sr = tid >> 4, sc = tid & 15;
   const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(base), 0, (int)((int64_t)T * ld * 4), 0x00020000);
-  unsigned kv_off[2];
+  unsigned kv_off[NLD];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) kv_off[i] = (unsigned)(((int64_t)(sr + 16 * i) * ld + h * HD + 4 * sc) * 4);
+  for (int i = 0; i < NLD; ++i) kv_off[i] = (unsigned)(((int64_t)(sr + RPP * i) * ld + h * HD + 4 * sc) * 4);
   const unsigned k_col = (unsigned)D * 4, v_col = (unsigned)D * 8, tile_bytes = (unsigned)(KT * ld * 4);
-  f32x4 rk[2], rv[2];
+  f32x4 rk[NLD], rv[NLD];
   auto fetch = [&](int kt) {
     const unsigned so = (unsigned)kt * tile_bytes;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_off[i] + k_col, so, 0));
       rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_off[i] + v_col, so, 0));
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(&Ks[buf][sr + 16 * i][4 * sc]) = rk[i];
-      *reinterpret_cast<f32x4*>(&Vs[buf][sr + 16 * i][4 * sc]) = rv[i];
+    for (int i = 0; i < NLD; ++i) {
+      *reinterpret_cast<f32x4*>(&Ks[buf][sr + RPP * i][4 * sc]) = rk[i];
+      *reinterpret_cast<f32x4*>(&Vs[buf][sr + RPP * i][4 * sc]) = rv[i];
     }
   };
 
@@ -94,11 +103,29 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
       const float* kp = &Ks[buf][ql][4 * h2];
+      const float* vp = &Vs[buf][4 * h2][ql];
+      float vr[PRELOAD ? 32 : 1];
+      if constexpr (PRELOAD) {
+        f32x4 kf[8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * s);
+        for (int s = 0; s < 8; ++s) kf[s] = *reinterpret_cast<const f32x4*>(kp + 8 * s);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[s][j], sacc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const int krow = (r & 3) + 8 * (r >> 2);
+          vr[2 * r] = vp[krow * HD];
+          vr[2 * r + 1] = vp[krow * HD + 32];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s][j], qf[s][j], sacc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * s);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[s][j], sacc, 0, 0, 0);
+        }
       }
       // lane (ql, h2) now holds S[q = q0+ql][key = kt*32 + (r&3) + 8*(r>>2) + 4*h2]
       const int kbase = kt * KT + 4 * h2;
@@ -112,11 +139,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float m_new = fmaxf(m_run, mloc);
-      const float alpha = expf(m_run - m_new);
+      const float alpha = FASTEXP ? __expf(m_run - m_new) : expf(m_run - m_new);
       float lsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sacc[r] = expf(sacc[r] - m_new);
+        sacc[r] = FASTEXP ? __expf(sacc[r] - m_new) : expf(sacc[r] - m_new);
         lsum += sacc[r];
       }
       lsum += __shfl_xor(lsum, 32, 64);
@@ -125,11 +152,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
       // O^T[d][q] += sum_key V[key][d] * P[q][key]:  A = V^T (rows = d), B = P^T (sacc)
-      const float* vp = &Vs[buf][4 * h2][ql];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int krow = (r & 3) + 8 * (r >> 2);
-        const float v0 = vp[krow * HD], v1 = vp[krow * HD + 32];
+        const float v0 = PRELOAD ? vr[2 * r] : vp[krow * HD], v1 = PRELOAD ? vr[2 * r + 1] : vp[krow * HD + 32];
         oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], oacc[0], 0, 0, 0);
         oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], oacc[1], 0, 0, 0);
       }
@@ -164,8 +190,20 @@ int attention(const float* qkv, float* out, int64_t batch, int T, int D, int hea
   ANYLOC_CHECK_ARG(T > 0 && batch > 0 && batch < 65536, "attention: bad T/batch");
   const double flops = 4.0 * (double)batch * heads * (double)T * T * HD;
   ProfScope prof("attention", stream, flops, 16.0 * batch * T * D);
-  hipLaunchKernelGGL(attention_kernel, dim3((T + 127) / 128, heads, (unsigned)batch), dim3(256), 0, stream, qkv, out,
-                     T, D, 1.0f / 8.0f);
+  // ANYLOC_ATTN_CFG (micro-benchmarks): 0 = default (fast exp + operand preload), 1 = neither, 2 = fast exp, 3 = preload
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("ANYLOC_ATTN_CFG");
+    cfg = e ? atoi(e) : 0;
+  }
+  const dim3 g4((T + 127) / 128, heads, (unsigned)batch), g2((T + 63) / 64, heads, (unsigned)batch);
+  (void)g2;
+  switch (cfg) {
+    case 1: hipLaunchKernelGGL((attention_kernel<4, false, false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
+    case 2: hipLaunchKernelGGL((attention_kernel<4, true, false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
+    case 3: hipLaunchKernelGGL((attention_kernel<4, false, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
+    default: hipLaunchKernelGGL((attention_kernel<4, true, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
+  }
   return launch_status("attention_kernel");
 }
 
