@@ -381,14 +381,55 @@ int launch_wide(const GemmProblem& p, hipStream_t stream) {
   }
 }
 
+// Row split of a GEMM into a 128-row-tile part [0, m1) and a 64-row-tile part [m1, M).
+// 512 blocks are resident (2 per CU), so a grid runs in "rounds" of 512 tiles; a tile count just
+// above a multiple of 512 pays a whole extra round for a few tiles (B = 32: 133 x 12 = 1596 tiles
+// = 3.1 rounds).  Cost model in units of one full round of 128x128 tiles: a full round of 64x128
+// tiles costs 0.55 (half the work, ~10 % less efficient); a last partial round costs 0.6 of its
+// kind when it leaves every CU at most one block (<= 256 tiles), else a full one.
+double rounds_cost(int64_t tiles, double unit) {
+  const int64_t full = tiles / 512, last = tiles % 512;
+  return unit * ((double)full + (last == 0 ? 0.0 : (last <= 256 ? 0.6 : 1.0)));
+}
+int64_t plan_row_split(int64_t M, int64_t N) {
+  const int64_t tn = (N + 127) / 128;
+  const int64_t tm = (M + 127) / 128;
+  double best = 1e30;
+  int64_t best_m1 = M;
+  for (int64_t k = tm; k >= 0; --k) {      // ties -> the larger 128-row part
+    const int64_t m1 = k * 128 < M ? k * 128 : M;
+    const int64_t t128 = k * 128 < M ? k * tn : tm * tn;
+    const int64_t t64 = ((M - m1 + 63) / 64) * tn;
+    const double cost = rounds_cost(t128, 1.0) + rounds_cost(t64, 0.55) +
+                        ((t128 > 0 && t64 > 0) ? 0.02 : 0.0);     // the second launch is not free
+    if (cost < best - 1e-9) {
+      best = cost;
+      best_m1 = m1;
+    }
+  }
+  // the model is coarse: only leave the plain 128-row grid for a predicted gain of >= 4 %
+  return best < 0.96 * rounds_cost(tm * tn, 1.0) ? best_m1 : M;
+}
+
 template <int EPI>
 int launch_wide_k(const GemmProblem& p, hipStream_t stream) {
-  // Few-row problems (B = 1 as the reference's scripts call the extractor: M = 530): a 128x128 grid
-  // would not even give every CU one block -- halve the tile height (64x128, 2x2 waves of 32x64).
-  const int64_t tiles128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (gemm_cfg() == 0 && tiles128 < 256 && p.K % 32 == 0)
-    return launch_cfg<64, 128, 2, 2, 32, 2, EPI, false, true>(p, stream);
-  return (p.K % 32 == 0) ? launch_wide<EPI, true>(p, stream) : launch_wide<EPI, false>(p, stream);
+  if (gemm_cfg() != 0 || p.K % 32 != 0 || EPI == EPI_PATCH)
+    return (p.K % 32 == 0) ? launch_wide<EPI, true>(p, stream) : launch_wide<EPI, false>(p, stream);
+  const int64_t m1 = plan_row_split(p.M, p.N);
+  if (m1 > 0) {
+    GemmProblem a = p;
+    a.M = m1;
+    ANYLOC_TRY((launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, true>(a, stream)));
+  }
+  if (m1 < p.M) {
+    GemmProblem b = p;                      // rows [m1, M) on 64x128 tiles (2x2 waves of 32x64)
+    b.M = p.M - m1;
+    b.A = p.A + m1 * p.lda;
+    b.C = p.C + m1 * p.ldc;
+    if (p.resid) b.resid = p.resid + m1 * p.ldc;
+    ANYLOC_TRY((launch_cfg<64, 128, 2, 2, 32, 2, EPI, false, true>(b, stream)));
+  }
+  return ANYLOC_OK;
 }
 
 }  // namespace
