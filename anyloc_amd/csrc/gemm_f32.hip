@@ -59,6 +59,11 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
+// 16 bytes per lane straight from global memory into LDS (wave-uniform LDS base + lane * 16)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
   return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
 }
@@ -70,7 +75,13 @@ __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem p, int tiles_m, int tiles_n) {
   constexpr int NT = 64 * WM * WN;
-  constexpr int LDS_LD = BK + 4;
+  // DMA (ABL bit 6): operands go global -> LDS directly (buffer_load ... lds), no VGPR round trip and
+  // no ds_write pass.  The LDS image is lane-linear (1 KiB per wave instruction = 8 rows of 128 B), so
+  // instead of padding rows the 16-byte chunks of a row are XOR-swizzled with ((row >> 1) & 7): applied
+  // to the per-lane SOURCE address when staging and to the column when reading fragments.
+  constexpr bool DMA = (ABL & 64) != 0;
+  static_assert(!DMA || (KFULL && !ROWSQ && BK == 32 && NT == 256), "DMA staging: K % 32 == 0, 4 waves, no row norms");
+  constexpr int LDS_LD = DMA ? BK : BK + 4;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int LPR = BK / 4;            // lanes per staged row (float4 each)
@@ -109,6 +120,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
     row = (row < p.N ? row : p.N - 1) - n0;
     w_off[i] = (unsigned)((row * p.ldw + 4 * kq) * 4);
   }
+  if constexpr (DMA) {
+    // instruction ii = 4*i + wave stages tile rows 8*ii .. 8*ii+7; lane -> (row 8*ii + lane/8, chunk lane%8)
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) {
+      const int trow = 8 * (4 * i + wave) + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((trow >> 1) & 7);
+      int64_t row = m0 + trow;
+      row = (row < p.M ? row : p.M - 1) - m0;
+      a_off[i] = (unsigned)((row * p.lda + 4 * chunk) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD4; ++i) {
+      const int trow = 8 * (4 * i + wave) + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((trow >> 1) & 7);
+      int64_t row = n0 + trow;
+      row = (row < p.N ? row : p.N - 1) - n0;
+      w_off[i] = (unsigned)((row * p.ldw + 4 * chunk) * 4);
+    }
+  }
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + m0 * p.lda), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
@@ -140,7 +170,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   auto fetch = [&](int kt, auto setc) {
     constexpr int S = decltype(setc)::value;
     const unsigned kb = (unsigned)kt * (BK * 4);          // byte offset of the slab (scalar)
-    if constexpr (KFULL) {
+    if constexpr (DMA) {
+#pragma unroll
+      for (int i = 0; i < A_LD4; ++i) dma16(a_rsrc, As + S * BM * LDS_LD + (4 * i + wave) * 256, a_off[i], kb);
+#pragma unroll
+      for (int i = 0; i < W_LD4; ++i) dma16(w_rsrc, Ws + S * BN * LDS_LD + (4 * i + wave) * 256, w_off[i], kb);
+    } else if constexpr (KFULL) {
 #pragma unroll
       for (int i = 0; i < A_LD4; ++i) ra[S][i] = buf_load16(a_rsrc, a_off[i], kb);
 #pragma unroll
@@ -155,6 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
   };
   auto stash = [&](auto setc) {           // set S holds the slab whose LDS buffer is S
     constexpr int S = decltype(setc)::value;
+    if constexpr (DMA) return;
     float* ad = As + S * BM * LDS_LD + st_off;
     float* wd = Ws + S * BN * LDS_LD + st_off;
 #pragma unroll
@@ -170,16 +206,20 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
 
   fetch(0, I0{});
   stash(I0{});
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (PF2 && nk > 1) fetch(1, I1{});
 
-  const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
+  // fragment address of this lane inside a 32-row block; DMA image: chunk (2s + kq) ^ swz
+  const int frag_off = DMA ? (lane & 31) * LDS_LD : (lane & 31) * LDS_LD + 4 * (lane >> 5);
+  const int swz = ((lane & 31) >> 1) & 7, kq2 = lane >> 5;
   f32x4 af[2][MI], bf[2][NI];
   auto load_frags = [&](const float* Ab, const float* Wb, int s, int set) {
+    const int col = DMA ? 4 * ((2 * s + kq2) ^ swz) : 8 * s;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) af[set][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDS_LD + 8 * s);
+    for (int mi = 0; mi < MI; ++mi) af[set][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDS_LD + col);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const f32x4*>(Wb + ni * 32 * LDS_LD + 8 * s);
+    for (int ni = 0; ni < NI; ++ni) bf[set][ni] = *reinterpret_cast<const f32x4*>(Wb + ni * 32 * LDS_LD + col);
   };
 
   auto slab = [&](int kt, auto curc) {
@@ -212,6 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
     if (!(ABL & 1) && kt + 1 < nk) {
       stash(Nxt{});
     }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     if (!(ABL & 2)) __syncthreads();
   };
   if constexpr ((ABL & 32) != 0) {
@@ -322,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
 template <int BM, int BN, int WM, int WN, int BK, int OCC, int EPI, bool ROWSQ, bool KFULL, int ABL = 0>
 int launch_cfg(const GemmProblem& p, hipStream_t stream) {
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
-  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+  const size_t lds = (size_t)2 * (BM + BN) * ((ABL & 64) ? BK : BK + 4) * sizeof(float);
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, BK, OCC, EPI, ROWSQ, KFULL, ABL>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
@@ -371,6 +412,9 @@ int launch_wide(const GemmProblem& p, hipStream_t stream) {
         if (c == 7) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 3>(p, stream);
         return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 4>(p, stream);
       }
+      return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
+    case 20:  // default tile, LDS-DMA staging
+      if constexpr (KFULL) return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 64>(p, stream);
       return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL>(p, stream);
     case 10:  // default tile, loads issued two slabs ahead
       return launch_cfg<128, 128, 2, 2, 32, 2, EPI, false, KFULL, 8>(p, stream);
