@@ -43,6 +43,7 @@ SIGNATURES = {
     "anyloc_l2norm_rows": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),
     "anyloc_preprocess_u8": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(C.c_float),
                                        C.POINTER(C.c_float), c_f32p, C.c_void_p]),
+    "anyloc_pool_tokens": (C.c_int, [c_f32p, C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.c_float, c_f32p, C.c_void_p]),
     "anyloc_gemm_nt": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64,
                                  c_i64, c_i64, c_i64, C.c_void_p]),
     "anyloc_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),

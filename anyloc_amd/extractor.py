@@ -68,6 +68,9 @@ class HipDinoV2:
         patch_w = keep(state_dict["patch_embed.proj.weight"].reshape(dim, 3 * PATCH * PATCH))
         patch_b = keep(state_dict["patch_embed.proj.bias"])
         cls = keep(state_dict["cls_token"].reshape(dim))
+        self.full_depth = ARCH[name][1]
+        self._final_norm = (keep(state_dict["norm.weight"]), keep(state_dict["norm.bias"])) \
+            if "norm.weight" in state_dict else None
         blocks = (_lib.VitBlockWeights * depth)()
         for i in range(depth):
             p = f"blocks.{i}."
@@ -113,6 +116,18 @@ class HipDinoV2:
     def to(self, device):
         return self
 
+    @torch.no_grad()
+    def __call__(self, img):
+        """The hub model's own forward: final LayerNorm of the CLS token (the head is Identity), [B,3,H,W] ->
+        [B, D] on the input's device -- the global descriptor of reference
+        ``scripts/dino_v2_global_vpr.py:115-128`` (``model = torch.hub.load(...); r = model(img[None])``)."""
+        if self._final_norm is None or self.depth != self.full_depth:
+            raise RuntimeError(f"{self.name}: the model forward needs all {self.full_depth} blocks and the final "
+                               f"norm.weight / norm.bias (loaded: {self.depth} blocks)")
+        tok = self.forward_taps(img, [(self.depth - 1, "token")], use_cls=True, norm_taps=False)
+        res = ops.layernorm(tok[:, 0].contiguous(), self._final_norm[0], self._final_norm[1], 1e-6)
+        return res if img.is_cuda else res.to(img.device)
+
     def pos_table(self, H, W):
         key = (H, W)
         if key not in self._pos_cache:
@@ -149,6 +164,17 @@ class HipDinoV2:
                                           n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
                                           ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")
         return out
+
+
+def hub_load(repo_or_dir, model, *args, **kwargs):
+    """Stand-in for ``torch.hub.load('facebookresearch/dinov2', name)`` (reference ``utilities.py:239-240``,
+    ``scripts/dino_v2_global_vpr.py:115-116``): there is no network, so the weights come from
+    ``anyloc_amd.weights`` and the returned object runs the HIP forward.  ``.eval()`` / ``.to(device)`` are
+    accepted and return the same object (it lives on the GPU)."""
+    if "dinov2" not in str(repo_or_dir) or model not in _DINO_V2_MODELS:
+        raise RuntimeError(f"hub stand-in only serves facebookresearch/dinov2 {_DINO_V2_MODELS}; "
+                           f"got {repo_or_dir!r}, {model!r} (no network in this environment)")
+    return HipDinoV2(model, weights.resolve_state_dict(model), _lib.require_gpu())
 
 
 class _NullHandle:

@@ -135,6 +135,38 @@ def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_te
     return (out, labels) if return_labels else out
 
 
+POOL_MODES = {"average": 0, "avg": 0, "max": 1, "gem": 2, "gem_abs": 3}
+
+
+def pool(tokens, method="average", gem_p=3.0):
+    """One pooled descriptor per image: "average" / "max" (reference scripts/dino_v2_gp.py:130-133),
+    "gem" (|mean(t^p)|^(1/p) * sign, scripts/dino_v2_gem.py:186-188) or "gem_abs" (:174-175).
+
+    tokens: device tensor [n_img, N, D] / [N, D], or a list of [N_i, D] tensors.  Returns [n_img, D]."""
+    if method not in POOL_MODES:
+        raise NotImplementedError(f"ID: {method}")
+    device = _lib.require_gpu()
+    lib = _lib.load()
+    if torch.is_tensor(tokens) and tokens.dim() in (2, 3):
+        t = _f32c(tokens, device)
+        t = t[None] if t.dim() == 2 else t
+        n_img, n_tok, D = t.shape
+        packed, offsets = t, None
+        empty = n_tok == 0
+    else:
+        packed, offsets, n_img, D = _offsets_for(tokens, device)
+        n_tok = -1
+        empty = bool(n_img) and bool((offsets[1:] == offsets[:-1]).any())
+    if n_img == 0:
+        return torch.empty(0, D, dtype=torch.float32, device=device)
+    if empty and POOL_MODES[method] == 1:
+        raise IndexError("max(): cannot reduce over an image with no tokens")     # torch.max on an empty dim
+    out = torch.empty(n_img, D, dtype=torch.float32, device=device)
+    _lib.check(lib.anyloc_pool_tokens(_lib.ptr(packed), _lib.ptr(offsets), n_img, n_tok, D, POOL_MODES[method],
+                                      float(gem_p), _lib.ptr(out), _lib.stream_ptr()), "anyloc_pool_tokens")
+    return out
+
+
 def kmeans_step(x, centers, mode="cosine", want_labels=False):
     """One assign + accumulate pass: returns (sums [K,D], counts [K], labels|None)."""
     _need_cuda(x, centers)

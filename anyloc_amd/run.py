@@ -95,6 +95,9 @@ def main(argv=None):
         sys.path.insert(0, ROOT)
     install_shims()
     import utilities  # noqa: F401  (ours: binds `from utilities import ...` in the script)
+    import torch.hub
+    from . import extractor
+    torch.hub.load = extractor.hub_load      # scripts that call the hub model directly (dino_v2_global_vpr.py:115)
     assert os.path.dirname(os.path.abspath(utilities.__file__)) == ROOT
     sys.argv = [script] + argv[1:]
     runpy.run_path(script, run_name="__main__")

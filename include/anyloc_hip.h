@@ -64,6 +64,23 @@ int anyloc_preprocess_u8(const unsigned char* img_hwc, int64_t batch, int64_t he
                          int64_t width, int64_t crop_h, int64_t crop_w,
                          const float* mean3, const float* std3, float* out, void* stream);
 
+/* ------------------------------------------------------------ pooling ----
+ * One global descriptor per image from its patch tokens, without VLAD:
+ *   ANYLOC_POOL_AVG      mean over tokens          (scripts/dino_v2_gp.py:130-131)
+ *   ANYLOC_POOL_MAX      max over tokens           (scripts/dino_v2_gp.py:132-133)
+ *   ANYLOC_POOL_GEM      x = mean(t^p); |x|^(1/p) * sign(x)   (scripts/dino_v2_gem.py:186-188)
+ *   ANYLOC_POOL_GEM_ABS  mean(|t|^p)^(1/p)         (scripts/dino_v2_gem.py:174-175)
+ *   tokens  [total_tokens, D]; image i = rows offsets[i] .. offsets[i+1]
+ *           (offsets: n_img+1 int64 on the device), or offsets == NULL and every
+ *           image has n_tok rows.  out [n_img, D].  p is read by the GeM modes only. */
+#define ANYLOC_POOL_AVG 0
+#define ANYLOC_POOL_MAX 1
+#define ANYLOC_POOL_GEM 2
+#define ANYLOC_POOL_GEM_ABS 3
+int anyloc_pool_tokens(const float* tokens, const int64_t* offsets, int64_t n_img,
+                       int64_t n_tok, int64_t D, int mode, float p, float* out,
+                       void* stream);
+
 /* ------------------------------------------------------------- matmul ----
  * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N] when bias != NULL): the fp32 MFMA GEMM
  * all dense contractions of the path run on (torch Linear layout: both

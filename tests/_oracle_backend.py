@@ -5,7 +5,7 @@ plumbing (argument conventions, caching, return types), not the kernels."""
 import torch
 from torch.nn import functional as F
 
-from oracle import dinov2_ref, faiss_flat, fpk_kmeans, vlad_ref
+from oracle import dinov2_ref, faiss_flat, fpk_kmeans, pool_ref, vlad_ref
 
 
 class OracleDinoV2:
@@ -17,6 +17,16 @@ class OracleDinoV2:
         self.model.eval()
         self.dim, self.depth = self.model.embed_dim, have
         self.device = torch.device("cpu")
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    @torch.no_grad()
+    def __call__(self, img):
+        return self.model(img.cpu().float())
 
     @torch.no_grad()
     def forward_taps(self, img, taps, use_cls=False, norm_taps=True, norm_concat=False):
@@ -52,6 +62,18 @@ def install(monkeypatch):
         onehot = (lab[None, :] == torch.arange(c.shape[0])[:, None]).to(x.dtype)
         return onehot @ x, onehot.sum(-1), lab
 
+    def pool(tokens, method="average", gem_p=3.0):
+        if method not in ops.POOL_MODES:
+            raise NotImplementedError(f"ID: {method}")
+        parts = list(tokens) if not isinstance(tokens, torch.Tensor) else list(tokens if tokens.ndim == 3 else tokens[None])
+        outs = []
+        for t in parts:
+            t = torch.as_tensor(t).float()[None]
+            outs.append(pool_ref.global_pool(t, method)[0] if method in ("average", "avg", "max")
+                        else pool_ref.gem_descriptors(t, gem_p, method == "gem_abs")[0])
+        return torch.stack(outs)
+
+    monkeypatch.setattr(ops, "pool", pool)
     monkeypatch.setattr(ops, "vlad", vlad)
     monkeypatch.setattr(ops, "kmeans_step", kmeans_step)
     monkeypatch.setattr(kmeans, "_local_step", kmeans_step)

@@ -155,3 +155,32 @@ def test_synthetic_state_dict_loads_into_hub_layout():
         assert not missing
         for k, v in sd.items():
             assert tuple(m.state_dict()[k].shape) == tuple(v.shape), k
+
+
+def test_pooling_host_surface(monkeypatch):
+    """Host side of the non-VLAD aggregations (argument conventions, error types, device round trip) with the
+    device entry point swapped for the CPU restatement; the kernel itself is checked in test_gpu_pooling.py."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _oracle_backend
+    from anyloc_amd import pooling
+    from oracle import pool_ref
+    _oracle_backend.install(monkeypatch)
+    x = torch.randn(3, 40, 16, generator=torch.Generator().manual_seed(0))
+    assert torch.equal(pooling.global_pool(x, "average"), torch.mean(x, dim=1))
+    assert torch.equal(pooling.global_pool(x, "max"), torch.max(x, dim=1)[0])
+    with pytest.raises(NotImplementedError, match="ID: median"):
+        pooling.global_pool(x, "median")
+    g = pooling.gem_descriptors(x, 3)
+    m = (x ** 3).mean(1)
+    assert torch.allclose(g, m.abs() ** (1 / 3) * m.sign(), atol=1e-6)
+    assert torch.equal(pooling.gem_descriptors(x, 3, gem_elem_by_elem=True), g)
+    assert torch.allclose(pooling.gem_descriptors(x, 2, gem_use_abs=True), (x.abs() ** 2).mean(1) ** 0.5, atol=1e-6)
+    ragged = pooling.global_pool([x[0, :5], x[1]], "average")
+    assert ragged.shape == (2, 16) and torch.allclose(ragged[0], x[0, :5].mean(0), atol=1e-6)
+    assert torch.equal(pool_ref.gem_descriptors(x, 3, False, True), pool_ref.gem_descriptors(x, 3))
+
+
+def test_hub_stand_in_refuses_other_repos(monkeypatch):
+    with pytest.raises(RuntimeError, match="no network"):
+        extractor.hub_load("pytorch/vision", "resnet50")

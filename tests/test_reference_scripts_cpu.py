@@ -25,7 +25,10 @@ def cpu_backend(monkeypatch):
     _oracle_backend.install(monkeypatch)
     weights.register_state_dict("dinov2_vits14", synth.synthetic_state_dict("dinov2_vits14", 0))
     saved_argv, saved_path, saved_mods = list(sys.argv), list(sys.path), set(sys.modules)
+    import torch.hub
+    saved_hub = torch.hub.load
     yield
+    torch.hub.load = saved_hub
     weights.unregister_state_dict()
     sys.argv[:] = saved_argv
     sys.path[:] = saved_path
@@ -88,6 +91,43 @@ def test_global_vocab_script_unmodified(cpu_backend, tmp_path, capsys):
     assert "R@1" in out and "END" in out
     centers = torch.load(str(vcache / "c_centers.pt"))
     assert tuple(centers.shape) == (4, 384) and centers.dtype == torch.float32 and centers.device.type == "cpu"
+
+
+def _run_recall_script(script, extra, tmp_path, capsys, n_db=5, n_qu=3):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import make_synth_dataset
+    make_synth_dataset.write(str(tmp_path / "data"), "st_lucia", n_db=n_db, n_qu=n_qu, h=112, w=140)
+    try:
+        launcher.main([os.path.join(REF, "scripts", script), "--prog.data-vg-dir", str(tmp_path / "data"),
+                       "--prog.cache-dir", str(tmp_path / "cache"), "--prog.vg-dataset-name", "st_lucia",
+                       "--model-type", "dinov2_vits14", "--bd-args.resize", "112", "140",
+                       "--top-k-vals", "1", "2", "3"] + extra)
+    except SystemExit as e:
+        assert e.code in (0, None)
+    out = capsys.readouterr().out
+    assert "Traceback" not in out and "Unhandled exception" not in out, out[-3000:]
+    return out
+
+
+@pytest.mark.parametrize("method", ["average", "max"])
+def test_global_pooling_script_unmodified(cpu_backend, tmp_path, capsys, method):
+    """scripts/dino_v2_gp.py: extractor -> torch mean/max over tokens -> get_top_k_recall."""
+    out = _run_recall_script("dino_v2_gp.py", ["--desc-layer", "9", "--desc-facet", "value",
+                                               "--pool-method", method], tmp_path, capsys)
+    assert "Generated pooled descriptors" in out and "R@1" in out
+
+
+def test_gem_script_unmodified(cpu_backend, tmp_path, capsys):
+    out = _run_recall_script("dino_v2_gem.py", ["--desc-layer", "9", "--desc-facet", "value", "--gem-p", "3"],
+                             tmp_path, capsys)
+    assert "Database GeMs shape: torch.Size([5, 384])" in out and "R@1" in out
+
+
+def test_cls_global_descriptor_script_unmodified(cpu_backend, tmp_path, capsys):
+    """scripts/dino_v2_global_vpr.py calls torch.hub.load itself and uses the model's CLS output: the launcher's
+    hub stand-in hands it our model object (all 12 blocks + final norm)."""
+    out = _run_recall_script("dino_v2_global_vpr.py", [], tmp_path, capsys)
+    assert "R@1" in out or "Recall" in out
 
 
 def test_demo_vlad_generate_unmodified(cpu_backend, tmp_path, capsys, monkeypatch):
