@@ -1,0 +1,152 @@
+"""PCA (optionally whitened) projection of global descriptors on the device.
+
+The reference reduces its 49 152-d VLADs with ``sklearn.decomposition.PCA(lower_dim, svd_solver='full',
+whiten=...)`` on the host (``utilities.py:522-586``, called at ``scripts/dino_v2_vlad.py:357-369``; the
+joint variant at ``scripts/joint_pca_project.py:84-86``): a LAPACK SVD of the centred [n, f] matrix.
+
+Here the O(n f min(n, f)) work runs on the fp32 MFMA GEMM of the library (``anyloc_gemm_nt``):
+
+* fit:  centre on the device; the smaller of the Gram matrix  Xc Xc^T [n, n]  and the scatter matrix
+  Xc^T Xc [f, f]  is one GEMM; its symmetric eigendecomposition (float64, ``torch.linalg.eigh`` --
+  a dense-solver library call, not a kernel of this package) gives the singular values and one side of the
+  SVD; for the Gram side the principal axes follow from one more GEMM, V^T = diag(1/s) U^T Xc.
+  Signs follow sklearn's ``svd_flip(u_based_decision=False)``: the largest-magnitude entry of every axis is
+  positive.
+* transform:  one GEMM with the bias epilogue,  X W^T - W mean,  W = components (/ sqrt(explained variance)
+  when whitening) -- the order sklearn's ``_BasePCA._transform`` uses.
+
+Attributes mirror sklearn's (``mean_, components_, explained_variance_, singular_values_, n_components_``)
+as device tensors.  fp32 throughout except the eigendecomposition.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def _gemm(a, w, bias=None):
+    """a [M,K] w[N,K]^T (+ bias) on the library GEMM; K zero-padded to the multiple of 4 the kernel's
+    16-byte loads need (zeros add nothing to the sums)."""
+    pad = -a.shape[1] % 4
+    if pad:
+        a, w = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(w, (0, pad))
+    return ops.gemm_nt(a, w, bias)
+
+
+class PCA:
+    def __init__(self, n_components: int, whiten: bool = False, precise: bool = False):
+        self.n_components = int(n_components)
+        self.whiten = bool(whiten)
+        # The Gram / scatter matrix squares the condition number: with fp32 sums the axes whose variance is below
+        # ~1e-7 x the largest one are noise.  That never matters for the leading axes a dimensionality reduction
+        # keeps; `precise` forms that one matrix in float64 (torch matmul) for callers that want the trailing axes
+        # (reduce_pca's low_factor > 0).
+        self.precise = bool(precise)
+
+    def _self_product(self, m):
+        if self.precise:
+            m = m.double()
+            return m @ m.t()
+        return _gemm(m, m)
+
+    # ---------------------------------------------------------------- fit ----
+    def fit(self, X):
+        device = _lib.require_gpu()
+        X = ops._f32c(torch.as_tensor(X), device)
+        if X.dim() != 2:
+            raise ValueError(f"Expected 2D array, got {X.dim()}D array instead")
+        n, f = X.shape
+        k = self.n_components
+        if not 1 <= k <= min(n, f):
+            raise ValueError(f"n_components={k} must be between 1 and min(n_samples, n_features)={min(n, f)} "
+                             f"with svd_solver='full'")
+        self.mean_ = X.mean(dim=0, dtype=torch.float64).to(torch.float32)
+        xc = X - self.mean_
+        if n <= f:
+            gram = self._self_product(xc)                                    # [n, n] = Xc Xc^T
+            lam, vec = self._eigh_desc(gram)
+            s = lam.clamp_min(0).sqrt()
+            u_t = vec[:, :k].t().to(torch.float32).contiguous()            # [k, n]
+            axes = _gemm(u_t, xc.t().contiguous())                   # [k, f] = U^T Xc
+            axes = axes / s[:k].to(torch.float32).clamp_min(torch.finfo(torch.float32).tiny)[:, None]
+        else:
+            xt = xc.t().contiguous()
+            scatter = self._self_product(xt)                              # [f, f] = Xc^T Xc
+            lam, vec = self._eigh_desc(scatter)
+            s = lam.clamp_min(0).sqrt()
+            axes = vec[:, :k].t().to(torch.float32).contiguous()
+        # unit length in fp32 (the GEMM above leaves ~1e-7 of drift) and sklearn's sign rule
+        axes = torch.nn.functional.normalize(axes, dim=1)
+        piv = axes.abs().argmax(dim=1)
+        sign = torch.sign(axes[torch.arange(k, device=device), piv])
+        sign = torch.where(sign == 0, torch.ones_like(sign), sign)
+        self.components_ = (axes * sign[:, None]).contiguous()
+        self.singular_values_ = s[:k].to(torch.float32)
+        self.explained_variance_ = (lam[:k].clamp_min(0) / max(n - 1, 1)).to(torch.float32)
+        total = float(lam.clamp_min(0).sum() / max(n - 1, 1))
+        self.explained_variance_ratio_ = self.explained_variance_ / total if total > 0 else self.explained_variance_
+        self.n_components_, self.n_samples_, self.n_features_in_ = k, n, f
+        self._w = None
+        return self
+
+    @staticmethod
+    def _eigh_desc(sym):
+        lam, vec = torch.linalg.eigh(sym.to(torch.float64))
+        return lam.flip(0), vec.flip(1)
+
+    # ---------------------------------------------------------- transform ----
+    def _projection(self):
+        if self._w is None:
+            w = self.components_
+            if self.whiten:
+                scale = self.explained_variance_.sqrt().clamp_min(torch.finfo(torch.float32).eps)
+                w = w / scale[:, None]
+            w = w.contiguous()
+            self._w = (w, -(w.double() @ self.mean_.double()).to(torch.float32))
+        return self._w
+
+    def transform(self, X):
+        if not hasattr(self, "components_"):
+            raise RuntimeError("This PCA instance is not fitted yet. Call 'fit' first.")
+        X = torch.as_tensor(X)
+        src = X.device
+        x = ops._f32c(X, _lib.require_gpu())
+        if x.dim() != 2 or x.shape[1] != self.n_features_in_:
+            raise ValueError(f"X has {x.shape[-1]} features, but PCA is expecting {self.n_features_in_} features")
+        w, b = self._projection()
+        out = _gemm(x, w, b)
+        return out if src.type == "cuda" else out.to(src)
+
+    def fit_transform(self, X):
+        return self.fit(X).transform(X)
+
+
+def reduce_pca(train_descs, test_descs, lower_dim: int, low_factor: float = 0.0, fallback: int = 256,
+               svd_solver: str = "full", whitening: bool = False):
+    """Device version of reference ``utilities.py:522-586`` (same arguments and return convention: numpy in ->
+    numpy out; tensors in -> tensors on the input's device).  ``svd_solver`` is accepted for signature
+    compatibility: the decomposition is always the exact (full) one."""
+    assert 0 <= low_factor <= 1
+    as_np = isinstance(train_descs, np.ndarray)
+    tr, ts = torch.as_tensor(train_descs), torch.as_tensor(test_descs)
+    if low_factor == 0.0:
+        pca = PCA(lower_dim, whiten=whitening)
+        out_tr, out_ts = pca.fit_transform(tr), pca.transform(ts)
+    else:
+        n_samples, n_components = tr.shape
+        if n_samples < n_components:
+            print(f"Too few samples, fallback to {fallback}d first")
+            both = PCA(fallback, precise=True).fit_transform(torch.cat((tr, ts)))
+            tr, ts = both[:n_samples], both[n_samples:]
+        n_down = int(low_factor * lower_dim)
+        n_up = lower_dim - n_down
+        print(f"Up: {n_up}, Down: {n_down}")
+        full = PCA(tr.shape[1], precise=True).fit(tr)
+        basis = torch.cat((full.components_[:n_up], full.components_[-n_down:]))
+        sel = PCA(lower_dim)
+        sel.mean_, sel.components_, sel.n_features_in_, sel._w = full.mean_, basis.contiguous(), tr.shape[1], None
+        sel.explained_variance_ = torch.cat((full.explained_variance_[:n_up], full.explained_variance_[-n_down:]))
+        out_tr, out_ts = sel.transform(tr), sel.transform(ts)
+    if as_np:
+        return out_tr.cpu().numpy(), out_ts.cpu().numpy()
+    return out_tr, out_ts

@@ -74,6 +74,8 @@ def install(monkeypatch):
         return torch.stack(outs)
 
     monkeypatch.setattr(ops, "pool", pool)
+    monkeypatch.setattr(ops, "gemm_nt", lambda a, w, bias=None: a.float() @ w.float().t() + (0 if bias is None else bias))
+    monkeypatch.setattr(ops, "_f32c", lambda t, device=None: t.detach().to("cpu", torch.float32).contiguous())
     monkeypatch.setattr(ops, "vlad", vlad)
     monkeypatch.setattr(ops, "kmeans_step", kmeans_step)
     monkeypatch.setattr(kmeans, "_local_step", kmeans_step)

@@ -1,0 +1,65 @@
+"""Device PCA (anyloc_amd.pca: Gram / scatter matrix and projections on anyloc_gemm_nt) against the
+reference's own implementation -- sklearn.decomposition.PCA(svd_solver='full'), which is what
+utilities.py:561-564 calls -- on seeded matrices with a well-separated spectrum."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def decaying(n, f, seed, decay=0.9, rank=None):
+    g = torch.Generator().manual_seed(seed)
+    r = min(n, f) if rank is None else rank
+    q1, _ = torch.linalg.qr(torch.randn(n, r, generator=g, dtype=torch.float64))
+    q2, _ = torch.linalg.qr(torch.randn(f, r, generator=g, dtype=torch.float64))
+    s = 10.0 * decay ** torch.arange(r, dtype=torch.float64)
+    return ((q1 * s) @ q2.t() + 0.3 * torch.randn(1, f, generator=g, dtype=torch.float64)).float()
+
+
+@pytest.mark.parametrize("shape,k,whiten", [((200, 3072), 32, False), ((200, 3072), 32, True),
+                                            ((1000, 384), 64, False), ((1000, 384), 64, True), ((130, 131), 9, False)])
+def test_pca_matches_sklearn_full_svd(shape, k, whiten):
+    from sklearn.decomposition import PCA as SkPCA
+    from anyloc_amd import pca
+    x, y = decaying(*shape, seed=1, rank=100), decaying(33, shape[1], seed=2, rank=33)
+    sk = SkPCA(k, svd_solver="full", whiten=whiten)
+    want_tr = sk.fit_transform(x.double().numpy())          # float64 LAPACK: the reference method at full accuracy
+    want_ts = sk.transform(y.double().numpy())
+    ours = pca.PCA(k, whiten=whiten)
+    got_tr, got_ts = ours.fit_transform(x.to(DEV)), ours.transform(y.to(DEV))
+    assert got_tr.is_cuda and got_tr.shape == (shape[0], k) and got_ts.shape == (33, k)
+    assert np.abs(ours.components_.cpu().numpy() - sk.components_).max() < 2e-5
+    assert np.allclose(ours.explained_variance_.cpu().numpy(), sk.explained_variance_, rtol=2e-5)
+    scale = np.abs(want_tr).max()
+    assert np.abs(got_tr.cpu().numpy() - want_tr).max() < 1e-4 * scale
+    assert np.abs(got_ts.cpu().numpy() - want_ts).max() < 1e-4 * scale
+    # sklearn run in float32 (what the reference actually feeds it) is no closer to the float64 result
+    sk32 = SkPCA(k, svd_solver="full", whiten=whiten)
+    ref32 = sk32.fit_transform(x.numpy())
+    assert np.abs(got_tr.cpu().numpy() - want_tr).max() < 4 * np.abs(ref32 - want_tr).max() + 1e-5 * scale
+    # numpy in -> numpy out through the drop-in function
+    import utilities
+    a, b = utilities.reduce_pca(x.numpy(), y.numpy(), k, whitening=whiten)
+    assert isinstance(a, np.ndarray) and np.abs(a - want_tr).max() < 1e-4 * scale and b.shape == (33, k)
+
+
+def test_pca_then_retrieval_keeps_ranking():
+    """The use the reference makes of it (scripts/dino_v2_vlad.py:357-372): project db + queries, re-normalise,
+    retrieve.  Data living in a 64-d subspace: a 64-d PCA keeps every inner product, so the top-k lists of the
+    projected and the raw descriptors coincide."""
+    from anyloc_amd import ops, pca
+    g = torch.Generator().manual_seed(7)
+    basis, _ = torch.linalg.qr(torch.randn(4096, 64, generator=g))
+    coef = torch.randn(600, 64, generator=g) * (0.97 ** torch.arange(64))
+    db = (coef @ basis.t()).to(DEV)
+    qu = db[::10] + 0.05 * (torch.randn(60, 64, generator=g) @ basis.t()).to(DEV)
+    p = pca.PCA(64).fit(db)
+    mean = p.mean_
+    raw_db, raw_qu = ops.l2norm_rows(db - mean), ops.l2norm_rows(qu - mean)
+    red_db, red_qu = ops.l2norm_rows(p.transform(db)), ops.l2norm_rows(p.transform(qu))
+    d0, i0 = ops.topk(raw_qu, raw_db, 5, "ip")
+    d1, i1 = ops.topk(red_qu, red_db, 5, "ip")
+    assert torch.equal(i0[:, 0], torch.arange(0, 600, 10, device=DEV))
+    assert float((i0 != i1).float().mean()) < 0.01 and float((d0 - d1).abs().max()) < 1e-4

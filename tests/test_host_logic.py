@@ -184,3 +184,70 @@ def test_pooling_host_surface(monkeypatch):
 def test_hub_stand_in_refuses_other_repos(monkeypatch):
     with pytest.raises(RuntimeError, match="no network"):
         extractor.hub_load("pytorch/vision", "resnet50")
+
+
+def _decaying(n, f, seed, rank=None, decay=0.8):
+    """Rows with a well-separated, geometrically decaying spectrum (unique principal axes)."""
+    g = torch.Generator().manual_seed(seed)
+    r = min(n, f) if rank is None else rank
+    q1, _ = torch.linalg.qr(torch.randn(n, r, generator=g, dtype=torch.float64))
+    q2, _ = torch.linalg.qr(torch.randn(f, r, generator=g, dtype=torch.float64))
+    s = 10.0 * decay ** torch.arange(r, dtype=torch.float64)
+    return ((q1 * s) @ q2.t() + 0.3 * torch.randn(1, f, generator=g, dtype=torch.float64)).float()
+
+
+@pytest.mark.parametrize("shape,k,whiten", [((60, 200), 16, False), ((60, 200), 16, True), ((300, 50), 12, False),
+                                            ((300, 50), 12, True), ((40, 41), 7, False)])
+def test_pca_host_logic_matches_sklearn(monkeypatch, shape, k, whiten):
+    """anyloc_amd.pca against the reference's own implementation (sklearn PCA, svd_solver='full') with the GEMM
+    entry point swapped for torch on the CPU: Gram / scatter branch choice, eigen-ordering, svd_flip signs,
+    whitening scale, transform order."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _oracle_backend
+    from sklearn.decomposition import PCA as SkPCA
+    from anyloc_amd import pca
+    _oracle_backend.install(monkeypatch)
+    x, y = _decaying(*shape, seed=1), _decaying(17, shape[1], seed=2)
+    sk = SkPCA(k, svd_solver="full", whiten=whiten)
+    want_tr, want_ts = sk.fit_transform(x.double().numpy()), None
+    want_ts = sk.transform(y.double().numpy())
+    ours = pca.PCA(k, whiten=whiten)
+    got_tr, got_ts = ours.fit_transform(x), ours.transform(y)
+    assert np.abs(ours.components_.numpy() - sk.components_).max() < 2e-5
+    assert np.allclose(ours.explained_variance_.numpy(), sk.explained_variance_, rtol=1e-5)
+    assert np.allclose(ours.singular_values_.numpy(), sk.singular_values_, rtol=1e-5)
+    assert np.allclose(ours.mean_.numpy(), sk.mean_, atol=1e-6)
+    scale = np.abs(want_tr).max()
+    assert np.abs(got_tr.numpy() - want_tr).max() < 1e-4 * scale
+    assert np.abs(got_ts.numpy() - want_ts).max() < 1e-4 * scale
+
+
+def test_reduce_pca_surface_matches_reference_function(monkeypatch, capsys):
+    """utilities.reduce_pca (numpy in / numpy out, low_factor and fallback branches) against the reference's own
+    function imported verbatim (utilities.py:522-586)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _oracle_backend
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present")
+    import utilities
+    ref = ref_loader.load_reference_utilities()
+    _oracle_backend.install(monkeypatch)
+    tr, ts = _decaying(80, 48, seed=3, decay=0.92).numpy(), _decaying(9, 48, seed=4, decay=0.92).numpy()
+    for kwargs in (dict(lower_dim=10), dict(lower_dim=10, whitening=True), dict(lower_dim=10, low_factor=0.3)):
+        a_tr, a_ts = utilities.reduce_pca(tr, ts, **kwargs)
+        b_tr, b_ts = ref.reduce_pca(tr.copy(), ts.copy(), **kwargs)
+        assert isinstance(a_tr, np.ndarray) and a_tr.shape == b_tr.shape and a_ts.shape == b_ts.shape
+        m = np.abs(b_tr).max()
+        assert np.abs(a_tr - b_tr).max() < 2e-4 * m and np.abs(a_ts - b_ts).max() < 2e-4 * m, kwargs
+    # too few samples: joint projection to `fallback` dims first (reference :566-574)
+    tr, ts = _decaying(30, 64, seed=5, rank=20).numpy(), _decaying(8, 64, seed=6, rank=8).numpy()
+    a_tr, a_ts = utilities.reduce_pca(tr, ts, lower_dim=6, low_factor=0.5, fallback=16)
+    b_tr, b_ts = ref.reduce_pca(tr.copy(), ts.copy(), lower_dim=6, low_factor=0.5, fallback=16)
+    assert "Too few samples, fallback to 16d first" in capsys.readouterr().out
+    assert a_tr.shape == b_tr.shape == (30, 6) and a_ts.shape == (8, 6)
+    # the lowest-variance axes of a rank-deficient matrix are not unique: compare the well-defined top half
+    m = np.abs(b_tr[:, :3]).max()
+    assert np.abs(a_tr[:, :3] - b_tr[:, :3]).max() < 5e-4 * m

@@ -102,28 +102,12 @@ def reduce_pca(train_descs: np.ndarray, test_descs: np.ndarray, lower_dim: int,
                low_factor: float = 0.0, fallback: int = 256, svd_solver: str = 'full',
                whitening: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """PCA dimensionality reduction fitted on ``train_descs`` and applied to both sets
-    (reference ``utilities.py:522-586``; sklearn on the host, only reached with
-    ``--pca-dim-reduce``).  ``low_factor`` > 0 mixes in that fraction of the
-    lowest-eigenvalue basis vectors; with too few samples both sets are first projected
-    jointly to ``fallback`` dimensions."""
-    from sklearn.decomposition import PCA
-    assert 0 <= low_factor <= 1
-    if low_factor == 0.0:
-        pca = PCA(lower_dim, svd_solver=svd_solver, whiten=whitening)
-        return pca.fit_transform(train_descs), pca.transform(test_descs)
-    n_samples, n_components = train_descs.shape
-    if n_samples < n_components:
-        print(f"Too few samples, fallback to {fallback}d first")
-        both = np.concatenate((train_descs.copy(), test_descs.copy()))
-        both_down = PCA(fallback, svd_solver=svd_solver).fit_transform(both)
-        train_descs, test_descs = both_down[:n_samples], both_down[n_samples:]
-    n_low = int(low_factor * lower_dim)
-    n_top = lower_dim - n_low
-    print(f"Up: {n_top}, Down: {n_low}")
-    pca = PCA(train_descs.shape[1], svd_solver=svd_solver)
-    pca.fit(train_descs)
-    basis = np.concatenate((pca.components_[:n_top], pca.components_[-n_low:]))
-    return (train_descs - pca.mean_) @ basis.T, (test_descs - pca.mean_) @ basis.T
+    (reference ``utilities.py:522-586``, reached with ``--pca-dim-reduce``).  ``low_factor`` > 0
+    mixes in that fraction of the lowest-eigenvalue basis vectors; with too few samples both sets
+    are first projected jointly to ``fallback`` dimensions.  Runs on the device
+    (``anyloc_amd.pca``: Gram / scatter matrix and projections on the fp32 MFMA GEMM)."""
+    from anyloc_amd import pca
+    return pca.reduce_pca(train_descs, test_descs, lower_dim, low_factor, fallback, svd_solver, whitening)
 
 
 seed_everything()
