@@ -4,19 +4,21 @@ The reference reduces its 49 152-d VLADs with ``sklearn.decomposition.PCA(lower_
 whiten=...)`` on the host (``utilities.py:522-586``, called at ``scripts/dino_v2_vlad.py:357-369``; the
 joint variant at ``scripts/joint_pca_project.py:84-86``): a LAPACK SVD of the centred [n, f] matrix.
 
-Here the O(n f min(n, f)) work runs on the fp32 MFMA GEMM of the library (``anyloc_gemm_nt``):
+Here the decomposition is reduced to GEMMs + one symmetric eigenproblem on the device, and the projections
+run on the fp32 MFMA GEMM of the library (``anyloc_gemm_nt``):
 
 * fit:  centre on the device; the smaller of the Gram matrix  Xc Xc^T [n, n]  and the scatter matrix
-  Xc^T Xc [f, f]  is one GEMM; its symmetric eigendecomposition (float64, ``torch.linalg.eigh`` --
-  a dense-solver library call, not a kernel of this package) gives the singular values and one side of the
-  SVD; for the Gram side the principal axes follow from one more GEMM, V^T = diag(1/s) U^T Xc.
+  Xc^T Xc [f, f]  is one GEMM (float64 library GEMM by default, see ``precise``); its symmetric
+  eigendecomposition (float64, ``torch.linalg.eigh`` -- a dense-solver library call, not a kernel of this
+  package) gives the singular values and one side of the SVD; for the Gram side the principal axes follow
+  from one more GEMM, V^T = diag(1/s) U^T Xc.
   Signs follow sklearn's ``svd_flip(u_based_decision=False)``: the largest-magnitude entry of every axis is
   positive.
 * transform:  one GEMM with the bias epilogue,  X W^T - W mean,  W = components (/ sqrt(explained variance)
   when whitening) -- the order sklearn's ``_BasePCA._transform`` uses.
 
 Attributes mirror sklearn's (``mean_, components_, explained_variance_, singular_values_, n_components_``)
-as device tensors.  fp32 throughout except the eigendecomposition.
+as device tensors.  
 """
 import numpy as np
 import torch
@@ -34,13 +36,14 @@ def _gemm(a, w, bias=None):
 
 
 class PCA:
-    def __init__(self, n_components: int, whiten: bool = False, precise: bool = False):
+    def __init__(self, n_components: int, whiten: bool = False, precise: bool = True):
         self.n_components = int(n_components)
         self.whiten = bool(whiten)
-        # The Gram / scatter matrix squares the condition number: with fp32 sums the axes whose variance is below
-        # ~1e-7 x the largest one are noise.  That never matters for the leading axes a dimensionality reduction
-        # keeps; `precise` forms that one matrix in float64 (torch matmul) for callers that want the trailing axes
-        # (reduce_pca's low_factor > 0).
+        # The Gram / scatter matrix squares the condition number: formed with fp32 sums, the axes whose variance is
+        # below ~1e-6 x the largest are noise (measured on the MI355X: axis 64 of a 0.9^k spectrum off by 1e-3).
+        # `precise` (default) forms that one symmetric matrix, and the k x f back-projection, in float64 with
+        # torch.matmul -- a plain library GEMM -- which brings the fit to the accuracy of the reference's float32
+        # LAPACK SVD or better; precise=False keeps everything on the fp32 MFMA kernel (fine for leading axes).
         self.precise = bool(precise)
 
     def _self_product(self, m):
@@ -66,9 +69,13 @@ class PCA:
             gram = self._self_product(xc)                                    # [n, n] = Xc Xc^T
             lam, vec = self._eigh_desc(gram)
             s = lam.clamp_min(0).sqrt()
-            u_t = vec[:, :k].t().to(torch.float32).contiguous()            # [k, n]
-            axes = _gemm(u_t, xc.t().contiguous())                   # [k, f] = U^T Xc
-            axes = axes / s[:k].to(torch.float32).clamp_min(torch.finfo(torch.float32).tiny)[:, None]
+            if self.precise:
+                axes = (vec[:, :k].t() @ xc.double()) / s[:k].clamp_min(1e-300)[:, None]      # [k, f] = U^T Xc / s
+                axes = axes.to(torch.float32)
+            else:
+                u_t = vec[:, :k].t().to(torch.float32).contiguous()            # [k, n]
+                axes = _gemm(u_t, xc.t().contiguous())
+                axes = axes / s[:k].to(torch.float32).clamp_min(torch.finfo(torch.float32).tiny)[:, None]
         else:
             xt = xc.t().contiguous()
             scatter = self._self_product(xt)                              # [f, f] = Xc^T Xc
@@ -136,12 +143,12 @@ def reduce_pca(train_descs, test_descs, lower_dim: int, low_factor: float = 0.0,
         n_samples, n_components = tr.shape
         if n_samples < n_components:
             print(f"Too few samples, fallback to {fallback}d first")
-            both = PCA(fallback, precise=True).fit_transform(torch.cat((tr, ts)))
+            both = PCA(fallback).fit_transform(torch.cat((tr, ts)))
             tr, ts = both[:n_samples], both[n_samples:]
         n_down = int(low_factor * lower_dim)
         n_up = lower_dim - n_down
         print(f"Up: {n_up}, Down: {n_down}")
-        full = PCA(tr.shape[1], precise=True).fit(tr)
+        full = PCA(tr.shape[1]).fit(tr)
         basis = torch.cat((full.components_[:n_up], full.components_[-n_down:]))
         sel = PCA(lower_dim)
         sel.mean_, sel.components_, sel.n_features_in_, sel._w = full.mean_, basis.contiguous(), tr.shape[1], None

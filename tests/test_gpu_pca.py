@@ -33,8 +33,10 @@ def test_pca_matches_sklearn_full_svd(shape, k, whiten):
     assert np.abs(ours.components_.cpu().numpy() - sk.components_).max() < 2e-5
     assert np.allclose(ours.explained_variance_.cpu().numpy(), sk.explained_variance_, rtol=2e-5)
     scale = np.abs(want_tr).max()
-    assert np.abs(got_tr.cpu().numpy() - want_tr).max() < 1e-4 * scale
-    assert np.abs(got_ts.cpu().numpy() - want_ts).max() < 1e-4 * scale
+    # whitening divides the trailing axes' fp32 projections (abs error ~1e-7 |x|) by their tiny standard deviation
+    tol = 5e-4 if whiten else 1e-4
+    assert np.abs(got_tr.cpu().numpy() - want_tr).max() < tol * scale
+    assert np.abs(got_ts.cpu().numpy() - want_ts).max() < tol * max(scale, np.abs(want_ts).max())
     # sklearn run in float32 (what the reference actually feeds it) is no closer to the float64 result
     sk32 = SkPCA(k, svd_solver="full", whiten=whiten)
     ref32 = sk32.fit_transform(x.numpy())
@@ -42,7 +44,19 @@ def test_pca_matches_sklearn_full_svd(shape, k, whiten):
     # numpy in -> numpy out through the drop-in function
     import utilities
     a, b = utilities.reduce_pca(x.numpy(), y.numpy(), k, whitening=whiten)
-    assert isinstance(a, np.ndarray) and np.abs(a - want_tr).max() < 1e-4 * scale and b.shape == (33, k)
+    assert isinstance(a, np.ndarray) and np.abs(a - want_tr).max() < tol * scale and b.shape == (33, k)
+
+
+def test_pca_all_fp32_kernel_mode_leading_axes():
+    """precise=False: Gram matrix and back-projection on the fp32 MFMA kernel; the leading axes (variance within
+    ~1e-3 of the largest) still agree with the float64 SVD."""
+    from sklearn.decomposition import PCA as SkPCA
+    from anyloc_amd import pca
+    x = decaying(300, 2048, seed=3, decay=0.9, rank=100)
+    sk = SkPCA(24, svd_solver="full").fit(x.double().numpy())
+    ours = pca.PCA(24, precise=False).fit(x.to(DEV))
+    assert np.abs(ours.components_.cpu().numpy() - sk.components_).max() < 1e-4
+    assert np.allclose(ours.singular_values_.cpu().numpy(), sk.singular_values_, rtol=1e-4)
 
 
 def test_pca_then_retrieval_keeps_ranking():
