@@ -59,6 +59,27 @@ def gemm_nt(a, w, bias=None):
     return out
 
 
+def split_x3(x):
+    """fp32 [rows, K] -> the three-bf16-plane image the split-bf16 GEMM reads (uint8 buffer)."""
+    _need_cuda(x)
+    x = _f32c(x)
+    rows, K = x.shape
+    lib = _lib.load()
+    out = torch.empty(lib.anyloc_x3_bytes(rows, K), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.anyloc_split_x3(_lib.ptr(x), K, rows, K, _lib.ptr(out), _lib.stream_ptr()), "anyloc_split_x3")
+    return out
+
+
+def gemm_nt_x6(a3, w3, M, N, K, bias=None):
+    """C[M,N] = A W^T (+ bias) from plane images made by split_x3 (bf16 matrix cores, fp32-level accuracy)."""
+    _need_cuda(a3, w3, bias)
+    out = torch.empty(M, N, dtype=torch.float32, device=a3.device)
+    _lib.check(_lib.load().anyloc_gemm_nt_x6(_lib.ptr(a3), _lib.ptr(w3),
+                                             _lib.ptr(_f32c(bias)) if bias is not None else None,
+                                             _lib.ptr(out), N, M, N, K, _lib.stream_ptr()), "anyloc_gemm_nt_x6")
+    return out
+
+
 def layernorm(x, weight, bias, eps=1e-6):
     _need_cuda(x, weight, bias)
     x = _f32c(x)

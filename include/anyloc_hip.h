@@ -64,6 +64,21 @@ int anyloc_preprocess_u8(const unsigned char* img_hwc, int64_t batch, int64_t he
                          int64_t width, int64_t crop_h, int64_t crop_w,
                          const float* mean3, const float* std3, float* out, void* stream);
 
+/* ------------------------------------------------- split-bf16 matmul ----
+ * The same contraction as anyloc_gemm_nt (torch Linear layout, reference
+ * utilities.py:269 model forward) on the bf16 matrix cores with fp32-level
+ * accuracy: every fp32 operand is the exact sum of three bf16 planes and the six
+ * leading plane products are accumulated in fp32 (csrc/gemm_x6.hip).
+ *   anyloc_x3_bytes   size of the plane image of an fp32 matrix [rows, K]
+ *   anyloc_split_x3   fp32 row-major [rows, K] (leading dim ldx) -> plane image
+ *   anyloc_gemm_nt_x6 C[M,N] = A * W^T (+ bias[N]) from the plane images of A [M,K]
+ *                     and W [N,K]; C fp32, leading dim ldc. */
+size_t anyloc_x3_bytes(int64_t rows, int64_t K);
+int anyloc_split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* x3,
+                    void* stream);
+int anyloc_gemm_nt_x6(const void* a3, const void* w3, const float* bias, float* C,
+                      int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+
 /* ------------------------------------------------------------ pooling ----
  * One global descriptor per image from its patch tokens, without VLAD:
  *   ANYLOC_POOL_AVG      mean over tokens          (scripts/dino_v2_gp.py:130-131)
