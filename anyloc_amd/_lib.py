@@ -36,6 +36,13 @@ class VitBlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BLOCK_FIELDS]
 
 
+X3_FIELDS = ("qkv_w3", "proj_w3", "fc1_w3", "fc2_w3")
+
+
+class VitBlockX3(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in X3_FIELDS]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test checks
 SIGNATURES = {
     "anyloc_version": (C.c_int, []),
@@ -65,6 +72,7 @@ SIGNATURES = {
     "anyloc_vit_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(VitConfig), c_f32p, c_f32p,
                                     c_f32p, C.POINTER(VitBlockWeights)]),
     "anyloc_vit_destroy": (None, [C.c_void_p]),
+    "anyloc_vit_attach_x3": (C.c_int, [C.c_void_p, C.POINTER(VitBlockX3)]),
     "anyloc_vit_workspace_bytes": (c_sz, [C.c_void_p, c_i64, c_i64, c_i64]),
     "anyloc_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_f32p, C.c_int32,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint, c_f32p,

@@ -102,6 +102,23 @@ struct GemmProblem {
 };
 int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream);
 
+// split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
+struct X6Problem {
+  const unsigned char* A3; int64_t RA;     // plane image of A [M, 16*K16], RA = rows the image was built with
+  const unsigned char* W3; int64_t RW;     // plane image of W [N, 16*K16]
+  float* C; int64_t ldc;
+  int64_t M, N;
+  int K16;                                  // k-blocks of 16
+  int64_t a_off, w_off;                     // byte offset of A3 / W3 inside its image (row sub-range of a larger image)
+  const float* bias;
+  const float* gamma;                       // EPI_LS_RESID
+  const float* resid;                       // EPI_LS_RESID, leading dim ldc
+  const char* tag;
+};
+size_t x3_bytes(int64_t rows, int64_t K);
+int split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* x3, hipStream_t stream);
+int gemm_x6(const X6Problem& p, int epilogue, hipStream_t stream);
+
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
                 int64_t dim, float eps, hipStream_t stream);
 int layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int dim,

@@ -28,12 +28,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XT = 128;                    // tile rows (both operands)
-constexpr int X_PLANE = XT * 32;           // bytes of one (kb, plane) tile image
-constexpr int X_OP = 3 * X_PLANE;          // one operand, one slab
-constexpr int X_STAGE = 2 * X_OP;          // 24 KiB
-constexpr int X_STAGES = 3;
-
 __device__ __forceinline__ void xtile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int nb = tiles_m * tiles_n;
   const int q = nb >> 3, r = nb & 7;
@@ -53,30 +47,38 @@ __device__ __forceinline__ void dma16b(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-struct X6Problem {
-  const unsigned char* A3; int64_t RA;     // x3 image of A, rows allocated
-  const unsigned char* W3; int64_t RW;
-  float* C; int64_t ldc;
-  int64_t M, N;
-  int K16;                                  // k-blocks of 16
-  const float* bias;
+
+// MI x NI 32x32 MFMA blocks per wave, 2 x 2 waves: block tile (64 MI) x (64 NI); STAGES-deep LDS ring of slabs
+template <int MI, int NI, int STAGES>
+struct X6Cfg {
+  static constexpr int BM = 64 * MI, BN = 64 * NI;
+  static constexpr int A_PLANE = BM * 32, W_PLANE = BN * 32;       // bytes of one (kb, plane) tile image
+  static constexpr int A_OP = 3 * A_PLANE, STAGE = A_OP + 3 * W_PLANE;
+  static constexpr int LDS = STAGES * STAGE;
+  static constexpr int A_DMA = BM / 128, W_DMA = BN / 128;          // 1 KiB chunks per wave per plane
+  static constexpr int NDMA = 3 * (A_DMA + W_DMA);                  // DMA instructions per wave per slab
 };
 
-template <int DUMMY>
-__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(X6Problem p, int tiles_m, int tiles_n) {
+__device__ __forceinline__ float x6_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float x6_silu(float v) { return v / (1.0f + expf(-v)); }
+
+template <int MI, int NI, int STAGES, int OCC, int EPI>
+__global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tiles_m, int tiles_n) {
+  using Cfg = X6Cfg<MI, NI, STAGES>;
+  static_assert(MI % 2 == 0 && NI % 2 == 0, "tiles are staged in 128-row units");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
   xtile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int64_t m0 = (int64_t)tm * XT, n0 = (int64_t)tn * XT;
+  const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
 
   const unsigned a_slab = (unsigned)(3 * p.RA * 32), w_slab = (unsigned)(3 * p.RW * 32);
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(p.A3), 0, (int)((int64_t)p.K16 * a_slab), 0x00020000);
+      const_cast<unsigned char*>(p.A3), 0, (int)((int64_t)p.K16 * a_slab - p.a_off), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(p.W3), 0, (int)((int64_t)p.K16 * w_slab), 0x00020000);
-  // wave w stages row-chunk w (32 rows = 1 KiB) of each of the 3 + 3 plane tiles of a slab
+      const_cast<unsigned char*>(p.W3), 0, (int)((int64_t)p.K16 * w_slab - p.w_off), 0x00020000);
+  // wave w stages the 32-row chunks w, w+4, ... (1 KiB each) of every plane tile of a slab
   unsigned a_voff[3], w_voff[3];
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
@@ -84,73 +86,144 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(X6Problem p, int tiles_
     w_voff[pl] = (unsigned)(((int64_t)pl * p.RW + n0 + 32 * wave) * 32 + lane * 16);
   }
   auto issue = [&](int kt, int stage) {
-    unsigned char* st = smem + stage * X_STAGE + wave * 1024;
+    unsigned char* st = smem + stage * Cfg::STAGE + wave * 1024;
+    const unsigned ao = (unsigned)kt * a_slab, wo = (unsigned)kt * w_slab;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) dma16b(a_rsrc, st + pl * X_PLANE, a_voff[pl], (unsigned)kt * a_slab);
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) dma16b(w_rsrc, st + X_OP + pl * X_PLANE, w_voff[pl], (unsigned)kt * w_slab);
+      for (int c = 0; c < Cfg::A_DMA; ++c) dma16b(a_rsrc, st + pl * Cfg::A_PLANE + c * 4096, a_voff[pl] + c * 4096, ao);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < Cfg::W_DMA; ++c)
+        dma16b(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * 4096, w_voff[pl] + c * 4096, wo);
   };
 
   // fragment address: lane (i = lane & 31, h = lane >> 5) reads the 16 bytes holding k = 8h .. 8h+7 of row i
   const int fr = lane & 31, fh = lane >> 5;
   const unsigned char* frag = smem + fr * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
   const int nk = p.K16;
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
 
   auto slab = [&](int kt, int stage) {
-    // this wave's DMA pieces of slab kt have landed (the 6 of slab kt+1 may still be in flight)
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // this wave's DMA pieces of slab kt have landed (those of the STAGES-2 later slabs may still be in flight)
+    if (STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone finished slab kt-1 (no fence: waits are explicit)
-    const unsigned char* sa = frag + stage * X_STAGE + (wm * 64) * 32;
-    const unsigned char* sw = frag + stage * X_STAGE + X_OP + (wn * 64) * 32;
-    bf16x8 a[2][3], b[2][3];
+    __builtin_amdgcn_s_barrier();   // everyone's pieces landed, everyone finished slab kt-1 (no fence: waits are explicit)
+    const unsigned char* sa = frag + stage * Cfg::STAGE + (wm * 32 * MI) * 32;
+    const unsigned char* sw = frag + stage * Cfg::STAGE + Cfg::A_OP + (wn * 32 * NI) * 32;
+    bf16x8 a[MI][3], b[NI][3];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        a[mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * X_PLANE + mi * 1024);
-        b[mi][pl] = *reinterpret_cast<const bf16x8*>(sw + pl * X_PLANE + mi * 1024);
-      }
-    if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (stage + 2) % 3: the buffer slab kt-1 used
-#define ANYLOC_X6_TERM(pa, pb)                                                                     \
-  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
+      for (int mi = 0; mi < MI; ++mi) a[mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * Cfg::A_PLANE + mi * 1024);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni][pl] = *reinterpret_cast<const bf16x8*>(sw + pl * Cfg::W_PLANE + ni * 1024);
+    }
+    // refill the buffer slab kt-1 used
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
+#define ANYLOC_X6_TERM(pa, pb)                                                                       \
+  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
     ANYLOC_X6_TERM(2, 0) ANYLOC_X6_TERM(0, 2) ANYLOC_X6_TERM(1, 1)
     ANYLOC_X6_TERM(1, 0) ANYLOC_X6_TERM(0, 1) ANYLOC_X6_TERM(0, 0)
 #undef ANYLOC_X6_TERM
   };
-  for (int kt = 0; kt < nk; kt += 3) {
+  for (int kt = 0; kt < nk; kt += STAGES) {
     slab(kt, 0);
     if (kt + 1 < nk) slab(kt + 1, 1);
-    if (kt + 2 < nk) slab(kt + 2, 2);
+    if (STAGES > 2 && kt + 2 < nk) slab(kt + 2, 2);
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 ----
-  const int64_t wrow0 = m0 + wm * 64 + 4 * (lane >> 5);
-  const int64_t wcol0 = n0 + wn * 64 + (lane & 31);
+  // ---- epilogue (same fused forms as gemm_f32.hip): C/D layout of the 32x32 MFMA:
+  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 ----
+  const int64_t wrow0 = m0 + wm * 32 * MI + 4 * (lane >> 5);
+  const int64_t wcol0 = n0 + wn * 32 * NI + (lane & 31);
+  if constexpr (EPI == EPI_SWIGLU) {
+    // W rows are interleaved in groups of 32: block 2j = gate[32j..], block 2j+1 = value[32j..]
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t col = wcol0 + ni * 32;
-    const bool cok = col < p.N;
-    const float bv = (cok && p.bias) ? p.bias[col] : 0.0f;
+    for (int nj = 0; nj < NI; nj += 2) {
+      const int64_t colg = wcol0 + nj * 32, colv = colg + 32;
+      const int64_t ocol = (n0 + wn * 32 * NI + nj * 32) / 2 + (lane & 31);
+      const bool cok = colv < p.N;
+      const float bg = (cok && p.bias) ? p.bias[colg] : 0.0f;
+      const float bv = (cok && p.bias) ? p.bias[colv] : 0.0f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-        if (row < p.M && cok) p.C[row * p.ldc + col] = acc[mi][ni][r] + bv;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+          if (row < p.M && cok) {
+            const float g = acc[mi][nj][r] + bg, v = acc[mi][nj + 1][r] + bv;
+            p.C[row * p.ldc + ocol] = x6_silu(g) * v;
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t col = wcol0 + ni * 32;
+      const bool cok = col < p.N;
+      const float bv = (cok && p.bias) ? p.bias[col] : 0.0f;
+      float gam = 0.0f;
+      if constexpr (EPI == EPI_LS_RESID) gam = cok ? p.gamma[col] : 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+          if (row < p.M && cok) {
+            const float v = acc[mi][ni][r] + bv;
+            const int64_t o = row * p.ldc + col;
+            if constexpr (EPI == EPI_STORE) p.C[o] = v;
+            else if constexpr (EPI == EPI_GELU) p.C[o] = x6_gelu_erf(v);
+            else p.C[o] = p.resid[o] + v * gam;
+          }
+        }
+    }
+  }
+}
+
+template <int MI, int NI, int STAGES, int OCC, int EPI>
+int launch_x6(const X6Problem& p, hipStream_t stream) {
+  using Cfg = X6Cfg<MI, NI, STAGES>;
+  const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, STAGES, OCC, EPI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_x6_kernel<MI, NI, STAGES, OCC, EPI>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256),
+                     Cfg::LDS, stream, p, tiles_m, tiles_n);
+  return launch_status("gemm_x6_kernel");
+}
+
+template <int EPI>
+int dispatch_x6(const X6Problem& p, hipStream_t stream) {
+  // ANYLOC_X6_CFG (micro-benchmarks): 0 = 128x256 tile, 2-deep ring (default); 1 = 128x128, 3-deep;
+  //                                   2 = 256x128, 3-deep (1 block/CU); 3 = 256x128, 2-deep
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("ANYLOC_X6_CFG");
+    cfg = e ? atoi(e) : 0;
+  }
+  switch (cfg) {
+    case 1: return launch_x6<2, 2, 3, 2, EPI>(p, stream);
+    case 2: return launch_x6<4, 2, 3, 1, EPI>(p, stream);
+    case 3: return launch_x6<4, 2, 2, 2, EPI>(p, stream);
+    default: return launch_x6<2, 4, 2, 2, EPI>(p, stream);
   }
 }
 
@@ -209,43 +282,54 @@ __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__
 
 }  // namespace
 
+size_t x3_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 3 * (size_t)rows * 32; }
+
+int split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* x3, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(x && x3 && rows > 0 && K > 0 && ldx >= K, "split_x3: bad arguments");
+  const int K16 = (int)((K + 15) / 16);
+  ProfScope prof("split_x3", stream, 0.0, 10.0 * rows * K);
+  hipLaunchKernelGGL(split_x3_kernel, dim3((unsigned)((rows + 127) / 128), (unsigned)((K16 + 1) / 2)), dim3(256), 0,
+                     stream, x, ldx, rows, K, static_cast<unsigned char*>(x3), rows, K16);
+  return launch_status("split_x3_kernel");
+}
+
+int gemm_x6(const X6Problem& p, int epilogue, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(p.A3 && p.W3 && p.C, "gemm_x6: null operand");
+  ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K16 > 0 && p.RA >= p.M && p.RW >= p.N, "gemm_x6: bad shape");
+  ANYLOC_CHECK_ARG((size_t)p.K16 * 3 * (size_t)p.RA * 32 < (1ull << 31) && (size_t)p.K16 * 3 * (size_t)p.RW * 32 < (1ull << 31),
+                   "gemm_x6: operand image exceeds the 2 GiB buffer-addressing range");
+  const int64_t K = 16ll * p.K16;
+  ProfScope prof(p.tag ? p.tag : "gemm_x6", stream, 2.0 * p.M * p.N * K, 6.0 * (p.M + p.N) * K + 4.0 * p.M * p.N);
+  switch (epilogue) {
+    case EPI_STORE: return dispatch_x6<EPI_STORE>(p, stream);
+    case EPI_GELU: return dispatch_x6<EPI_GELU>(p, stream);
+    case EPI_LS_RESID:
+      ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_x6: LS_RESID needs gamma and resid");
+      return dispatch_x6<EPI_LS_RESID>(p, stream);
+    case EPI_SWIGLU:
+      ANYLOC_CHECK_ARG(p.N % 64 == 0, "gemm_x6: SWIGLU needs N %% 64 == 0");
+      return dispatch_x6<EPI_SWIGLU>(p, stream);
+    default: set_error("gemm_x6: unsupported epilogue %d", epilogue); return ANYLOC_ERR_INVALID_ARG;
+  }
+}
+
 }  // namespace anyloc
 
 using namespace anyloc;
 
-extern "C" size_t anyloc_x3_bytes(int64_t rows, int64_t K) {
-  return (size_t)((K + 15) / 16) * 3 * (size_t)rows * 32;
-}
+extern "C" size_t anyloc_x3_bytes(int64_t rows, int64_t K) { return x3_bytes(rows, K); }
 
 extern "C" int anyloc_split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* x3, void* stream) {
-  ANYLOC_CHECK_ARG(x && x3 && rows > 0 && K > 0 && ldx >= K, "split_x3: bad arguments");
-  const int K16 = (int)((K + 15) / 16);
-  ProfScope prof("split_x3", (hipStream_t)stream, 0.0, 10.0 * rows * K);
-  hipLaunchKernelGGL(split_x3_kernel, dim3((unsigned)((rows + 127) / 128), (unsigned)((K16 + 1) / 2)), dim3(256), 0,
-                     (hipStream_t)stream, x, ldx, rows, K, static_cast<unsigned char*>(x3), rows, K16);
-  return launch_status("split_x3_kernel");
+  return split_x3(x, ldx, rows, K, x3, (hipStream_t)stream);
 }
 
 extern "C" int anyloc_gemm_nt_x6(const void* a3, const void* w3, const float* bias, float* C, int64_t ldc, int64_t M,
                                  int64_t N, int64_t K, void* stream) {
-  ANYLOC_CHECK_ARG(a3 && w3 && C, "gemm_nt_x6: null operand");
   ANYLOC_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_nt_x6: bad shape M=%lld N=%lld K=%lld", (long long)M,
                    (long long)N, (long long)K);
-  X6Problem p;
+  X6Problem p{};
   p.A3 = static_cast<const unsigned char*>(a3); p.RA = M;
   p.W3 = static_cast<const unsigned char*>(w3); p.RW = N;
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K16 = (int)((K + 15) / 16); p.bias = bias;
-  ANYLOC_CHECK_ARG(anyloc_x3_bytes(M, K) < (1ull << 31) && anyloc_x3_bytes(N, K) < (1ull << 31),
-                   "gemm_nt_x6: operand image exceeds the 2 GiB buffer-addressing range");
-  const int tiles_m = (int)((M + XT - 1) / XT), tiles_n = (int)((N + XT - 1) / XT);
-  static bool attr_set = false;
-  if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, X_STAGES * X_STAGE));
-    attr_set = true;
-  }
-  ProfScope prof("gemm_x6", (hipStream_t)stream, 2.0 * M * N * K, 6.0 * (M + N) * K + 4.0 * M * N);
-  hipLaunchKernelGGL(gemm_x6_kernel<0>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), X_STAGES * X_STAGE,
-                     (hipStream_t)stream, p, tiles_m, tiles_n);
-  return launch_status("gemm_x6_kernel");
+  return gemm_x6(p, EPI_STORE, (hipStream_t)stream);
 }

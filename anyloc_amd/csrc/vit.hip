@@ -28,6 +28,7 @@ struct anyloc_vit {
   const float* patch_b;
   const float* cls;
   std::vector<anyloc_vit_block_weights> blocks;
+  std::vector<anyloc_vit_block_x3> x3;      // optional: three-plane bf16 images of the four weight matrices
 };
 
 namespace anyloc {
@@ -35,6 +36,7 @@ namespace {
 
 struct VitWs {
   float *x, *y, *qkv, *h;   // qkv doubles as the im2col buffer; attention output aliases y
+  unsigned char* a3;        // split-bf16 mode: plane image of the current GEMM's activation operand
   size_t bytes;
 };
 
@@ -47,6 +49,7 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   const int64_t qkv_elems = std::max<int64_t>(M * 3 * c.dim, batch * np * c.patch_k_pad);
   w.qkv = a.take<float>(qkv_elems);
   w.h = a.take<float>(M * c.ffn_hidden);
+  w.a3 = a.take<unsigned char>(x3_bytes(M, std::max(c.dim, c.ffn_hidden)));
   w.bytes = a.off;
   return w;
 }
@@ -63,6 +66,24 @@ int linear(const float* A, int64_t lda, const float* Wt, int64_t K, const float*
   g.resid = C;
   g.tag = tag;
   return gemm_nt(g, epi, stream);
+}
+
+// y = act(A W^T + b) with A given in fp32: split A into planes, then the six-product bf16 GEMM
+int linear_x6(const float* A, int64_t K, unsigned char* a3, const void* w3, int64_t w_rows, int64_t w_row0,
+              const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
+              const char* tag, hipStream_t stream) {
+  ANYLOC_TRY(split_x3(A, K, M, K, a3, stream));
+  X6Problem g{};
+  g.A3 = a3; g.RA = M;
+  g.W3 = static_cast<const unsigned char*>(w3) + w_row0 * 32; g.RW = w_rows;
+  g.w_off = w_row0 * 32;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K16 = (int)((K + 15) / 16);
+  g.bias = bias;
+  g.gamma = gamma;
+  g.resid = C;
+  g.tag = tag;
+  return gemm_x6(g, epi, stream);
 }
 
 }  // namespace
@@ -114,6 +135,19 @@ int anyloc_vit_create(anyloc_vit_t** out, const anyloc_vit_config* cfg, const fl
   return ANYLOC_OK;
 }
 
+int anyloc_vit_attach_x3(anyloc_vit_t* h, const anyloc_vit_block_x3* blocks) {
+  ANYLOC_CHECK_ARG(h, "vit_attach_x3: null handle");
+  if (!blocks) {
+    h->x3.clear();
+    return ANYLOC_OK;
+  }
+  for (int i = 0; i < h->cfg.depth; ++i)
+    ANYLOC_CHECK_ARG(blocks[i].qkv_w3 && blocks[i].proj_w3 && blocks[i].fc1_w3 && blocks[i].fc2_w3,
+                     "vit_attach_x3: block %d has a null plane image", i);
+  h->x3.assign(blocks, blocks + h->cfg.depth);
+  return ANYLOC_OK;
+}
+
 void anyloc_vit_destroy(anyloc_vit_t* h) { delete h; }
 
 size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch, int64_t img_h, int64_t img_w) {
@@ -145,6 +179,8 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
     set_error("vit_forward: workspace %zu < %zu", workspace_bytes, w.bytes);
     return ANYLOC_ERR_WORKSPACE;
   }
+  const bool x6 = flags & ANYLOC_VIT_SPLIT_BF16;
+  ANYLOC_CHECK_ARG(!x6 || !h->x3.empty(), "vit_forward: ANYLOC_VIT_SPLIT_BF16 without anyloc_vit_attach_x3");
   const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
   const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;
   const int64_t ldo = (int64_t)n_taps * D;
@@ -181,28 +217,51 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       for (int t = 0; t < n_taps; ++t) {
         if (tap_layers[t] != l) continue;
         const int f = tap_facets[t];
-        ANYLOC_TRY(linear(w.y, D, b.qkv_w + (int64_t)f * D * D, D, b.qkv_b + (int64_t)f * D, w.qkv, D, M, D,
-                          EPI_STORE, nullptr, "vit_facet_gemm", stream));
+        if (x6)
+          ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].qkv_w3, 3 * D, (int64_t)f * D, b.qkv_b + (int64_t)f * D, w.qkv, D,
+                               M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream));
+        else
+          ANYLOC_TRY(linear(w.y, D, b.qkv_w + (int64_t)f * D * D, D, b.qkv_b + (int64_t)f * D, w.qkv, D, M, D,
+                            EPI_STORE, nullptr, "vit_facet_gemm", stream));
         ANYLOC_TRY(facet_rows(w.qkv, D, 0, out, ldo, t * D, batch, T, skip, rows_per_img, D, norm_taps, 1e-12f,
                               stream));
       }
       break;
     }
-    ANYLOC_TRY(linear(w.y, D, b.qkv_w, D, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
+    if (x6)
+      ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].qkv_w3, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr,
+                           "vit_qkv_gemm", stream));
+    else
+      ANYLOC_TRY(linear(w.y, D, b.qkv_w, D, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
     for (int t = 0; t < n_taps; ++t)
       if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
         ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
                               norm_taps, 1e-12f, stream));
     ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream));
-    ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
+    if (x6)
+      ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
+                           "vit_proj_gemm", stream));
+    else
+      ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
     ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
-    if (c.ffn_kind == 0) {
-      ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr, "vit_fc1_gemm", stream));
+    if (x6) {
+      if (c.ffn_kind == 0)
+        ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].fc1_w3, Hh, 0, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr,
+                             "vit_fc1_gemm", stream));
+      else
+        ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].fc1_w3, 2 * Hh, 0, b.fc1_b, w.h, Hh, M, 2 * Hh, EPI_SWIGLU, nullptr,
+                             "vit_w12_gemm", stream));
+      ANYLOC_TRY(linear_x6(w.h, Hh, w.a3, h->x3[l].fc2_w3, D, 0, b.fc2_b, w.x, D, M, D, EPI_LS_RESID, b.ls2,
+                           "vit_fc2_gemm", stream));
     } else {
-      ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, 2 * Hh, EPI_SWIGLU, nullptr, "vit_w12_gemm", stream));
+      if (c.ffn_kind == 0) {
+        ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr, "vit_fc1_gemm", stream));
+      } else {
+        ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, 2 * Hh, EPI_SWIGLU, nullptr, "vit_w12_gemm", stream));
+      }
+      ANYLOC_TRY(linear(w.h, Hh, b.fc2_w, Hh, b.fc2_b, w.x, D, M, D, EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
     }
-    ANYLOC_TRY(linear(w.h, Hh, b.fc2_w, Hh, b.fc2_b, w.x, D, M, D, EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
     for (int t = 0; t < n_taps; ++t)
       if (tap_layers[t] == l && tap_facets[t] == ANYLOC_FACET_TOKEN)
         ANYLOC_TRY(facet_rows(w.x, D, 0, out, ldo, t * D, batch, T, skip, rows_per_img, D, norm_taps, 1e-12f, stream));

@@ -12,6 +12,8 @@ Differences from the reference that do not change results:
 import ctypes as C
 import math
 
+import os
+
 import torch
 from torch.nn import functional as F
 
@@ -48,7 +50,13 @@ def interpolate_pos_embed(pos_embed, h_img, w_img):
 class HipDinoV2:
     """Device-resident DINOv2 weights + the C handle of the HIP forward."""
 
-    def __init__(self, name, state_dict, device, max_layer=None):
+    def __init__(self, name, state_dict, device, max_layer=None, gemm=None):
+        """``gemm``: "x6" (default) runs the block GEMMs as six bf16 MFMA products of exact three-way bf16 splits
+        (fp32-level accuracy, csrc/gemm_x6.hip); "f32" keeps them on the fp32 MFMA kernel.  Env ANYLOC_GEMM
+        overrides the default."""
+        self.gemm = gemm or os.environ.get("ANYLOC_GEMM", "x6")
+        if self.gemm not in ("x6", "f32"):
+            raise ValueError(f"gemm mode must be 'x6' or 'f32', got {self.gemm!r}")
         dim, depth, heads, ffn, hidden = ARCH[name]
         have = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         depth = min(depth, have)
@@ -72,6 +80,7 @@ class HipDinoV2:
         self._final_norm = (keep(state_dict["norm.weight"]), keep(state_dict["norm.bias"])) \
             if "norm.weight" in state_dict else None
         blocks = (_lib.VitBlockWeights * depth)()
+        x3 = (_lib.VitBlockX3 * depth)()
         for i in range(depth):
             p = f"blocks.{i}."
             if self.ffn_kind == 0:
@@ -95,11 +104,20 @@ class HipDinoV2:
                 fc1_w=fc1_w, fc1_b=fc1_b, fc2_w=fc2_w, fc2_b=fc2_b, ls2=state_dict[p + "ls2.gamma"])
             for f in _lib.BLOCK_FIELDS:
                 setattr(blocks[i], f, keep(vals[f]).data_ptr())
+            if self.gemm == "x6":
+                for f3, f in zip(_lib.X3_FIELDS, ("qkv_w", "proj_w", "fc1_w", "fc2_w")):
+                    img3 = ops.split_x3(dev(vals[f]))
+                    self._keep.append(img3)
+                    setattr(x3[i], f3, img3.data_ptr())
         cfg = _lib.VitConfig(dim, depth, heads, self.ffn_kind, hidden, PATCH, 3 * PATCH * PATCH)
         self._handle = C.c_void_p()
         lib = _lib.load()
         _lib.check(lib.anyloc_vit_create(C.byref(self._handle), C.byref(cfg), _lib.ptr(patch_w),
                                          _lib.ptr(patch_b), _lib.ptr(cls), blocks), "anyloc_vit_create")
+        if self.gemm == "x6":
+            _lib.check(lib.anyloc_vit_attach_x3(self._handle, x3), "anyloc_vit_attach_x3")
+        # the plane image of one activation operand must stay inside 2 GiB of buffer addressing
+        self.max_rows = (2 ** 31 - 1) // (6 * max(dim, hidden)) - 512
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -153,13 +171,18 @@ class HipDinoV2:
         out = torch.empty(B, rows, n_taps * self.dim, dtype=torch.float32, device=self.device)
         if B == 0:
             return out
+        chunk = max(1, self.max_rows // (np_ + 1))
+        if self.gemm == "x6" and B > chunk:
+            for s0 in range(0, B, chunk):
+                out[s0:s0 + chunk] = self.forward_taps(img[s0:s0 + chunk], taps, use_cls, norm_taps, norm_concat)
+            return out
         lib = _lib.load()
         ws_bytes = lib.anyloc_vit_workspace_bytes(self._handle, B, H, W)
         ws = _lib.workspace(ws_bytes, self.device, "vit")
         layers = (C.c_int32 * n_taps)(*[t[0] for t in taps])
         facets = (C.c_int32 * n_taps)(*[ops.FACETS[t[1]] for t in taps])
         flags = (ops.VIT_USE_CLS if use_cls else 0) | (ops.VIT_NORM_TAPS if norm_taps else 0) | \
-            (ops.VIT_NORM_CONCAT if norm_concat else 0)
+            (ops.VIT_NORM_CONCAT if norm_concat else 0) | (ops.VIT_SPLIT_BF16 if self.gemm == "x6" else 0)
         _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
                                           n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
                                           ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")

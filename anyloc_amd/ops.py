@@ -13,7 +13,7 @@ from . import _lib
 VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
 FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
-VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT = 1, 2, 4
+VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16 = 1, 2, 4, 8
 
 
 def _f32c(t, device=None):

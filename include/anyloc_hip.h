@@ -218,6 +218,19 @@ void anyloc_vit_destroy(anyloc_vit_t* h);
 #define ANYLOC_FACET_VALUE 2
 #define ANYLOC_FACET_TOKEN 3
 /* forward flags */
+/* Optional split-bf16 execution of the block GEMMs (csrc/gemm_x6.hip): attach the
+ * three-plane images (anyloc_split_x3 of qkv.weight [3D,D], proj.weight [D,D], the
+ * fc1 / interleaved w12 matrix and fc2 / w3, all caller-owned, alive while attached)
+ * and pass ANYLOC_VIT_SPLIT_BF16 to anyloc_vit_forward.  blocks == NULL detaches. */
+typedef struct anyloc_vit_block_x3 {
+  const void* qkv_w3;
+  const void* proj_w3;
+  const void* fc1_w3;
+  const void* fc2_w3;
+} anyloc_vit_block_x3;
+int anyloc_vit_attach_x3(anyloc_vit_t* h, const anyloc_vit_block_x3* blocks /*host array [depth]*/);
+#define ANYLOC_VIT_SPLIT_BF16 8u     /* block GEMMs on the bf16 matrix cores, fp32-level accuracy */
+
 #define ANYLOC_VIT_USE_CLS 1u        /* keep the CLS row (utilities.py:270-273) */
 #define ANYLOC_VIT_NORM_TAPS 2u      /* L2-normalise each tap (utilities.py:282-283) */
 #define ANYLOC_VIT_NORM_CONCAT 4u    /* L2-normalise the concatenated taps again
