@@ -48,27 +48,28 @@ __device__ __forceinline__ void dma16b(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
 }
 
 
-// MI x NI 32x32 MFMA blocks per wave, 2 x 2 waves: block tile (64 MI) x (64 NI); STAGES-deep LDS ring of slabs
-template <int MI, int NI, int STAGES>
+// MI x NI 32x32 MFMA blocks per wave, WM x WN waves: block tile (32 MI WM) x (32 NI WN); STAGES-deep LDS ring
+template <int MI, int NI, int WM, int WN, int STAGES>
 struct X6Cfg {
-  static constexpr int BM = 64 * MI, BN = 64 * NI;
+  static constexpr int NW = WM * WN;
+  static constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
   static constexpr int A_PLANE = BM * 32, W_PLANE = BN * 32;       // bytes of one (kb, plane) tile image
   static constexpr int A_OP = 3 * A_PLANE, STAGE = A_OP + 3 * W_PLANE;
   static constexpr int LDS = STAGES * STAGE;
-  static constexpr int A_DMA = BM / 128, W_DMA = BN / 128;          // 1 KiB chunks per wave per plane
+  static constexpr int A_DMA = BM / (32 * NW), W_DMA = BN / (32 * NW);   // 1 KiB pieces per wave per plane
   static constexpr int NDMA = 3 * (A_DMA + W_DMA);                  // DMA instructions per wave per slab
+  static_assert(BM % (32 * NW) == 0 && BN % (32 * NW) == 0, "each wave stages whole 32-row pieces");
 };
 
 __device__ __forceinline__ float x6_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float x6_silu(float v) { return v / (1.0f + expf(-v)); }
 
-template <int MI, int NI, int STAGES, int OCC, int EPI>
-__global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tiles_m, int tiles_n) {
-  using Cfg = X6Cfg<MI, NI, STAGES>;
-  static_assert(MI % 2 == 0 && NI % 2 == 0, "tiles are staged in 128-row units");
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHED = 0>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p, int tiles_m, int tiles_n) {
+  using Cfg = X6Cfg<MI, NI, WM, WN, STAGES>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int tm, tn;
   xtile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tile
       const_cast<unsigned char*>(p.A3), 0, (int)((int64_t)p.K16 * a_slab - p.a_off), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(p.W3), 0, (int)((int64_t)p.K16 * w_slab - p.w_off), 0x00020000);
-  // wave w stages the 32-row chunks w, w+4, ... (1 KiB each) of every plane tile of a slab
+  // wave w stages the 32-row pieces w, w+NW, ... (1 KiB each) of every plane tile of a slab
   unsigned a_voff[3], w_voff[3];
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
@@ -91,12 +92,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tile
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int c = 0; c < Cfg::A_DMA; ++c) dma16b(a_rsrc, st + pl * Cfg::A_PLANE + c * 4096, a_voff[pl] + c * 4096, ao);
+      for (int c = 0; c < Cfg::A_DMA; ++c)
+        dma16b(a_rsrc, st + pl * Cfg::A_PLANE + c * (1024 * Cfg::NW), a_voff[pl] + c * (1024 * Cfg::NW), ao);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int c = 0; c < Cfg::W_DMA; ++c)
-        dma16b(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * 4096, w_voff[pl] + c * 4096, wo);
+        dma16b(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * (1024 * Cfg::NW), w_voff[pl] + c * (1024 * Cfg::NW), wo);
   };
 
   // fragment address: lane (i = lane & 31, h = lane >> 5) reads the 16 bytes holding k = 8h .. 8h+7 of row i
@@ -113,13 +115,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tile
 
   const int nk = p.K16;
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue(s, s);
+  for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
 
   auto slab = [&](int kt, int stage) {
     // this wave's DMA pieces of slab kt have landed (those of the STAGES-2 later slabs may still be in flight)
-    if (STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (a refill is issued in EVERY slab -- past the last k-block it is out of the descriptor's range, moves no
+    // data and zero-fills -- so the count of younger pieces in flight is a compile-time constant)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::NDMA) : "memory");
     __builtin_amdgcn_s_barrier();   // everyone's pieces landed, everyone finished slab kt-1 (no fence: waits are explicit)
     const unsigned char* sa = frag + stage * Cfg::STAGE + (wm * 32 * MI) * 32;
     const unsigned char* sw = frag + stage * Cfg::STAGE + Cfg::A_OP + (wn * 32 * NI) * 32;
@@ -132,13 +134,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tile
       for (int ni = 0; ni < NI; ++ni) b[ni][pl] = *reinterpret_cast<const bf16x8*>(sw + pl * Cfg::W_PLANE + ni * 1024);
     }
     // refill the buffer slab kt-1 used
-    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
+    issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
+    if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
 #define ANYLOC_X6_TERM(pa, pb)                                                                       \
   _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
     ANYLOC_X6_TERM(2, 0) ANYLOC_X6_TERM(0, 2) ANYLOC_X6_TERM(1, 1)
     ANYLOC_X6_TERM(1, 0) ANYLOC_X6_TERM(0, 1) ANYLOC_X6_TERM(0, 0)
 #undef ANYLOC_X6_TERM
+    if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
+    if constexpr (SCHED >= 1) {
+      // spread the DMA pieces of the next slab between the MFMAs instead of issuing them in one burst:
+      // all fragment reads first, then {MFMA x G, one VMEM piece} groups
+      constexpr int PIECES = Cfg::NDMA, G = (6 * MI * NI) / (PIECES + 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + NI), 0);
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
   };
   for (int kt = 0; kt < nk; kt += STAGES) {
     slab(kt, 0);
@@ -146,6 +161,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tile
     if (STAGES > 2 && kt + 2 < nk) slab(kt + 2, 2);
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail refills before LDS is released
   // ---- epilogue (same fused forms as gemm_f32.hip): C/D layout of the 32x32 MFMA:
   //      row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 ----
   const int64_t wrow0 = m0 + wm * 32 * MI + 4 * (lane >> 5);
@@ -195,35 +211,41 @@ __global__ __launch_bounds__(256, OCC) void gemm_x6_kernel(X6Problem p, int tile
   }
 }
 
-template <int MI, int NI, int STAGES, int OCC, int EPI>
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHED = 0>
 int launch_x6(const X6Problem& p, hipStream_t stream) {
-  using Cfg = X6Cfg<MI, NI, STAGES>;
+  using Cfg = X6Cfg<MI, NI, WM, WN, STAGES>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
   static bool attr_set = false;
   if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, STAGES, OCC, EPI>),
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_x6_kernel<MI, NI, STAGES, OCC, EPI>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256),
+  hipLaunchKernelGGL((gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED>), dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WM * WN),
                      Cfg::LDS, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_x6_kernel");
 }
 
 template <int EPI>
 int dispatch_x6(const X6Problem& p, hipStream_t stream) {
-  // ANYLOC_X6_CFG (micro-benchmarks): 0 = 128x256 tile, 2-deep ring (default); 1 = 128x128, 3-deep;
-  //                                   2 = 256x128, 3-deep (1 block/CU); 3 = 256x128, 2-deep
+  // ANYLOC_X6_CFG (micro-benchmarks): 0 = 128x256 tile, 4 waves, 2-deep ring, two blocks per CU (default);
+  //   1 = 128x128 3-deep; 2 = 256x128 3-deep (1 block/CU); 3 = 256x128 2-deep; 7 / 8 = 256x256 with 8 waves
   static int cfg = -1;
   if (cfg < 0) {
     const char* e = getenv("ANYLOC_X6_CFG");
     cfg = e ? atoi(e) : 0;
   }
   switch (cfg) {
-    case 1: return launch_x6<2, 2, 3, 2, EPI>(p, stream);
-    case 2: return launch_x6<4, 2, 3, 1, EPI>(p, stream);
-    case 3: return launch_x6<4, 2, 2, 2, EPI>(p, stream);
-    default: return launch_x6<2, 4, 2, 2, EPI>(p, stream);
+    case 1: return launch_x6<2, 2, 2, 2, 3, 2, EPI>(p, stream);
+    case 2: return launch_x6<4, 2, 2, 2, 3, 1, EPI>(p, stream);
+    case 3: return launch_x6<4, 2, 2, 2, 2, 2, EPI>(p, stream);
+    case 4: return launch_x6<2, 4, 2, 2, 2, 2, EPI, 0>(p, stream);   // default tile, refills issued in one burst
+    case 5: return launch_x6<2, 2, 2, 2, 3, 2, EPI, 1>(p, stream);
+    case 6: return launch_x6<4, 2, 2, 2, 2, 2, EPI, 1>(p, stream);
+    case 7: return launch_x6<4, 2, 2, 4, 2, 1, EPI, 1>(p, stream);   // 256x256 tile, 8 waves, one block per CU
+    case 8: return launch_x6<2, 4, 4, 2, 2, 1, EPI, 1>(p, stream);
+    case 9: return launch_x6<2, 4, 2, 2, 2, 2, EPI, 2>(p, stream);
+    default: return launch_x6<2, 4, 2, 2, 2, 2, EPI, 1>(p, stream);  // 128x256, refills interleaved with the MFMAs
   }
 }
 

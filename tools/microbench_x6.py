@@ -7,8 +7,11 @@ from anyloc_amd import ops
 dev = "cuda"
 g = torch.Generator(device=dev); g.manual_seed(0)
 res = []
-for (M, N, K) in [(300, 200, 48), (1000, 384, 384), (2048, 1536, 1536), (32330, 4608, 1536), (32330, 1536, 1536),
-                  (32330, 8192, 1536), (32330, 1536, 4096)]:
+SHAPES = [(300, 200, 48), (1000, 384, 384), (2048, 1536, 1536), (32330, 4608, 1536), (32330, 1536, 1536),
+          (32330, 8192, 1536), (32330, 1536, 4096)]
+if os.environ.get("X6_BIG"):
+    SHAPES = SHAPES[3:]
+for (M, N, K) in SHAPES:
     a = torch.randn(M, K, generator=g, device=dev) * (0.5 + torch.rand(M, 1, generator=g, device=dev))
     w = torch.randn(N, K, generator=g, device=dev) * 0.02
     bias = torch.randn(N, generator=g, device=dev)
