@@ -26,9 +26,17 @@ constexpr int KLD = HD + 4;   // padded K row (ds_read_b128 conflict-free)
 // WB = waves (32-query tiles) per workgroup; FASTEXP = v_exp_f32-based exponential
 // PRELOAD: read the whole K fragment set and the whole V column set of a tile into registers before
 //          the MFMA chains that consume them (2 waves/SIMD instead of 3, but no LDS wait inside a chain)
-template <int WB, bool FASTEXP, bool PRELOAD>
+__device__ __forceinline__ unsigned attn_bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// OUT3: the output is written as the three-plane bf16 image (x3 layout of gemm_x6.hip, R = batch*T rows) that the
+// projection GEMM reads, instead of fp32
+template <int WB, bool FASTEXP, bool PRELOAD, bool OUT3 = false>
 __global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            int T, int D, float scale) {
+                                                            int T, int D, float scale, unsigned char* __restrict__ out3,
+                                                            int64_t R3) {
   constexpr int NT = 64 * WB;
   constexpr int RPP = NT / 16;          // K/V rows staged per pass (16 lanes per 256-byte row)
   constexpr int NLD = KT / RPP;         // staging passes per tile
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(con
   // oacc[db][r] = O[q0+ql][db*32 + (r&3) + 8*(r>>2) + 4*h2]  ->  float4 per (db, r>>2)
   if (wave_active && q0 + ql < T) {
     const float inv = 1.0f / l_run;
-    float* op = out + (b * T + q0 + ql) * (int64_t)D + h * HD + 4 * h2;
+    const int64_t row = b * T + q0 + ql;
+    float* op = out + row * (int64_t)D + h * HD + 4 * h2;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -177,7 +186,32 @@ __global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(con
         v[1] = oacc[db][4 * g + 1] * inv;
         v[2] = oacc[db][4 * g + 2] * inv;
         v[3] = oacc[db][4 * g + 3] * inv;
-        *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g) = v;
+        if constexpr (OUT3) {
+          // 4 consecutive k = h*64 + db*32 + 8g + 4*h2 .. +3  ->  8 bytes in each plane
+          const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
+          unsigned char* dst = out3 + (((int64_t)(k0 >> 4) * 3) * R3 + row) * 32 +
+                               (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
+          unsigned pk[3][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float r = v[j];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              const unsigned bb = attn_bf16_rne(r);
+              if (j & 1) pk[pl][j >> 1] |= bb << 16;
+              else pk[pl][j >> 1] = bb;
+              r -= __uint_as_float(bb << 16);
+            }
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            uint2 o;
+            o.x = pk[pl][0]; o.y = pk[pl][1];
+            *reinterpret_cast<uint2*>(dst + pl * R3 * 32) = o;
+          }
+        } else {
+          *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g) = v;
+        }
       }
   }
 }
@@ -185,7 +219,8 @@ __global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(con
 }  // namespace
 
 // qkv [B*T, 3D] (q | k | v, each head-major 64-wide), out [B*T, D]
-int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads, hipStream_t stream) {
+int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads, hipStream_t stream,
+              unsigned char* out3) {
   ANYLOC_CHECK_ARG(D == heads * HD, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   ANYLOC_CHECK_ARG(T > 0 && batch > 0 && batch < 65536, "attention: bad T/batch");
   const double flops = 4.0 * (double)batch * heads * (double)T * T * HD;
@@ -198,11 +233,16 @@ int attention(const float* qkv, float* out, int64_t batch, int T, int D, int hea
   }
   const dim3 g4((T + 127) / 128, heads, (unsigned)batch), g2((T + 63) / 64, heads, (unsigned)batch);
   (void)g2;
+  const int64_t R3 = batch * T;
+  if (out3) {
+    hipLaunchKernelGGL((attention_kernel<4, true, true, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3);
+    return launch_status("attention_kernel");
+  }
   switch (cfg) {
-    case 1: hipLaunchKernelGGL((attention_kernel<4, false, false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
-    case 2: hipLaunchKernelGGL((attention_kernel<4, true, false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
-    case 3: hipLaunchKernelGGL((attention_kernel<4, false, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
-    default: hipLaunchKernelGGL((attention_kernel<4, true, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f); break;
+    case 1: hipLaunchKernelGGL((attention_kernel<4, false, false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3); break;
+    case 2: hipLaunchKernelGGL((attention_kernel<4, true, false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3); break;
+    case 3: hipLaunchKernelGGL((attention_kernel<4, false, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3); break;
+    default: hipLaunchKernelGGL((attention_kernel<4, true, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3); break;
   }
   return launch_status("attention_kernel");
 }

@@ -107,6 +107,7 @@ struct X6Problem {
   const unsigned char* A3; int64_t RA;     // plane image of A [M, 16*K16], RA = rows the image was built with
   const unsigned char* W3; int64_t RW;     // plane image of W [N, 16*K16]
   float* C; int64_t ldc;
+  unsigned char* C3; int64_t RC;            // optional (GELU / SwiGLU): write the result as a plane image with RC rows
   int64_t M, N;
   int K16;                                  // k-blocks of 16
   int64_t a_off, w_off;                     // byte offset of A3 / W3 inside its image (row sub-range of a larger image)
@@ -118,6 +119,8 @@ struct X6Problem {
 size_t x3_bytes(int64_t rows, int64_t K);
 int split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* x3, hipStream_t stream);
 int gemm_x6(const X6Problem& p, int epilogue, hipStream_t stream);
+int layernorm_x3(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* x3,
+                 hipStream_t stream);
 
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
                 int64_t dim, float eps, hipStream_t stream);
@@ -131,7 +134,7 @@ int facet_rows(const float* src, int64_t lds_, int coff, float* out, int64_t ldo
                int64_t batch, int T, int skip, int rows_per_img, int dim, int normalize, float eps,
                hipStream_t stream);
 int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads,
-              hipStream_t stream);
+              hipStream_t stream, unsigned char* out3 = nullptr);   // out3: write the result as a plane image instead
 
 // single-pass fused VLAD / k-means (vlad_fused.hip)
 struct FusedArgs {

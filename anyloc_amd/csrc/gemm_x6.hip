@@ -61,10 +61,30 @@ struct X6Cfg {
   static_assert(BM % (32 * NW) == 0 && BN % (32 * NW) == 0, "each wave stages whole 32-row pieces");
 };
 
+__device__ __forceinline__ unsigned bf16_rne(float x) {          // finite inputs
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// one fp32 value -> its three bf16 planes at (row, col) of an x3 image with R rows
+__device__ __forceinline__ void store_x3(unsigned char* img, int64_t R, int64_t row, int64_t col, float v) {
+  const int e = (int)(col & 15);
+  unsigned char* dst = img + (((col >> 4) * 3) * R + row) * 32 + ((((e >> 3) ^ (int)((row >> 3) & 1))) << 4) + (e & 7) * 2;
+  float r = v;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const unsigned b = bf16_rne(r);
+    *reinterpret_cast<unsigned short*>(dst + pl * R * 32) = (unsigned short)b;
+    r -= __uint_as_float(b << 16);                                 // exact
+  }
+}
+
 __device__ __forceinline__ float x6_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float x6_silu(float v) { return v / (1.0f + expf(-v)); }
 
-template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHED = 0>
+// OUT3: the activation (GELU / SwiGLU epilogues) is written as the plane image the NEXT GEMM reads (p.C3, p.RC rows)
+// instead of fp32 -- the value never makes an fp32 round trip through HBM
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHED = 0, bool OUT3 = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p, int tiles_m, int tiles_n) {
   using Cfg = X6Cfg<MI, NI, WM, WN, STAGES>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -182,7 +202,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p,
           const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
           if (row < p.M && cok) {
             const float g = acc[mi][nj][r] + bg, v = acc[mi][nj + 1][r] + bv;
-            p.C[row * p.ldc + ocol] = x6_silu(g) * v;
+            if constexpr (OUT3) store_x3(p.C3, p.RC, row, ocol, x6_silu(g) * v);
+            else p.C[row * p.ldc + ocol] = x6_silu(g) * v;
           }
         }
     }
@@ -203,7 +224,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p,
             const float v = acc[mi][ni][r] + bv;
             const int64_t o = row * p.ldc + col;
             if constexpr (EPI == EPI_STORE) p.C[o] = v;
-            else if constexpr (EPI == EPI_GELU) p.C[o] = x6_gelu_erf(v);
+            else if constexpr (EPI == EPI_GELU) {
+              if constexpr (OUT3) store_x3(p.C3, p.RC, row, col, x6_gelu_erf(v));
+              else p.C[o] = x6_gelu_erf(v);
+            }
             else p.C[o] = p.resid[o] + v * gam;
           }
         }
@@ -211,23 +235,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p,
   }
 }
 
-template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHED = 0>
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHED = 0, bool OUT3 = false>
 int launch_x6(const X6Problem& p, hipStream_t stream) {
   using Cfg = X6Cfg<MI, NI, WM, WN, STAGES>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
   static bool attr_set = false;
   if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED>),
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED, OUT3>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED>), dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WM * WN),
+  hipLaunchKernelGGL((gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED, OUT3>), dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WM * WN),
                      Cfg::LDS, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_x6_kernel");
 }
 
 template <int EPI>
 int dispatch_x6(const X6Problem& p, hipStream_t stream) {
+  if constexpr (EPI == EPI_GELU || EPI == EPI_SWIGLU)
+    if (p.C3) return launch_x6<2, 4, 2, 2, 2, 2, EPI, 1, true>(p, stream);
   // ANYLOC_X6_CFG (micro-benchmarks): 0 = 128x256 tile, 4 waves, 2-deep ring, two blocks per CU (default);
   //   1 = 128x128 3-deep; 2 = 256x128 3-deep (1 block/CU); 3 = 256x128 2-deep; 7 / 8 = 256x256 with 8 waves
   static int cfg = -1;
@@ -250,11 +276,6 @@ int dispatch_x6(const X6Problem& p, hipStream_t stream) {
 }
 
 // ---- fp32 row-major -> x3 planes ------------------------------------------------------------------------
-__device__ __forceinline__ unsigned bf16_rne(float x) {          // finite inputs
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
 __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int64_t K,
                                                        unsigned char* __restrict__ out, int64_t R, int K16) {
   const int64_t row = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 1);
@@ -302,7 +323,114 @@ __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__
   }
 }
 
+// LayerNorm whose output is written directly as the plane image of the next GEMM's A operand (no fp32 y).
+// 16 rows per 256-thread block.  Phase 1: wave w holds its rows 4w..4w+3 entirely in registers (NV float4 per lane
+// and row) and reduces mean / variance with wave shuffles.  Phase 2, per chunk of 256 columns: the normalised
+// values go through a [16][256] fp32 LDS tile and are read back in IMAGE order -- thread = (k-block, row, half) --
+// so every store instruction writes whole 512-byte runs of the image, 16 bytes per lane.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int dim, int64_t rows,
+                                                           float eps, unsigned char* __restrict__ out, int64_t R) {
+  constexpr int LDT = 256 + 4;                     // padded tile row (floats): rows land on different banks
+  __shared__ __attribute__((aligned(16))) float tile[16][LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n4 = dim >> 2;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  f32x4 v[4][NV];
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = min(row0 + wave * 4 + q, rows - 1);       // tail rows recompute the last row, never stored
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < n4) {
+        v[q][i] = xr[idx];
+        s += (v[q][i][0] + v[q][i][1]) + (v[q][i][2] + v[q][i][3]);
+      }
+    }
+    mean[q] = wave_sum(s) / (float)dim;
+    float qs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < n4) {
+        const float d0 = v[q][i][0] - mean[q], d1 = v[q][i][1] - mean[q], d2 = v[q][i][2] - mean[q], d3 = v[q][i][3] - mean[q];
+        qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    rstd[q] = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
+  }
+  // image-order role of this thread inside a 256-column chunk: two (k-block, row, half) items
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;                                 // float4 index inside the row = chunk i, lane
+    if (i > 0) __syncthreads();
+    if (idx < n4) {
+      const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[q][i][j] - mean[q]) * rstd[q] * wv[j] + bv[j];
+        *reinterpret_cast<f32x4*>(&tile[wave * 4 + q][4 * lane]) = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int item = tid + 256 * u;                              // 16 k-blocks x 16 rows x 2 halves
+      const int kbl = item >> 5, r = (item >> 1) & 15, half = item & 1;
+      const int k0 = 256 * i + 16 * kbl + 8 * half;
+      const int64_t row = row0 + r;
+      if (k0 < dim && row < rows) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
+        unsigned pk[3][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float rr = j < 4 ? lo[j & 3] : hi[j & 3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned bb = bf16_rne(rr);
+            if (j & 1) pk[pl][j >> 1] |= bb << 16;
+            else pk[pl][j >> 1] = bb;
+            rr -= __uint_as_float(bb << 16);
+          }
+        }
+        unsigned char* dst = out + (((int64_t)(k0 >> 4) * 3) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          u32x4 o;
+          o[0] = pk[pl][0]; o[1] = pk[pl][1]; o[2] = pk[pl][2]; o[3] = pk[pl][3];
+          *reinterpret_cast<u32x4*>(dst + pl * R * 32) = o;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int layernorm_x3(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* x3,
+                 hipStream_t stream) {
+  ANYLOC_CHECK_ARG(dim % 16 == 0 && dim <= 2048, "layernorm_x3: dim %d (needs a multiple of 16, at most 2048)", dim);
+  ProfScope prof("layernorm_x3", stream, 8.0 * rows * dim, 10.0 * rows * dim);
+  const dim3 grid((unsigned)((rows + 15) / 16));
+  unsigned char* out = static_cast<unsigned char*>(x3);
+  const int nv = (dim / 4 + 63) / 64;
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_x3_kernel<1>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+    case 2: hipLaunchKernelGGL(layernorm_x3_kernel<2>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+    case 3: hipLaunchKernelGGL(layernorm_x3_kernel<3>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+    case 4: hipLaunchKernelGGL(layernorm_x3_kernel<4>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+    case 5: hipLaunchKernelGGL(layernorm_x3_kernel<5>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+    case 6: hipLaunchKernelGGL(layernorm_x3_kernel<6>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+    default: hipLaunchKernelGGL(layernorm_x3_kernel<8>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, rows); break;
+  }
+  return launch_status("layernorm_x3_kernel");
+}
 
 size_t x3_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 3 * (size_t)rows * 32; }
 
@@ -316,7 +444,12 @@ int split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* x3, hip
 }
 
 int gemm_x6(const X6Problem& p, int epilogue, hipStream_t stream) {
-  ANYLOC_CHECK_ARG(p.A3 && p.W3 && p.C, "gemm_x6: null operand");
+  ANYLOC_CHECK_ARG(p.A3 && p.W3 && (p.C || p.C3), "gemm_x6: null operand");
+  if (p.C3) {
+    const int64_t n_out = epilogue == EPI_SWIGLU ? p.N / 2 : p.N;
+    ANYLOC_CHECK_ARG((epilogue == EPI_GELU || epilogue == EPI_SWIGLU) && n_out % 16 == 0 && p.RC >= p.M,
+                     "gemm_x6: plane-image output needs a GELU / SwiGLU epilogue and a multiple of 16 output columns");
+  }
   ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K16 > 0 && p.RA >= p.M && p.RW >= p.N, "gemm_x6: bad shape");
   ANYLOC_CHECK_ARG((size_t)p.K16 * 3 * (size_t)p.RA * 32 < (1ull << 31) && (size_t)p.K16 * 3 * (size_t)p.RW * 32 < (1ull << 31),
                    "gemm_x6: operand image exceeds the 2 GiB buffer-addressing range");

@@ -18,6 +18,7 @@
 //   y   = LN2(x)
 //   h   = gelu(y W1^T + b)  |  silu(y Wg^T+b)*(y Wv^T+b)    EPI_GELU | EPI_SWIGLU
 //   x  += ls2 * (h W2^T + b)                        EPI_LS_RESID (in place)
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -36,7 +37,8 @@ namespace {
 
 struct VitWs {
   float *x, *y, *qkv, *h;   // qkv doubles as the im2col buffer; attention output aliases y
-  unsigned char* a3;        // split-bf16 mode: plane image of the current GEMM's activation operand
+  unsigned char* a3;        // split-bf16 mode: plane image of a D-wide activation operand (LN output, attention output)
+  unsigned char* h3;        //                  plane image of the FFN hidden activation
   size_t bytes;
 };
 
@@ -49,7 +51,8 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   const int64_t qkv_elems = std::max<int64_t>(M * 3 * c.dim, batch * np * c.patch_k_pad);
   w.qkv = a.take<float>(qkv_elems);
   w.h = a.take<float>(M * c.ffn_hidden);
-  w.a3 = a.take<unsigned char>(x3_bytes(M, std::max(c.dim, c.ffn_hidden)));
+  w.a3 = a.take<unsigned char>(x3_bytes(M, c.dim));
+  w.h3 = a.take<unsigned char>(x3_bytes(M, c.ffn_hidden));
   w.bytes = a.off;
   return w;
 }
@@ -68,12 +71,21 @@ int linear(const float* A, int64_t lda, const float* Wt, int64_t K, const float*
   return gemm_nt(g, epi, stream);
 }
 
-// y = act(A W^T + b) with A given in fp32: split A into planes, then the six-product bf16 GEMM
+// ANYLOC_X6_FUSE=0: keep fp32 activations and split them in front of every GEMM (A/B measurements)
+bool x6_fused() {
+  const char* e = getenv("ANYLOC_X6_FUSE");      // read per forward: tests flip it inside one process
+  return !(e && atoi(e) == 0);
+}
+
+// y = act(A W^T + b) on the six-product bf16 GEMM.  A is given as fp32 (split into planes here) or, when A == nullptr,
+// a3 already holds its plane image (written by the producer).  c3 != nullptr: the activation is written as the plane
+// image of the next GEMM instead of fp32 C.
 int linear_x6(const float* A, int64_t K, unsigned char* a3, const void* w3, int64_t w_rows, int64_t w_row0,
               const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
-              const char* tag, hipStream_t stream) {
-  ANYLOC_TRY(split_x3(A, K, M, K, a3, stream));
+              const char* tag, hipStream_t stream, unsigned char* c3 = nullptr) {
+  if (A) ANYLOC_TRY(split_x3(A, K, M, K, a3, stream));
   X6Problem g{};
+  g.C3 = c3; g.RC = M;
   g.A3 = a3; g.RA = M;
   g.W3 = static_cast<const unsigned char*>(w3) + w_row0 * 32; g.RW = w_rows;
   g.w_off = w_row0 * 32;
@@ -181,6 +193,7 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
   }
   const bool x6 = flags & ANYLOC_VIT_SPLIT_BF16;
   ANYLOC_CHECK_ARG(!x6 || !h->x3.empty(), "vit_forward: ANYLOC_VIT_SPLIT_BF16 without anyloc_vit_attach_x3");
+  const bool fuse_x6 = x6 && x6_fused();
   const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
   const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;
   const int64_t ldo = (int64_t)n_taps * D;
@@ -211,14 +224,18 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
   for (int l = 0; l <= last_layer; ++l) {
     const anyloc_vit_block_weights& b = h->blocks[l];
     const bool last = (l == last_layer);
-    ANYLOC_TRY(layernorm(w.x, w.y, b.norm1_w, b.norm1_b, M, D, 1e-6f, stream));
+    // split-bf16 mode, fused producers: LayerNorm / attention / FFN activation write plane images directly
+    const bool fuse = fuse_x6;
+    if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, stream));
+    else ANYLOC_TRY(layernorm(w.x, w.y, b.norm1_w, b.norm1_b, M, D, 1e-6f, stream));
+    const float* y_in = fuse ? nullptr : w.y;     // nullptr: the plane image is already in w.a3
     if (last && !last_needs_full) {
       // only q/k/v taps remain: compute just the tapped thirds of the QKV projection
       for (int t = 0; t < n_taps; ++t) {
         if (tap_layers[t] != l) continue;
         const int f = tap_facets[t];
         if (x6)
-          ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].qkv_w3, 3 * D, (int64_t)f * D, b.qkv_b + (int64_t)f * D, w.qkv, D,
+          ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, (int64_t)f * D, b.qkv_b + (int64_t)f * D, w.qkv, D,
                                M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream));
         else
           ANYLOC_TRY(linear(w.y, D, b.qkv_w + (int64_t)f * D * D, D, b.qkv_b + (int64_t)f * D, w.qkv, D, M, D,
@@ -229,7 +246,7 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       break;
     }
     if (x6)
-      ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].qkv_w3, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr,
+      ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr,
                            "vit_qkv_gemm", stream));
     else
       ANYLOC_TRY(linear(w.y, D, b.qkv_w, D, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
@@ -237,23 +254,25 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
         ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
                               norm_taps, 1e-12f, stream));
-    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream));
+    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr));
     if (x6)
-      ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
+      ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
                            "vit_proj_gemm", stream));
     else
       ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
-    ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
+    if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
+    else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
     if (x6) {
+      unsigned char* c3 = fuse ? w.h3 : nullptr;
       if (c.ffn_kind == 0)
-        ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].fc1_w3, Hh, 0, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr,
-                             "vit_fc1_gemm", stream));
+        ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].fc1_w3, Hh, 0, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr,
+                             "vit_fc1_gemm", stream, c3));
       else
-        ANYLOC_TRY(linear_x6(w.y, D, w.a3, h->x3[l].fc1_w3, 2 * Hh, 0, b.fc1_b, w.h, Hh, M, 2 * Hh, EPI_SWIGLU, nullptr,
-                             "vit_w12_gemm", stream));
-      ANYLOC_TRY(linear_x6(w.h, Hh, w.a3, h->x3[l].fc2_w3, D, 0, b.fc2_b, w.x, D, M, D, EPI_LS_RESID, b.ls2,
-                           "vit_fc2_gemm", stream));
+        ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].fc1_w3, 2 * Hh, 0, b.fc1_b, w.h, Hh, M, 2 * Hh, EPI_SWIGLU, nullptr,
+                             "vit_w12_gemm", stream, c3));
+      ANYLOC_TRY(linear_x6(fuse ? nullptr : w.h, Hh, w.h3, h->x3[l].fc2_w3, D, 0, b.fc2_b, w.x, D, M, D, EPI_LS_RESID,
+                           b.ls2, "vit_fc2_gemm", stream));
     } else {
       if (c.ffn_kind == 0) {
         ANYLOC_TRY(linear(w.y, D, b.fc1_w, D, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr, "vit_fc1_gemm", stream));

@@ -93,6 +93,30 @@ def test_vit_tokens_agree_between_gemm_modes(monkeypatch, name, layer, depth):
         weights.unregister_state_dict()
 
 
+@pytest.mark.parametrize("name,layer,depth,hw", [("dinov2_vits14", 9, None, (224, 224)), ("dinov2_vitg14", 1, 2, (126, 154)),
+                                                 ("dinov2_vitl14", 2, 3, (70, 98))])
+def test_fused_plane_producers_equal_split_passes(monkeypatch, name, layer, depth, hw):
+    """LayerNorm / attention / GELU-SwiGLU epilogue writing the plane image directly vs fp32 activations + a
+    split pass (ANYLOC_X6_FUSE=0).  The split is exact, so the only difference is LayerNorm's reduction order
+    (per-wave rows vs per-block rows): a few ulp on unit-norm tokens."""
+    import utilities
+    monkeypatch.setenv("ANYLOC_GEMM", "x6")
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, depth=depth))
+    try:
+        imgs = torch.cat(synth.synthetic_places(4, 1, hw[0], hw[1], seed=9)[:2]).to(DEV)
+        res = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("ANYLOC_X6_FUSE", fuse)
+            res[fuse] = (utilities.DinoV2ExtractFeatures(name, layer, "value", device=DEV)(imgs),
+                         utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False,
+                                                         device=DEV)(imgs))
+        assert float((res["1"][0] - res["0"][0]).abs().max()) < 1e-6
+        scale = float(res["0"][1].abs().max())
+        assert float((res["1"][1] - res["0"][1]).abs().max()) < 2e-6 * scale
+    finally:
+        weights.unregister_state_dict()
+
+
 def test_golden_tokens_in_fp32_mfma_mode(monkeypatch, golden_dir):
     """The exact-fp32 MFMA path stays a supported mode (ANYLOC_GEMM=f32): same golden vector, same tolerance."""
     import utilities
