@@ -252,8 +252,11 @@ int launch_x6(const X6Problem& p, hipStream_t stream) {
 
 template <int EPI>
 int dispatch_x6(const X6Problem& p, hipStream_t stream) {
+  // few tiles (small batches): 128x128 tiles double the number of workgroups
+  const bool small = ((p.M + 127) / 128) * ((p.N + 255) / 256) < 512;
   if constexpr (EPI == EPI_GELU || EPI == EPI_SWIGLU)
-    if (p.C3) return launch_x6<2, 4, 2, 2, 2, 2, EPI, 1, true>(p, stream);
+    if (p.C3) return small ? launch_x6<2, 2, 2, 2, 3, 2, EPI, 1, true>(p, stream)
+                           : launch_x6<2, 4, 2, 2, 2, 2, EPI, 1, true>(p, stream);
   // ANYLOC_X6_CFG (micro-benchmarks): 0 = 128x256 tile, 4 waves, 2-deep ring, two blocks per CU (default);
   //   1 = 128x128 3-deep; 2 = 256x128 3-deep (1 block/CU); 3 = 256x128 2-deep; 7 / 8 = 256x256 with 8 waves
   static int cfg = -1;
@@ -271,7 +274,8 @@ int dispatch_x6(const X6Problem& p, hipStream_t stream) {
     case 7: return launch_x6<4, 2, 2, 4, 2, 1, EPI, 1>(p, stream);   // 256x256 tile, 8 waves, one block per CU
     case 8: return launch_x6<2, 4, 4, 2, 2, 1, EPI, 1>(p, stream);
     case 9: return launch_x6<2, 4, 2, 2, 2, 2, EPI, 2>(p, stream);
-    default: return launch_x6<2, 4, 2, 2, 2, 2, EPI, 1>(p, stream);  // 128x256, refills interleaved with the MFMAs
+    default:                                                         // 128x256, refills interleaved with the MFMAs
+      return small ? launch_x6<2, 2, 2, 2, 3, 2, EPI, 1>(p, stream) : launch_x6<2, 4, 2, 2, 2, 2, EPI, 1>(p, stream);
   }
 }
 

@@ -77,6 +77,11 @@ bool x6_fused() {
   return !(e && atoi(e) == 0);
 }
 
+int64_t x6_min_rows() {
+  const char* e = getenv("ANYLOC_X6_MIN_ROWS");
+  return e ? atoll(e) : 1600;
+}
+
 // y = act(A W^T + b) on the six-product bf16 GEMM.  A is given as fp32 (split into planes here) or, when A == nullptr,
 // a3 already holds its plane image (written by the producer).  c3 != nullptr: the activation is written as the plane
 // image of the next GEMM instead of fp32 C.
@@ -191,8 +196,12 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
     set_error("vit_forward: workspace %zu < %zu", workspace_bytes, w.bytes);
     return ANYLOC_ERR_WORKSPACE;
   }
-  const bool x6 = flags & ANYLOC_VIT_SPLIT_BF16;
-  ANYLOC_CHECK_ARG(!x6 || !h->x3.empty(), "vit_forward: ANYLOC_VIT_SPLIT_BF16 without anyloc_vit_attach_x3");
+  ANYLOC_CHECK_ARG(!(flags & ANYLOC_VIT_SPLIT_BF16) || !h->x3.empty(),
+                   "vit_forward: ANYLOC_VIT_SPLIT_BF16 without anyloc_vit_attach_x3");
+  // below ~3 images of 530 tokens the GEMMs have too few 128-row tiles to fill 256 CUs twice over: the fp32-MFMA
+  // kernel with its 64-row split is faster there (measured B=1: 60 vs 40 images/s), so the split-bf16 request is
+  // honoured from x6_min_rows() rows up (ANYLOC_X6_MIN_ROWS overrides)
+  const bool x6 = (flags & ANYLOC_VIT_SPLIT_BF16) && M >= x6_min_rows();
   const bool fuse_x6 = x6 && x6_fused();
   const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
   const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;

@@ -76,6 +76,7 @@ def test_gemm_x6_deterministic_and_tail_rows_untouched():
 @pytest.mark.parametrize("name,layer,depth", [("dinov2_vits14", 9, None), ("dinov2_vitg14", 1, 2)])
 def test_vit_tokens_agree_between_gemm_modes(monkeypatch, name, layer, depth):
     import utilities
+    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")        # small test batches: force the split-bf16 kernels
     sd = synth.synthetic_state_dict(name, 0, depth=depth)
     weights.register_state_dict(name, sd)
     try:
@@ -101,6 +102,7 @@ def test_fused_plane_producers_equal_split_passes(monkeypatch, name, layer, dept
     (per-wave rows vs per-block rows): a few ulp on unit-norm tokens."""
     import utilities
     monkeypatch.setenv("ANYLOC_GEMM", "x6")
+    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, depth=depth))
     try:
         imgs = torch.cat(synth.synthetic_places(4, 1, hw[0], hw[1], seed=9)[:2]).to(DEV)
@@ -120,6 +122,7 @@ def test_fused_plane_producers_equal_split_passes(monkeypatch, name, layer, dept
 def test_golden_tokens_in_fp32_mfma_mode(monkeypatch, golden_dir):
     """The exact-fp32 MFMA path stays a supported mode (ANYLOC_GEMM=f32): same golden vector, same tolerance."""
     import utilities
+    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
     g1 = np.load(os.path.join(golden_dir, "config1_vits14_l9_value_k8.npz"))
     name = str(g1["model"])
     weights.register_state_dict(name, synth.synthetic_state_dict(name, int(g1["weights_seed"])))
@@ -131,6 +134,27 @@ def test_golden_tokens_in_fp32_mfma_mode(monkeypatch, golden_dir):
             ext = utilities.DinoV2ExtractFeatures(name, 9, "value", device=DEV)
             one = ext(db[:1].to(DEV))
             assert float((one[0].cpu() - torch.from_numpy(g1["tokens_img0"])).abs().max()) < 2e-5, mode
+    finally:
+        weights.unregister_state_dict()
+
+
+def test_small_batches_take_the_fp32_mfma_kernels(monkeypatch):
+    """Below ANYLOC_X6_MIN_ROWS token rows (default 1600, i.e. B <= 3 at 322x322) a split-bf16 forward runs the
+    exact-fp32 kernels (more, smaller tiles): bit-identical to ANYLOC_GEMM=f32, and different bits from the forced
+    split-bf16 run of the same batch."""
+    import utilities
+    name = "dinov2_vits14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, depth=4))
+    try:
+        img = synth.synthetic_places(1, 0, 224, 224, seed=3)[0].to(DEV)            # 257 rows
+        monkeypatch.setenv("ANYLOC_GEMM", "x6")
+        auto = utilities.DinoV2ExtractFeatures(name, 3, "value", device=DEV)(img)
+        monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+        forced = utilities.DinoV2ExtractFeatures(name, 3, "value", device=DEV)(img)
+        monkeypatch.setenv("ANYLOC_GEMM", "f32")
+        exact = utilities.DinoV2ExtractFeatures(name, 3, "value", device=DEV)(img)
+        assert torch.equal(auto, exact)
+        assert not torch.equal(forced, exact) and float((forced - exact).abs().max()) < 2e-6
     finally:
         weights.unregister_state_dict()
 
