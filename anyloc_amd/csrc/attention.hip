@@ -216,11 +216,244 @@ __global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(con
   }
 }
 
+// ---- split-bf16 ("x6") attention: both matrix products on v_mfma_f32_32x32x16_bf16 with fp32-level accuracy ----
+// Same structure as attention_kernel (S^T = K Q^T, online softmax per lane, O^T += V^T P^T), but every operand is the
+// exact sum of three bf16 planes and each product is the six leading plane products (see gemm_x6.hip):
+//   * Q is split once per wave into registers; K and V are split ONCE PER WORKGROUP while a 32-key tile is staged
+//     into LDS (K as [plane][key][64 d], V transposed as [plane][d][32 keys] so that the A fragment of V^T P^T is
+//     two 8-byte reads); P = exp(S - m) is split in registers right after the softmax.
+//   * 24 + 24 MFMAs of 8 passes per key tile instead of 32 + 32 of 16 passes: 1536 instead of 4096 matrix-core
+//     cycles per wave and tile.
+constexpr int KROW = 144;     // bytes per key row of one K plane (128 + 16: ds_read_b128 conflict-free)
+constexpr int VROW = 72;      // bytes per d row of one V^T plane (64 + 8: ds_read_b64 conflict-free)
+
+typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
+
+// four floats -> the packed bf16 pairs of their three planes: pk[plane][0] = (x0, x1), pk[plane][1] = (x2, x3)
+__device__ __forceinline__ void split4(const f32x4 v, unsigned pk[3][2]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned b = attn_bf16_rne(r);
+      if (j & 1) pk[pl][j >> 1] |= b << 16;
+      else pk[pl][j >> 1] = b;
+      r -= __uint_as_float(b << 16);
+    }
+  }
+}
+
+#define ANYLOC_MFMA_BF16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(attn_bf16x8, a), __builtin_bit_cast(attn_bf16x8, b), c, 0, 0, 0)
+
+template <bool OUT3>
+__global__ __launch_bounds__(256, 2) void attention_x6_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
+                                                              int D, float scale, unsigned char* __restrict__ out3,
+                                                              int64_t R3) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][3][KT * KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[2][3][HD * VROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t ld = 3 * (int64_t)D;
+  const float* base = qkv + b * T * ld;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, h2 = lane >> 5;
+  const bool wave_active = q0 < T;
+
+  // ---- Q fragments (B operand): lane (query ql, half h2), k-step s: d = 16 s + 8 h2 + j, three planes ----
+  attn_u32x4 qf[3][4];
+  {
+    const int qr = min(q0 + ql, T - 1);
+    const float* qp = base + (int64_t)qr * ld + h * HD + 8 * h2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      unsigned lo[3][2], hi[3][2];
+      split4(*reinterpret_cast<const f32x4*>(qp + 16 * s), lo);
+      split4(*reinterpret_cast<const f32x4*>(qp + 16 * s + 4), hi);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        qf[pl][s][0] = lo[pl][0]; qf[pl][s][1] = lo[pl][1]; qf[pl][s][2] = hi[pl][0]; qf[pl][s][3] = hi[pl][1];
+      }
+    }
+  }
+
+  // ---- K/V staging: 16 lanes cover one 256-byte head row of a key; two passes of 16 keys ----
+  const int sr = tid >> 4, sc = tid & 15;
+  const __amdgpu_buffer_rsrc_t kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(base), 0, (int)((int64_t)T * ld * 4), 0x00020000);
+  unsigned kv_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) kv_off[i] = (unsigned)(((int64_t)(sr + 16 * i) * ld + h * HD + 4 * sc) * 4);
+  const unsigned k_col = (unsigned)D * 4, v_col = (unsigned)D * 8, tile_bytes = (unsigned)(KT * ld * 4);
+  f32x4 rk[2], rv[2];
+  auto fetch = [&](int kt) {
+    const unsigned so = (unsigned)kt * tile_bytes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_off[i] + k_col, so, 0));
+      rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kv_off[i] + v_col, so, 0));
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = sr + 16 * i;
+      unsigned pk[3][2];
+      split4(rk[i], pk);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        attn_u32x2 o;
+        o[0] = pk[pl][0]; o[1] = pk[pl][1];
+        *reinterpret_cast<attn_u32x2*>(&Ks[buf][pl][key * KROW + sc * 8]) = o;
+      }
+      split4(rv[i], pk);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<unsigned short*>(&Vs[buf][pl][(4 * sc + j) * VROW + key * 2]) =
+              (unsigned short)(pk[pl][j >> 1] >> (16 * (j & 1)));
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (T + KT - 1) / KT;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) fetch(kt + 1);
+    if (wave_active) {
+      // S^T = K_tile (A: rows = keys) x Q^T (B: cols = queries), 4 k-steps of 16 d, six plane products each
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        attn_u32x4 kf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          kf[pl] = *reinterpret_cast<const attn_u32x4*>(&Ks[buf][pl][ql * KROW + s * 32 + h2 * 16]);
+        sacc = ANYLOC_MFMA_BF16(kf[2], qf[0][s], sacc);
+        sacc = ANYLOC_MFMA_BF16(kf[0], qf[2][s], sacc);
+        sacc = ANYLOC_MFMA_BF16(kf[1], qf[1][s], sacc);
+        sacc = ANYLOC_MFMA_BF16(kf[1], qf[0][s], sacc);
+        sacc = ANYLOC_MFMA_BF16(kf[0], qf[1][s], sacc);
+        sacc = ANYLOC_MFMA_BF16(kf[0], qf[0][s], sacc);
+      }
+      // V^T fragments (A operand of O^T += V^T P^T): lane (d = db*32 + ql, h2); k-step s2, element j <-> key
+      // (j&3) + 8*(2*s2 + (j>>2)) + 4*h2 -- the keys register r = 8*s2 + j of the score block holds
+      attn_u32x4 vf[3][2][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned char* vp = &Vs[buf][pl][(db * 32 + ql) * VROW + (16 * s2 + 4 * h2) * 2];
+            const attn_u32x2 a0 = *reinterpret_cast<const attn_u32x2*>(vp);
+            const attn_u32x2 a1 = *reinterpret_cast<const attn_u32x2*>(vp + 16);
+            vf[pl][db][s2][0] = a0[0]; vf[pl][db][s2][1] = a0[1]; vf[pl][db][s2][2] = a1[0]; vf[pl][db][s2][3] = a1[1];
+          }
+      // lane (ql, h2) holds S[q = q0+ql][key = kt*32 + (r&3) + 8*(r>>2) + 4*h2], still unscaled
+      const int kbase = kt * KT + 4 * h2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] *= scale;                 // power of two: exact
+      if (kbase + 28 + 3 >= T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + (r & 3) + 8 * (r >> 2) >= T) sacc[r] = -INFINITY;
+      }
+      float mloc = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __expf(m_run - m_new);
+      float lsum = 0.f;
+      attn_u32x4 pf[3][2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __expf(sacc[r] - m_new);
+        lsum += p;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned bb = attn_bf16_rne(p);
+          if (r & 1) pf[pl][r >> 3][(r & 7) >> 1] |= bb << 16;
+          else pf[pl][r >> 3][(r & 7) >> 1] = bb;
+          p -= __uint_as_float(bb << 16);
+        }
+      }
+      lsum += __shfl_xor(lsum, 32, 64);
+      l_run = l_run * alpha + lsum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          oacc[db] = ANYLOC_MFMA_BF16(vf[2][db][s2], pf[0][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_BF16(vf[0][db][s2], pf[2][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_BF16(vf[1][db][s2], pf[1][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_BF16(vf[1][db][s2], pf[0][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_BF16(vf[0][db][s2], pf[1][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_BF16(vf[0][db][s2], pf[0][s2], oacc[db]);
+        }
+    }
+    if (kt + 1 < nkt) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // oacc[db][r] = O[q0+ql][db*32 + (r&3) + 8*(r>>2) + 4*h2]
+  if (wave_active && q0 + ql < T) {
+    const float inv = 1.0f / l_run;
+    const int64_t row = b * T + q0 + ql;
+    float* op = out + row * (int64_t)D + h * HD + 4 * h2;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = oacc[db][4 * g + 0] * inv;
+        v[1] = oacc[db][4 * g + 1] * inv;
+        v[2] = oacc[db][4 * g + 2] * inv;
+        v[3] = oacc[db][4 * g + 3] * inv;
+        if constexpr (OUT3) {
+          const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
+          unsigned char* dst = out3 + (((int64_t)(k0 >> 4) * 3) * R3 + row) * 32 +
+                               (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
+          unsigned pk[3][2];
+          split4(v, pk);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            uint2 o;
+            o.x = pk[pl][0]; o.y = pk[pl][1];
+            *reinterpret_cast<uint2*>(dst + pl * R3 * 32) = o;
+          }
+        } else {
+          *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g) = v;
+        }
+      }
+  }
+}
+
 }  // namespace
 
 // qkv [B*T, 3D] (q | k | v, each head-major 64-wide), out [B*T, D]
 int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads, hipStream_t stream,
-              unsigned char* out3) {
+              unsigned char* out3, bool x6) {
   ANYLOC_CHECK_ARG(D == heads * HD, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   ANYLOC_CHECK_ARG(T > 0 && batch > 0 && batch < 65536, "attention: bad T/batch");
   const double flops = 4.0 * (double)batch * heads * (double)T * T * HD;
@@ -234,6 +467,16 @@ int attention(const float* qkv, float* out, int64_t batch, int T, int D, int hea
   const dim3 g4((T + 127) / 128, heads, (unsigned)batch), g2((T + 63) / 64, heads, (unsigned)batch);
   (void)g2;
   const int64_t R3 = batch * T;
+  // ANYLOC_ATTN_X6: 1 = split-bf16 kernel for every call (kernel tests), 0 = never, unset = when the caller asks
+  {
+    const char* e = getenv("ANYLOC_ATTN_X6");
+    if (e) x6 = atoi(e) != 0;
+  }
+  if (x6) {
+    if (out3) hipLaunchKernelGGL((attention_x6_kernel<true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3);
+    else hipLaunchKernelGGL((attention_x6_kernel<false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3);
+    return launch_status("attention_x6_kernel");
+  }
   if (out3) {
     hipLaunchKernelGGL((attention_kernel<4, true, true, true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3);
     return launch_status("attention_kernel");

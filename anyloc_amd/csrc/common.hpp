@@ -134,7 +134,8 @@ int facet_rows(const float* src, int64_t lds_, int coff, float* out, int64_t ldo
                int64_t batch, int T, int skip, int rows_per_img, int dim, int normalize, float eps,
                hipStream_t stream);
 int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads,
-              hipStream_t stream, unsigned char* out3 = nullptr);   // out3: write the result as a plane image instead
+              hipStream_t stream, unsigned char* out3 = nullptr,    // out3: write the result as a plane image instead
+              bool x6 = false);                                      // x6: split-bf16 matrix products
 
 // single-pass fused VLAD / k-means (vlad_fused.hip)
 struct FusedArgs {

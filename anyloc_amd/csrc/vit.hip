@@ -263,7 +263,7 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
         ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
                               norm_taps, 1e-12f, stream));
-    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr));
+    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr, x6));
     if (x6)
       ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
                            "vit_proj_gemm", stream));
