@@ -26,11 +26,6 @@ constexpr int KLD = HD + 4;   // padded K row (ds_read_b128 conflict-free)
 // WB = waves (32-query tiles) per workgroup; FASTEXP = v_exp_f32-based exponential
 // PRELOAD: read the whole K fragment set and the whole V column set of a tile into registers before
 //          the MFMA chains that consume them (2 waves/SIMD instead of 3, but no LDS wait inside a chain)
-__device__ __forceinline__ unsigned attn_bf16_rne(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
 // OUT3: the output is written as the three-plane bf16 image (x3 layout of gemm_x6.hip, R = batch*T rows) that the
 // projection GEMM reads, instead of fp32
 template <int WB, bool FASTEXP, bool PRELOAD, bool OUT3 = false>
@@ -191,22 +186,13 @@ __global__ __launch_bounds__(64 * WB, PRELOAD ? 2 : 1) void attention_kernel(con
           const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
           unsigned char* dst = out3 + (((int64_t)(k0 >> 4) * 3) * R3 + row) * 32 +
                                (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
-          unsigned pk[3][2];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float r = v[j];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-              const unsigned bb = attn_bf16_rne(r);
-              if (j & 1) pk[pl][j >> 1] |= bb << 16;
-              else pk[pl][j >> 1] = bb;
-              r -= __uint_as_float(bb << 16);
-            }
-          }
+          unsigned t0[3], t1[3];
+          split_pair_x3(v[0], v[1], t0);
+          split_pair_x3(v[2], v[3], t1);
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
             uint2 o;
-            o.x = pk[pl][0]; o.y = pk[pl][1];
+            o.x = t0[pl]; o.y = t1[pl];
             *reinterpret_cast<uint2*>(dst + pl * R3 * 32) = o;
           }
         } else {
@@ -233,17 +219,11 @@ typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
 
 // four floats -> the packed bf16 pairs of their three planes: pk[plane][0] = (x0, x1), pk[plane][1] = (x2, x3)
 __device__ __forceinline__ void split4(const f32x4 v, unsigned pk[3][2]) {
+  unsigned t0[3], t1[3];
+  split_pair_x3(v[0], v[1], t0);
+  split_pair_x3(v[2], v[3], t1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float r = v[j];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      const unsigned b = attn_bf16_rne(r);
-      if (j & 1) pk[pl][j >> 1] |= b << 16;
-      else pk[pl][j >> 1] = b;
-      r -= __uint_as_float(b << 16);
-    }
-  }
+  for (int pl = 0; pl < 3; ++pl) { pk[pl][0] = t0[pl]; pk[pl][1] = t1[pl]; }
 }
 
 #define ANYLOC_MFMA_BF16(a, b, c) \
@@ -384,16 +364,14 @@ __global__ __launch_bounds__(256, 2) void attention_x6_kernel(const float* __res
       float lsum = 0.f;
       attn_u32x4 pf[3][2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = __expf(sacc[r] - m_new);
-        lsum += p;
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __expf(sacc[r] - m_new), p1 = __expf(sacc[r + 1] - m_new);
+        lsum += p0;
+        lsum += p1;
+        unsigned t[3];
+        split_pair_x3(p0, p1, t);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const unsigned bb = attn_bf16_rne(p);
-          if (r & 1) pf[pl][r >> 3][(r & 7) >> 1] |= bb << 16;
-          else pf[pl][r >> 3][(r & 7) >> 1] = bb;
-          p -= __uint_as_float(bb << 16);
-        }
+        for (int pl = 0; pl < 3; ++pl) pf[pl][r >> 3][(r & 7) >> 1] = t[pl];
       }
       lsum += __shfl_xor(lsum, 32, 64);
       l_run = l_run * alpha + lsum;

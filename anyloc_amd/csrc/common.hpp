@@ -78,6 +78,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- exact three-way bf16 split (split-bf16 GEMM / attention): x = x1 + x2 + x3, round-to-nearest-even at every
+// step, residuals exact in fp32.  Two values per call: v_cvt_pk_bf16_f32 rounds and packs a pair in one instruction;
+// pk[plane] = (plane of a) | (plane of b) << 16.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_x3(float a, float b, unsigned pk[3]) {
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    f32x2 v;
+    v[0] = a; v[1] = b;
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    pk[pl] = u;
+    a -= __uint_as_float(u << 16);               // exact
+    b -= __uint_as_float(u & 0xffff0000u);
+  }
+}
+
 // ---- internal kernels shared between translation units ---------------------
 enum GemmEpilogue {
   EPI_STORE = 0,      // C = acc (+ bias)

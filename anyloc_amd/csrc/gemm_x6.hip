@@ -61,22 +61,14 @@ struct X6Cfg {
   static_assert(BM % (32 * NW) == 0 && BN % (32 * NW) == 0, "each wave stages whole 32-row pieces");
 };
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {          // finite inputs
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
 // one fp32 value -> its three bf16 planes at (row, col) of an x3 image with R rows
 __device__ __forceinline__ void store_x3(unsigned char* img, int64_t R, int64_t row, int64_t col, float v) {
   const int e = (int)(col & 15);
   unsigned char* dst = img + (((col >> 4) * 3) * R + row) * 32 + ((((e >> 3) ^ (int)((row >> 3) & 1))) << 4) + (e & 7) * 2;
-  float r = v;
+  unsigned pk[3];
+  split_pair_x3(v, 0.0f, pk);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    const unsigned b = bf16_rne(r);
-    *reinterpret_cast<unsigned short*>(dst + pl * R * 32) = (unsigned short)b;
-    r -= __uint_as_float(b << 16);                                 // exact
-  }
+  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned short*>(dst + pl * R * 32) = (unsigned short)pk[pl];
 }
 
 __device__ __forceinline__ float x6_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -304,19 +296,9 @@ __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__
     unsigned pk[3][4];
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-      unsigned t[3][2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float r = v[j + e];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const unsigned b = bf16_rne(r);
-          t[pl][e] = b;
-          r -= __uint_as_float(b << 16);               // exact
-        }
-      }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) pk[pl][j >> 1] = t[pl][0] | (t[pl][1] << 16);
+      unsigned t[3];
+      split_pair_x3(v[j], v[j + 1], t);
+      pk[0][j >> 1] = t[0]; pk[1][j >> 1] = t[1]; pk[2][j >> 1] = t[2];
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
@@ -393,15 +375,10 @@ __global__ __launch_bounds__(256) void layernorm_x3_kernel(const float* __restri
         const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
         unsigned pk[3][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float rr = j < 4 ? lo[j & 3] : hi[j & 3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            const unsigned bb = bf16_rne(rr);
-            if (j & 1) pk[pl][j >> 1] |= bb << 16;
-            else pk[pl][j >> 1] = bb;
-            rr -= __uint_as_float(bb << 16);
-          }
+        for (int j = 0; j < 4; ++j) {
+          unsigned t[3];
+          split_pair_x3(j < 2 ? lo[2 * j] : hi[2 * j - 4], j < 2 ? lo[2 * j + 1] : hi[2 * j - 3], t);
+          pk[0][j] = t[0]; pk[1][j] = t[1]; pk[2][j] = t[2];
         }
         unsigned char* dst = out + (((int64_t)(k0 >> 4) * 3) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4);
 #pragma unroll
