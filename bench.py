@@ -206,6 +206,8 @@ def main():
         "peak_note": ("dense bf16 MFMA peak 2500 / 6 products per fp32-accurate product (exact 3-way bf16 split)"
                       if x6 else "fp32 MFMA peak"),
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+        "clock_note": ("profiles/r01_pmc_x6.md: under this kernel the chip runs 1.65 GHz (power limit) with the "
+                       "matrix cores busy 83.6 % of SIMD cycles; `peak` is the nominal 2.4 GHz figure") if x6 else None,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"], "traffic": None,
         "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
                       "vs_fp32_mfma_peak": round(all_gemm / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -159,6 +159,20 @@ def test_small_batches_take_the_fp32_mfma_kernels(monkeypatch):
         weights.unregister_state_dict()
 
 
+def test_large_batches_are_chunked_below_the_plane_image_limit(monkeypatch):
+    """One operand's plane image must stay inside 2 GiB of buffer addressing: the extractor splits the batch
+    (``max_rows``); chunked and unchunked results are identical."""
+    from anyloc_amd import extractor
+    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+    name = "dinov2_vits14"
+    model = extractor.HipDinoV2(name, synth.synthetic_state_dict(name, 0, depth=3), torch.device(DEV), gemm="x6")
+    imgs = torch.cat(synth.synthetic_places(6, 1, 112, 140, seed=2)[:2]).to(DEV)       # 7 images x 81 tokens
+    whole = model.forward_taps(imgs, [(2, "value")])
+    model.max_rows = 2 * 81 + 5                                                          # -> chunks of 2 images
+    parts = model.forward_taps(imgs, [(2, "value")])
+    assert torch.equal(whole, parts)
+
+
 def test_vit_forward_without_attached_planes_is_an_error():
     from anyloc_amd import _lib, extractor, ops
     name = "dinov2_vits14"
