@@ -54,6 +54,10 @@ SIGNATURES = {
     "anyloc_x3_bytes": (C.c_size_t, [c_i64, c_i64]),
     "anyloc_split_x3": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
     "anyloc_gemm_nt_x6": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p]),
+    "anyloc_h2_bytes": (C.c_size_t, [c_i64, c_i64]),
+    "anyloc_split_h2": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
+    "anyloc_gemm_nt_h3": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64,
+                                    C.c_void_p]),
     "anyloc_gemm_nt": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64,
                                  c_i64, c_i64, c_i64, C.c_void_p]),
     "anyloc_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),

@@ -80,6 +80,29 @@ def gemm_nt_x6(a3, w3, M, N, K, bias=None):
     return out
 
 
+def split_h2(x):
+    """EXPERIMENTAL: fp32 [rows, K] -> (two-plane fp16 image, inv_scale[rows]) for gemm_nt_h3."""
+    _need_cuda(x)
+    x = _f32c(x)
+    rows, K = x.shape
+    lib = _lib.load()
+    img = torch.empty(lib.anyloc_h2_bytes(rows, K), dtype=torch.uint8, device=x.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(lib.anyloc_split_h2(_lib.ptr(x), K, rows, K, _lib.ptr(img), _lib.ptr(inv), _lib.stream_ptr()),
+               "anyloc_split_h2")
+    return img, inv
+
+
+def gemm_nt_h3(a2, w2, M, N, K, bias=None):
+    """EXPERIMENTAL: C[M,N] = A W^T (+ bias) from split_h2 images (three fp16 matrix-core products per k-step)."""
+    (a_img, a_inv), (w_img, w_inv) = a2, w2
+    out = torch.empty(M, N, dtype=torch.float32, device=a_img.device)
+    _lib.check(_lib.load().anyloc_gemm_nt_h3(_lib.ptr(a_img), _lib.ptr(a_inv), _lib.ptr(w_img), _lib.ptr(w_inv),
+                                             _lib.ptr(_f32c(bias)) if bias is not None else None, _lib.ptr(out), N,
+                                             M, N, K, _lib.stream_ptr()), "anyloc_gemm_nt_h3")
+    return out
+
+
 def layernorm(x, weight, bias, eps=1e-6):
     _need_cuda(x, weight, bias)
     x = _f32c(x)

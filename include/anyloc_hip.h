@@ -79,6 +79,20 @@ int anyloc_split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* 
 int anyloc_gemm_nt_x6(const void* a3, const void* w3, const float* bias, float* C,
                       int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* ------------------------------------- EXPERIMENTAL: fp16 two-term matmul ----
+ * Same contraction with THREE fp16 matrix-core products per k-step: every operand
+ * row is scaled by a power of two into [2^14, 2^15) and split into two fp16 planes
+ * (22 mantissa bits); the epilogue descales with inv_a[row] * inv_w[col]
+ * (csrc/gemm_h3.hip, tools/split_fp16_study.py).  Not used by anyloc_vit_forward.
+ *   anyloc_split_h2    fp32 [rows, K] (K % 16 == 0) -> plane image + inv_scale[rows]
+ *   anyloc_gemm_nt_h3  C[M,N] = A W^T (+ bias[N]) from the two images */
+size_t anyloc_h2_bytes(int64_t rows, int64_t K);
+int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2,
+                    float* inv_scale, void* stream);
+int anyloc_gemm_nt_h3(const void* a2, const float* a_inv, const void* w2,
+                      const float* w_inv, const float* bias, float* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, void* stream);
+
 /* ------------------------------------------------------------ pooling ----
  * One global descriptor per image from its patch tokens, without VLAD:
  *   ANYLOC_POOL_AVG      mean over tokens          (scripts/dino_v2_gp.py:130-131)
