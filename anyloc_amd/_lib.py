@@ -43,6 +43,13 @@ class VitBlockX3(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in X3_FIELDS]
 
 
+H2_FIELDS = ("qkv_w2", "qkv_inv", "proj_w2", "proj_inv", "fc1_w2", "fc1_inv", "fc2_w2", "fc2_inv")
+
+
+class VitBlockH2(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in H2_FIELDS]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test checks
 SIGNATURES = {
     "anyloc_version": (C.c_int, []),
@@ -77,6 +84,7 @@ SIGNATURES = {
                                     c_f32p, C.POINTER(VitBlockWeights)]),
     "anyloc_vit_destroy": (None, [C.c_void_p]),
     "anyloc_vit_attach_x3": (C.c_int, [C.c_void_p, C.POINTER(VitBlockX3)]),
+    "anyloc_vit_attach_h2": (C.c_int, [C.c_void_p, C.POINTER(VitBlockH2)]),
     "anyloc_vit_workspace_bytes": (c_sz, [C.c_void_p, c_i64, c_i64, c_i64]),
     "anyloc_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_f32p, C.c_int32,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint, c_f32p,

@@ -139,6 +139,25 @@ int gemm_x6(const X6Problem& p, int epilogue, hipStream_t stream);
 int layernorm_x3(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* x3,
                  hipStream_t stream);
 
+// row-scaled two-term fp16 GEMM on two-plane operand images (gemm_h3.hip)
+struct H3Problem {
+  const unsigned char* A2; int64_t RA; const float* a_inv;   // image of A [M, 16*K16], rows of the image, 2^-e per row
+  const unsigned char* W2; int64_t RW; const float* w_inv;   // image of W [N, 16*K16]
+  float* C; int64_t ldc;
+  int64_t M, N;
+  int K16;
+  int64_t a_off, w_off;                     // byte offset of A2 / W2 inside its image (row sub-range)
+  const float* bias;
+  const float* gamma;                       // EPI_LS_RESID
+  const float* resid;                       // EPI_LS_RESID, leading dim ldc
+  const char* tag;
+};
+size_t h2_bytes(int64_t rows, int64_t K);
+int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream);
+int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
+                 float* inv_scale, hipStream_t stream);
+int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
+
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
                 int64_t dim, float eps, hipStream_t stream);
 int layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int dim,

@@ -1,4 +1,4 @@
-// EXPERIMENTAL -- row-scaled two-term fp16 split ("h3") GEMM: C = A W^T with fp32-level accuracy from THREE fp16
+// Row-scaled two-term fp16 split ("h3") GEMM: C = A W^T with fp32-level accuracy from THREE fp16
 // matrix-core products per k-step (half the passes of gemm_x6.hip, which is limited by the chip's power budget).
 //
 // Every operand row is scaled by a power of two so that its largest magnitude lies in [2^14, 2^15):
@@ -7,8 +7,9 @@
 // and below that its absolute error is 2^-39 of the row maximum.  a*b = (hh + hl + lh + ll) 2^-(ea+eb); ll is below
 // 2^-24 and dropped, the other three accumulate in ONE fp32 accumulator (they have their natural magnitudes) and the
 // epilogue multiplies by inv_a[row] * inv_w[col] (powers of two: exact).  CPU emulation of the whole ViT:
-// tools/split_fp16_study.py.  Not used by the ViT forward yet: the attention output and the FFN hidden activation
-// need their exact row maximum before they can be quantised (rows are produced by different workgroups).
+// tools/split_fp16_study.py.  In the ViT forward (ANYLOC_GEMM=h3) LayerNorm quantises its own output (the row is in
+// registers); the attention output and the FFN hidden activation are written as fp32 and quantised by split_h2_kernel,
+// because their rows are produced by different workgroups and the exact row maximum must be known first.
 //
 // Operand image ("h2"): [k/16][plane 0..1][row][16] fp16, 32 bytes per (k-block, plane, row), 16-byte halves swapped
 // when (row >> 3) & 1 -- the x3 image of gemm_x6.hip with two planes; same DMA staging, same fragment reads.
@@ -43,14 +44,6 @@ __device__ __forceinline__ void hdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-struct H3Problem {
-  const unsigned char* A2; int64_t RA; const float* a_inv;     // image of A, rows, 2^-e per row
-  const unsigned char* W2; int64_t RW; const float* w_inv;
-  float* C; int64_t ldc;
-  int64_t M, N;
-  int K16;
-  const float* bias;
-};
 
 template <int MI, int NI, int WM, int WN, int STAGES>
 struct H3Cfg {
@@ -64,7 +57,10 @@ struct H3Cfg {
   static_assert(BM % (32 * NW) == 0 && BN % (32 * NW) == 0, "each wave stages whole 32-row pieces");
 };
 
-template <int MI, int NI, int WM, int WN, int STAGES, int OCC>
+__device__ __forceinline__ float h3_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float h3_silu(float v) { return v / (1.0f + expf(-v)); }
+
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p, int tiles_m, int tiles_n) {
   using Cfg = H3Cfg<MI, NI, WM, WN, STAGES>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -76,9 +72,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
 
   const unsigned a_slab = (unsigned)(2 * p.RA * 32), w_slab = (unsigned)(2 * p.RW * 32);
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(p.A2), 0, (int)((int64_t)p.K16 * a_slab), 0x00020000);
+      const_cast<unsigned char*>(p.A2), 0, (int)((int64_t)p.K16 * a_slab - p.a_off), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(p.W2), 0, (int)((int64_t)p.K16 * w_slab), 0x00020000);
+      const_cast<unsigned char*>(p.W2), 0, (int)((int64_t)p.K16 * w_slab - p.w_off), 0x00020000);
   unsigned a_voff[2], w_voff[2];
 #pragma unroll
   for (int pl = 0; pl < 2; ++pl) {
@@ -149,56 +145,87 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  // ---- epilogue: acc * 2^-(e_row + e_col), then the same fused forms as gemm_x6.hip / gemm_f32.hip ----
   const int64_t wrow0 = m0 + wm * 32 * MI + 4 * (lane >> 5);
   const int64_t wcol0 = n0 + wn * 32 * NI + (lane & 31);
+  if constexpr (EPI == EPI_SWIGLU) {
+    float bg[NI / 2], bv[NI / 2], sg[NI / 2], sv[NI / 2];
+    bool cok[NI / 2];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int64_t col = wcol0 + ni * 32;
-    const bool cok = col < p.N;
-    const float bv = (cok && p.bias) ? p.bias[col] : 0.0f;
-    const float sw_ = cok ? p.w_inv[col] : 0.0f;
+    for (int nj = 0; nj < NI; nj += 2) {
+      const int64_t colg = wcol0 + nj * 32, colv = colg + 32;
+      cok[nj / 2] = colv < p.N;
+      bg[nj / 2] = (cok[nj / 2] && p.bias) ? p.bias[colg] : 0.0f;
+      bv[nj / 2] = (cok[nj / 2] && p.bias) ? p.bias[colv] : 0.0f;
+      sg[nj / 2] = cok[nj / 2] ? p.w_inv[colg] : 0.0f;
+      sv[nj / 2] = cok[nj / 2] ? p.w_inv[colv] : 0.0f;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-        if (row < p.M && cok) p.C[row * p.ldc + col] = acc[mi][ni][r] * (p.a_inv[row] * sw_) + bv;
+        if (row < p.M) {
+          const float ai = p.a_inv[row];
+#pragma unroll
+          for (int nj = 0; nj < NI; nj += 2)
+            if (cok[nj / 2]) {
+              const int64_t ocol = (n0 + wn * 32 * NI + nj * 32) / 2 + (lane & 31);
+              const float g = acc[mi][nj][r] * (ai * sg[nj / 2]) + bg[nj / 2];
+              const float v = acc[mi][nj + 1][r] * (ai * sv[nj / 2]) + bv[nj / 2];
+              p.C[row * p.ldc + ocol] = h3_silu(g) * v;
+            }
+        }
+      }
+  } else {
+    float bv[NI], sw_[NI], gam[NI];
+    bool cok[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t col = wcol0 + ni * 32;
+      cok[ni] = col < p.N;
+      bv[ni] = (cok[ni] && p.bias) ? p.bias[col] : 0.0f;
+      sw_[ni] = cok[ni] ? p.w_inv[col] : 0.0f;
+      gam[ni] = 0.0f;
+      if constexpr (EPI == EPI_LS_RESID) gam[ni] = cok[ni] ? p.gamma[col] : 0.0f;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) {
+          const float ai = p.a_inv[row];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            if (cok[ni]) {
+              const float v = acc[mi][ni][r] * (ai * sw_[ni]) + bv[ni];
+              const int64_t o = row * p.ldc + wcol0 + ni * 32;
+              if constexpr (EPI == EPI_STORE) p.C[o] = v;
+              else if constexpr (EPI == EPI_GELU) p.C[o] = h3_gelu_erf(v);
+              else p.C[o] = p.resid[o] + v * gam[ni];
+            }
+        }
       }
   }
 }
 
-// fp32 row-major [rows, K] -> h2 image + inv[row] = 2^-e.  16 rows per block, wave w owns rows 4w..4w+3 with the row
-// in registers (NV float4 per lane); the scaled values go through a 16 x 256 LDS tile and are stored in image order.
+// ---- quantisers: rows held in registers (NV float4 per lane and row, 4 rows per wave, 16 rows per block) ----
+// scale / inverse scale of a row from its largest magnitude: amax * 2^e in [2^14, 2^15)
+__device__ __forceinline__ float h2_row_scale(float amax, float& inv) {
+  const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
+  inv = __uint_as_float((unsigned)(127 - e) << 23);
+  return __uint_as_float((unsigned)(127 + e) << 23);
+}
+
+// the scaled values of 16 rows go through a 16 x 256 LDS tile, chunk by chunk, and are stored in IMAGE order
+// (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
 template <int NV>
-__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
-                                                       unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R) {
-  constexpr int LDT = 256 + 4;
-  __shared__ __attribute__((aligned(16))) float tile[16][LDT];
+__device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[4][NV], const float (&scale)[4], float (*tile)[256 + 4],
+                                              int dim, int64_t row0, int64_t rows, unsigned char* out, int64_t R) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n4 = dim >> 2;
-  const int64_t row0 = (int64_t)blockIdx.x * 16;
-  f32x4 v[4][NV];
-  float scale[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ldx);
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < n4) {
-        v[q][i] = xr[idx];
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[q][i][0]), fabsf(v[q][i][1])), fmaxf(fabsf(v[q][i][2]), fabsf(v[q][i][3]))));
-      }
-    }
-    amax = wave_max(amax);
-    // 2^e with amax * 2^e in [2^14, 2^15): e = 14 - floor(log2(amax)) from the exponent field (amax = 0 -> scale 1)
-    const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
-    const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
-    scale[q] = __uint_as_float((unsigned)(127 + e) << 23);
-    if (lane == 0 && row0 + wave * 4 + q < rows) inv[row] = __uint_as_float((unsigned)(127 - e) << 23);
-  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
@@ -244,16 +271,94 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
   }
 }
 
+// fp32 row-major [rows, K] -> h2 image + inv[row] = 2^-e
+template <int NV>
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
+                                                       unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R) {
+  __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = dim >> 2;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  f32x4 v[4][NV];
+  float scale[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ldx);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < n4) {
+        v[q][i] = xr[idx];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[q][i][0]), fabsf(v[q][i][1])), fmaxf(fabsf(v[q][i][2]), fabsf(v[q][i][3]))));
+      }
+    }
+    float iv;
+    scale[q] = h2_row_scale(wave_max(amax), iv);
+    if (lane == 0 && row0 + wave * 4 + q < rows) inv[row] = iv;
+  }
+  h2_store_rows<NV>(v, scale, tile, dim, row0, rows, out, R);
+}
+
+// LayerNorm (torch semantics, biased variance) whose output is quantised straight into the h2 image
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int dim, int64_t rows, float eps,
+                                                           unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R) {
+  __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = dim >> 2;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  f32x4 v[4][NV];
+  float scale[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < n4) {
+        v[q][i] = xr[idx];
+        s += (v[q][i][0] + v[q][i][1]) + (v[q][i][2] + v[q][i][3]);
+      }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float qs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < n4) {
+        const float d0 = v[q][i][0] - mean, d1 = v[q][i][1] - mean, d2 = v[q][i][2] - mean, d3 = v[q][i][3] - mean;
+        qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < n4) {
+        const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[q][i][j] = (v[q][i][j] - mean) * rstd * wv[j] + bv[j];
+          amax = fmaxf(amax, fabsf(v[q][i][j]));
+        }
+      }
+    }
+    float iv;
+    scale[q] = h2_row_scale(wave_max(amax), iv);
+    if (lane == 0 && row0 + wave * 4 + q < rows) inv[row] = iv;
+  }
+  h2_store_rows<NV>(v, scale, tile, dim, row0, rows, out, R);
+}
+
 }  // namespace
 
-}  // namespace anyloc
+size_t h2_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 2 * (size_t)rows * 32; }
 
-using namespace anyloc;
-
-extern "C" size_t anyloc_h2_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 2 * (size_t)rows * 32; }
-
-extern "C" int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream) {
   ANYLOC_CHECK_ARG(x && h2 && inv_scale && rows > 0 && K > 0 && ldx >= K, "split_h2: bad arguments");
   ANYLOC_CHECK_ARG(K % 16 == 0 && K <= 4096 && ldx % 4 == 0, "split_h2: K must be a multiple of 16, at most 4096 (got %lld)",
                    (long long)K);
@@ -273,43 +378,95 @@ extern "C" int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_
   return launch_status("split_h2_kernel");
 }
 
-extern "C" int anyloc_gemm_nt_h3(const void* a2, const float* a_inv, const void* w2, const float* w_inv, const float* bias,
-                                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  ANYLOC_CHECK_ARG(a2 && a_inv && w2 && w_inv && C, "gemm_nt_h3: null operand");
-  ANYLOC_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 16 == 0 && ldc >= N, "gemm_nt_h3: bad shape");
-  ANYLOC_CHECK_ARG(anyloc_h2_bytes(M, K) < (1ull << 31) && anyloc_h2_bytes(N, K) < (1ull << 31),
-                   "gemm_nt_h3: operand image exceeds the 2 GiB buffer-addressing range");
-  H3Problem p{};
-  p.A2 = static_cast<const unsigned char*>(a2); p.RA = M; p.a_inv = a_inv;
-  p.W2 = static_cast<const unsigned char*>(w2); p.RW = N; p.w_inv = w_inv;
-  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K16 = (int)(K / 16); p.bias = bias;
+int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
+                 float* inv_scale, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(dim % 16 == 0 && dim <= 2048, "layernorm_h2: dim %d (needs a multiple of 16, at most 2048)", dim);
+  ProfScope prof("layernorm_h2", stream, 8.0 * rows * dim, 8.0 * rows * dim);
+  const dim3 grid((unsigned)((rows + 15) / 16));
+  unsigned char* out = static_cast<unsigned char*>(h2);
+  const int nv = (dim / 4 + 63) / 64;
+#define ANYLOC_LN_H2(NVV) \
+  hipLaunchKernelGGL(layernorm_h2_kernel<NVV>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, rows)
+  if (nv <= 1) ANYLOC_LN_H2(1);
+  else if (nv <= 2) ANYLOC_LN_H2(2);
+  else if (nv <= 3) ANYLOC_LN_H2(3);
+  else if (nv <= 4) ANYLOC_LN_H2(4);
+  else if (nv <= 6) ANYLOC_LN_H2(6);
+  else ANYLOC_LN_H2(8);
+#undef ANYLOC_LN_H2
+  return launch_status("layernorm_h2_kernel");
+}
+
+template <int EPI>
+int dispatch_h3(const H3Problem& p, hipStream_t stream) {
+  // ANYLOC_H3_CFG (micro-benchmarks): 0 = 128x256 tile, 3-deep ring (default; 128x128 when there are few tiles); 1 = 2-deep
   static int cfg = -1;
   if (cfg < 0) {
     const char* e = getenv("ANYLOC_H3_CFG");
     cfg = e ? atoi(e) : 0;
   }
-  ProfScope prof("gemm_h3", stream, 2.0 * M * N * K, 4.0 * (M + N) * K + 4.0 * M * N);
 #define ANYLOC_LAUNCH_H3(MI, NI, WM, WN, ST, OCC)                                                                     \
   do {                                                                                                                \
     using Cfg = H3Cfg<MI, NI, WM, WN, ST>;                                                                            \
-    const int tiles_m = (int)((M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((N + Cfg::BN - 1) / Cfg::BN);             \
+    const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);         \
     static bool attr_set = false;                                                                                     \
     if (!attr_set) {                                                                                                  \
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, OCC>),          \
+      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI>),     \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));                          \
       attr_set = true;                                                                                                \
     }                                                                                                                 \
-    hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, OCC>), dim3((unsigned)(tiles_m * tiles_n)),                 \
+    hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI>), dim3((unsigned)(tiles_m * tiles_n)),            \
                        dim3(64 * WM * WN), Cfg::LDS, stream, p, tiles_m, tiles_n);                                    \
   } while (0)
+  const bool small = ((p.M + 127) / 128) * ((p.N + 255) / 256) < 512;
+  if (small && cfg == 0) {
+    ANYLOC_LAUNCH_H3(2, 2, 2, 2, 3, 2);                     // few tiles: 128x128
+    return launch_status("gemm_h3_kernel");
+  }
   switch (cfg) {
-    case 1: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 2, 2); break;     // 128x256, 2-deep
-    case 2: ANYLOC_LAUNCH_H3(4, 2, 2, 4, 2, 1); break;     // 256x256, 8 waves, 2-deep
-    case 3: ANYLOC_LAUNCH_H3(4, 2, 2, 4, 3, 1); break;     // 256x256, 8 waves, 3-deep
-    case 4: ANYLOC_LAUNCH_H3(4, 4, 2, 2, 2, 1); break;     // 256x256, 4 waves of 128x128 (256 accumulator registers)
-    default: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 3, 2); break;    // 128x256, 3-deep ring
+    case 1: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 2, 2); break;
+    default: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 3, 2); break;
   }
 #undef ANYLOC_LAUNCH_H3
   return launch_status("gemm_h3_kernel");
+}
+
+int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(p.A2 && p.a_inv && p.W2 && p.w_inv && p.C, "gemm_h3: null operand");
+  ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K16 > 0 && p.RA >= p.M && p.RW >= p.N, "gemm_h3: bad shape");
+  ANYLOC_CHECK_ARG((size_t)p.K16 * 2 * (size_t)p.RA * 32 < (1ull << 31) && (size_t)p.K16 * 2 * (size_t)p.RW * 32 < (1ull << 31),
+                   "gemm_h3: operand image exceeds the 2 GiB buffer-addressing range");
+  const int64_t K = 16ll * p.K16;
+  ProfScope prof(p.tag ? p.tag : "gemm_h3", stream, 2.0 * p.M * p.N * K, 4.0 * (p.M + p.N) * K + 4.0 * p.M * p.N);
+  switch (epilogue) {
+    case EPI_STORE: return dispatch_h3<EPI_STORE>(p, stream);
+    case EPI_GELU: return dispatch_h3<EPI_GELU>(p, stream);
+    case EPI_LS_RESID:
+      ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_h3: LS_RESID needs gamma and resid");
+      return dispatch_h3<EPI_LS_RESID>(p, stream);
+    case EPI_SWIGLU:
+      ANYLOC_CHECK_ARG(p.N % 64 == 0, "gemm_h3: SWIGLU needs N %% 64 == 0");
+      return dispatch_h3<EPI_SWIGLU>(p, stream);
+    default: set_error("gemm_h3: unsupported epilogue %d", epilogue); return ANYLOC_ERR_INVALID_ARG;
+  }
+}
+
+}  // namespace anyloc
+
+using namespace anyloc;
+
+extern "C" size_t anyloc_h2_bytes(int64_t rows, int64_t K) { return h2_bytes(rows, K); }
+
+extern "C" int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, void* stream) {
+  return split_h2(x, ldx, rows, K, h2, inv_scale, (hipStream_t)stream);
+}
+
+extern "C" int anyloc_gemm_nt_h3(const void* a2, const float* a_inv, const void* w2, const float* w_inv, const float* bias,
+                                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+  ANYLOC_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 16 == 0 && ldc >= N, "gemm_nt_h3: bad shape");
+  H3Problem p{};
+  p.A2 = static_cast<const unsigned char*>(a2); p.RA = M; p.a_inv = a_inv;
+  p.W2 = static_cast<const unsigned char*>(w2); p.RW = N; p.w_inv = w_inv;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K16 = (int)(K / 16); p.bias = bias;
+  return gemm_h3(p, EPI_STORE, (hipStream_t)stream);
 }

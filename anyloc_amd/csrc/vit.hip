@@ -30,6 +30,7 @@ struct anyloc_vit {
   const float* cls;
   std::vector<anyloc_vit_block_weights> blocks;
   std::vector<anyloc_vit_block_x3> x3;      // optional: three-plane bf16 images of the four weight matrices
+  std::vector<anyloc_vit_block_h2> h2;      // optional: two-plane fp16 images + row scales of the same matrices
 };
 
 namespace anyloc {
@@ -39,6 +40,7 @@ struct VitWs {
   float *x, *y, *qkv, *h;   // qkv doubles as the im2col buffer; attention output aliases y
   unsigned char* a3;        // split-bf16 mode: plane image of a D-wide activation operand (LN output, attention output)
   unsigned char* h3;        //                  plane image of the FFN hidden activation
+  float *ainv, *hinv;       // fp16 mode: 2^-e per row of the images in a3 / h3
   size_t bytes;
 };
 
@@ -53,6 +55,8 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   w.h = a.take<float>(M * c.ffn_hidden);
   w.a3 = a.take<unsigned char>(x3_bytes(M, c.dim));
   w.h3 = a.take<unsigned char>(x3_bytes(M, c.ffn_hidden));
+  w.ainv = a.take<float>(M);
+  w.hinv = a.take<float>(M);
   w.bytes = a.off;
   return w;
 }
@@ -101,6 +105,25 @@ int linear_x6(const float* A, int64_t K, unsigned char* a3, const void* w3, int6
   g.resid = C;
   g.tag = tag;
   return gemm_x6(g, epi, stream);
+}
+
+// the same linear layer on the row-scaled two-term fp16 GEMM (gemm_h3.hip).  A == nullptr: a2 / ainv already hold the
+// quantised operand (written by layernorm_h2); otherwise A (fp32, row-major, width K) is quantised here first.
+int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const void* w2, const float* winv, int64_t w_rows,
+              int64_t w_row0, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
+              const char* tag, hipStream_t stream) {
+  if (A) ANYLOC_TRY(split_h2(A, K, M, K, a2, ainv, stream));
+  H3Problem g{};
+  g.A2 = a2; g.RA = M; g.a_inv = ainv;
+  g.W2 = static_cast<const unsigned char*>(w2) + w_row0 * 32; g.RW = w_rows; g.w_inv = winv + w_row0;
+  g.w_off = w_row0 * 32;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K16 = (int)(K / 16);
+  g.bias = bias;
+  g.gamma = gamma;
+  g.resid = C;
+  g.tag = tag;
+  return gemm_h3(g, epi, stream);
 }
 
 }  // namespace
@@ -165,6 +188,23 @@ int anyloc_vit_attach_x3(anyloc_vit_t* h, const anyloc_vit_block_x3* blocks) {
   return ANYLOC_OK;
 }
 
+int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
+  ANYLOC_CHECK_ARG(h, "vit_attach_h2: null handle");
+  if (!blocks) {
+    h->h2.clear();
+    return ANYLOC_OK;
+  }
+  ANYLOC_CHECK_ARG(h->cfg.dim % 16 == 0 && h->cfg.ffn_hidden % 16 == 0 && h->cfg.ffn_hidden <= 4096 && h->cfg.dim <= 2048,
+                   "vit_attach_h2: dim %d / ffn_hidden %d outside the fp16 path's limits", h->cfg.dim, h->cfg.ffn_hidden);
+  for (int i = 0; i < h->cfg.depth; ++i) {
+    const anyloc_vit_block_h2& b = blocks[i];
+    ANYLOC_CHECK_ARG(b.qkv_w2 && b.qkv_inv && b.proj_w2 && b.proj_inv && b.fc1_w2 && b.fc1_inv && b.fc2_w2 && b.fc2_inv,
+                     "vit_attach_h2: block %d has a null image or scale array", i);
+  }
+  h->h2.assign(blocks, blocks + h->cfg.depth);
+  return ANYLOC_OK;
+}
+
 void anyloc_vit_destroy(anyloc_vit_t* h) { delete h; }
 
 size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch, int64_t img_h, int64_t img_w) {
@@ -201,7 +241,10 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
   // below ~3 images of 530 tokens the GEMMs have too few 128-row tiles to fill 256 CUs twice over: the fp32-MFMA
   // kernel with its 64-row split is faster there (measured B=1: 60 vs 40 images/s), so the split-bf16 request is
   // honoured from x6_min_rows() rows up (ANYLOC_X6_MIN_ROWS overrides)
-  const bool x6 = (flags & ANYLOC_VIT_SPLIT_BF16) && M >= x6_min_rows();
+  ANYLOC_CHECK_ARG(!(flags & ANYLOC_VIT_SPLIT_FP16) || !h->h2.empty(),
+                   "vit_forward: ANYLOC_VIT_SPLIT_FP16 without anyloc_vit_attach_h2");
+  const bool h3m = (flags & ANYLOC_VIT_SPLIT_FP16) && M >= x6_min_rows();
+  const bool x6 = !h3m && (flags & ANYLOC_VIT_SPLIT_BF16) && M >= x6_min_rows();
   const bool fuse_x6 = x6 && x6_fused();
   const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
   const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;
@@ -235,7 +278,8 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
     const bool last = (l == last_layer);
     // split-bf16 mode, fused producers: LayerNorm / attention / FFN activation write plane images directly
     const bool fuse = fuse_x6;
-    if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, stream));
+    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, w.ainv, stream));
+    else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm1_w, b.norm1_b, M, D, 1e-6f, stream));
     const float* y_in = fuse ? nullptr : w.y;     // nullptr: the plane image is already in w.a3
     if (last && !last_needs_full) {
@@ -243,7 +287,10 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       for (int t = 0; t < n_taps; ++t) {
         if (tap_layers[t] != l) continue;
         const int f = tap_facets[t];
-        if (x6)
+        if (h3m)
+          ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, (int64_t)f * D,
+                               b.qkv_b + (int64_t)f * D, w.qkv, D, M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream));
+        else if (x6)
           ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, (int64_t)f * D, b.qkv_b + (int64_t)f * D, w.qkv, D,
                                M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream));
         else
@@ -254,7 +301,10 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       }
       break;
     }
-    if (x6)
+    if (h3m)
+      ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M,
+                           3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
+    else if (x6)
       ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr,
                            "vit_qkv_gemm", stream));
     else
@@ -263,16 +313,29 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
         ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
                               norm_taps, 1e-12f, stream));
-    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr, x6));
-    if (x6)
+    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr, x6 || h3m));
+    if (h3m)     // the attention output is fp32: its rows span all heads, the row maximum is only known now
+      ANYLOC_TRY(linear_h3(w.y, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
+                           EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
+    else if (x6)
       ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
                            "vit_proj_gemm", stream));
     else
       ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
-    if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
+    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream));
+    else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
-    if (x6) {
+    if (h3m) {
+      if (c.ffn_kind == 0)
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, w.h, Hh, M, Hh,
+                             EPI_GELU, nullptr, "vit_fc1_gemm", stream));
+      else
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0, b.fc1_b, w.h, Hh, M,
+                             2 * Hh, EPI_SWIGLU, nullptr, "vit_w12_gemm", stream));
+      ANYLOC_TRY(linear_h3(w.h, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
+                           EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
+    } else if (x6) {
       unsigned char* c3 = fuse ? w.h3 : nullptr;
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].fc1_w3, Hh, 0, b.fc1_b, w.h, Hh, M, Hh, EPI_GELU, nullptr,

@@ -20,6 +20,7 @@ from torch.nn import functional as F
 from . import _lib, ops, weights
 from .synth import ARCH, PATCH, POS_GRID
 
+DEFAULT_GEMM = "x6"      # block-GEMM arithmetic when neither the constructor nor ANYLOC_GEMM says otherwise
 _DINO_V2_MODELS = ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14", "dinov2_vitg14")
 _DINO_FACETS = ("query", "key", "value", "token")
 INTERP_OFFSET = 0.1
@@ -51,12 +52,12 @@ class HipDinoV2:
     """Device-resident DINOv2 weights + the C handle of the HIP forward."""
 
     def __init__(self, name, state_dict, device, max_layer=None, gemm=None):
-        """``gemm``: "x6" (default) runs the block GEMMs as six bf16 MFMA products of exact three-way bf16 splits
-        (fp32-level accuracy, csrc/gemm_x6.hip); "f32" keeps them on the fp32 MFMA kernel.  Env ANYLOC_GEMM
-        overrides the default."""
-        self.gemm = gemm or os.environ.get("ANYLOC_GEMM", "x6")
-        if self.gemm not in ("x6", "f32"):
-            raise ValueError(f"gemm mode must be 'x6' or 'f32', got {self.gemm!r}")
+        """``gemm``: "x6" runs the block GEMMs as six bf16 MFMA products of exact three-way bf16 splits
+        (csrc/gemm_x6.hip); "h3" as three fp16 MFMA products of row-scaled two-term fp16 splits (csrc/gemm_h3.hip);
+        both have fp32-level accuracy; "f32" keeps them on the fp32 MFMA kernel.  Env ANYLOC_GEMM sets the default."""
+        self.gemm = gemm or os.environ.get("ANYLOC_GEMM", DEFAULT_GEMM)
+        if self.gemm not in ("x6", "h3", "f32"):
+            raise ValueError(f"gemm mode must be 'x6', 'h3' or 'f32', got {self.gemm!r}")
         dim, depth, heads, ffn, hidden = ARCH[name]
         have = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         depth = min(depth, have)
@@ -81,6 +82,7 @@ class HipDinoV2:
             if "norm.weight" in state_dict else None
         blocks = (_lib.VitBlockWeights * depth)()
         x3 = (_lib.VitBlockX3 * depth)()
+        h2 = (_lib.VitBlockH2 * depth)()
         for i in range(depth):
             p = f"blocks.{i}."
             if self.ffn_kind == 0:
@@ -109,6 +111,12 @@ class HipDinoV2:
                     img3 = ops.split_x3(dev(vals[f]))
                     self._keep.append(img3)
                     setattr(x3[i], f3, img3.data_ptr())
+            if self.gemm == "h3":
+                for f in ("qkv", "proj", "fc1", "fc2"):
+                    img2, inv = ops.split_h2(dev(vals[f + "_w"]))
+                    self._keep += [img2, inv]
+                    setattr(h2[i], f + "_w2", img2.data_ptr())
+                    setattr(h2[i], f + "_inv", inv.data_ptr())
         cfg = _lib.VitConfig(dim, depth, heads, self.ffn_kind, hidden, PATCH, 3 * PATCH * PATCH)
         self._handle = C.c_void_p()
         lib = _lib.load()
@@ -116,6 +124,8 @@ class HipDinoV2:
                                          _lib.ptr(patch_b), _lib.ptr(cls), blocks), "anyloc_vit_create")
         if self.gemm == "x6":
             _lib.check(lib.anyloc_vit_attach_x3(self._handle, x3), "anyloc_vit_attach_x3")
+        if self.gemm == "h3":
+            _lib.check(lib.anyloc_vit_attach_h2(self._handle, h2), "anyloc_vit_attach_h2")
         # the plane image of one activation operand must stay inside 2 GiB of buffer addressing
         self.max_rows = (2 ** 31 - 1) // (6 * max(dim, hidden)) - 512
 
@@ -172,7 +182,7 @@ class HipDinoV2:
         if B == 0:
             return out
         chunk = max(1, self.max_rows // (np_ + 1))
-        if self.gemm == "x6" and B > chunk:
+        if self.gemm in ("x6", "h3") and B > chunk:
             for s0 in range(0, B, chunk):
                 out[s0:s0 + chunk] = self.forward_taps(img[s0:s0 + chunk], taps, use_cls, norm_taps, norm_concat)
             return out
@@ -182,7 +192,8 @@ class HipDinoV2:
         layers = (C.c_int32 * n_taps)(*[t[0] for t in taps])
         facets = (C.c_int32 * n_taps)(*[ops.FACETS[t[1]] for t in taps])
         flags = (ops.VIT_USE_CLS if use_cls else 0) | (ops.VIT_NORM_TAPS if norm_taps else 0) | \
-            (ops.VIT_NORM_CONCAT if norm_concat else 0) | (ops.VIT_SPLIT_BF16 if self.gemm == "x6" else 0)
+            (ops.VIT_NORM_CONCAT if norm_concat else 0) | (ops.VIT_SPLIT_BF16 if self.gemm == "x6" else 0) | \
+            (ops.VIT_SPLIT_FP16 if self.gemm == "h3" else 0)
         _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
                                           n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
                                           ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")

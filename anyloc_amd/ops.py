@@ -13,7 +13,7 @@ from . import _lib
 VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
 FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
-VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16 = 1, 2, 4, 8
+VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1, 2, 4, 8, 16
 
 
 def _f32c(t, device=None):
@@ -81,7 +81,7 @@ def gemm_nt_x6(a3, w3, M, N, K, bias=None):
 
 
 def split_h2(x):
-    """EXPERIMENTAL: fp32 [rows, K] -> (two-plane fp16 image, inv_scale[rows]) for gemm_nt_h3."""
+    """fp32 [rows, K] -> (two-plane fp16 image, inv_scale[rows]) for gemm_nt_h3 (rows scaled into [2^14, 2^15))."""
     _need_cuda(x)
     x = _f32c(x)
     rows, K = x.shape
@@ -94,7 +94,7 @@ def split_h2(x):
 
 
 def gemm_nt_h3(a2, w2, M, N, K, bias=None):
-    """EXPERIMENTAL: C[M,N] = A W^T (+ bias) from split_h2 images (three fp16 matrix-core products per k-step)."""
+    """C[M,N] = A W^T (+ bias) from split_h2 images (three fp16 matrix-core products per k-step)."""
     (a_img, a_inv), (w_img, w_inv) = a2, w2
     out = torch.empty(M, N, dtype=torch.float32, device=a_img.device)
     _lib.check(_lib.load().anyloc_gemm_nt_h3(_lib.ptr(a_img), _lib.ptr(a_inv), _lib.ptr(w_img), _lib.ptr(w_inv),

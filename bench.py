@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from anyloc_amd import _lib, ops, retrieval, synth, weights  # noqa: E402
+from anyloc_amd.extractor import DEFAULT_GEMM  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16)
@@ -69,7 +70,7 @@ def main():
     # within 1.2 % of whole multiples of the 512 resident thread blocks (2 per CU) -- no tail wave
     ap.add_argument("--batch", type=int, default=61, help="query images per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm", choices=["x6", "f32"], default=os.environ.get("ANYLOC_GEMM", "x6"),
+    ap.add_argument("--gemm", choices=["x6", "h3", "f32"], default=os.environ.get("ANYLOC_GEMM", DEFAULT_GEMM),
                     help="block GEMMs: x6 = exact 3-way bf16 split, six bf16 MFMA products, fp32 accumulate "
                          "(fp32-level accuracy); f32 = fp32 MFMA")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
@@ -194,19 +195,21 @@ def main():
     gemm_ms = sum(v["ms"] for k, v in prof.items() if k.endswith("_gemm"))
     gemm_fl = sum(v["flops"] for k, v in prof.items() if k.endswith("_gemm"))
     kern_ms = sum(v["ms"] for v in prof.values())
-    x6 = args.gemm == "x6" and dom_name.endswith("_gemm") and dom_name != "vit_patch_embed_gemm"
-    # x6: every algorithmic flop costs six bf16-MFMA flops, so the roofline of the fp32-accurate contraction is
-    # the dense bf16 peak / 6; `achieved` stays ALGORITHMIC flops / time in both modes.
-    peak = PEAK_BF16_MFMA_TFLOPS / X6_PRODUCTS if x6 else PEAK_FP32_MFMA_TFLOPS
+    products = {"x6": 6, "h3": 3}.get(args.gemm)      # matrix-core products per fp32-accurate product
+    x6 = products is not None and dom_name.endswith("_gemm") and dom_name != "vit_patch_embed_gemm"
+    # split modes: every algorithmic flop costs `products` bf16/fp16-MFMA flops, so the roofline of the fp32-accurate
+    # contraction is the dense 16-bit peak / products; `achieved` stays ALGORITHMIC flops / time in every mode.
+    peak = PEAK_BF16_MFMA_TFLOPS / products if x6 else PEAK_FP32_MFMA_TFLOPS
     all_gemm = gemm_fl / (gemm_ms * 1e-3) / 1e12
     e2e = value / world * flops_per_image() / 1e12
     roofline = {
         "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
         "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "peak_note": ("dense bf16 MFMA peak 2500 / 6 products per fp32-accurate product (exact 3-way bf16 split)"
+        "peak_note": ((f"dense 16-bit MFMA peak 2500 / {products} matrix-core products per fp32-accurate product (" +
+                       ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
                       if x6 else "fp32 MFMA peak"),
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "clock_note": ("profiles/r01_pmc_x6.md: under this kernel the chip runs 1.65 GHz (power limit) with the "
+        "clock_note": ("profiles/r01_pmc_x6.md: under the split-bf16 GEMM the chip runs 1.65 GHz (power limit) with the "
                        "matrix cores busy 83.6 % of SIMD cycles; `peak` is the nominal 2.4 GHz figure") if x6 else None,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"], "traffic": None,
         "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
@@ -224,8 +227,10 @@ def main():
         "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm,
         "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f32 (GEMM operands as exact 3-way bf16 splits, 6 bf16 MFMA products, fp32 accumulate)"
-                  if args.gemm == "x6" else "f32"), "data": "synthetic",
+        "dtype": {"x6": "f32 (GEMM operands as exact 3-way bf16 splits, 6 bf16 MFMA products, fp32 accumulate)",
+                  "h3": "f32 (GEMM operands as row-scaled 2-term fp16 splits, 3 fp16 MFMA products, fp32 accumulate; "
+                        "attention on 3-way bf16 splits)",
+                  "f32": "f32"}[args.gemm], "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: DINOv2 ViT-G/14 layer31 'value' K=32 VLAD, "
                                "322x322, top-20 vs 10k-row database per GPU", "batch_per_gpu": B, "gemm": args.gemm,
                    "images_per_step": B * world, "db_rows_per_gpu": N_DB, "vlad_dim": K_CLUSTERS * 1536,

@@ -79,11 +79,11 @@ int anyloc_split_x3(const float* x, int64_t ldx, int64_t rows, int64_t K, void* 
 int anyloc_gemm_nt_x6(const void* a3, const void* w3, const float* bias, float* C,
                       int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
 
-/* ------------------------------------- EXPERIMENTAL: fp16 two-term matmul ----
+/* ------------------------------------------------ fp16 two-term matmul ----
  * Same contraction with THREE fp16 matrix-core products per k-step: every operand
  * row is scaled by a power of two into [2^14, 2^15) and split into two fp16 planes
  * (22 mantissa bits); the epilogue descales with inv_a[row] * inv_w[col]
- * (csrc/gemm_h3.hip, tools/split_fp16_study.py).  Not used by anyloc_vit_forward.
+ * (csrc/gemm_h3.hip, tools/split_fp16_study.py).
  *   anyloc_split_h2    fp32 [rows, K] (K % 16 == 0) -> plane image + inv_scale[rows]
  *   anyloc_gemm_nt_h3  C[M,N] = A W^T (+ bias[N]) from the two images */
 size_t anyloc_h2_bytes(int64_t rows, int64_t K);
@@ -244,6 +244,19 @@ typedef struct anyloc_vit_block_x3 {
 } anyloc_vit_block_x3;
 int anyloc_vit_attach_x3(anyloc_vit_t* h, const anyloc_vit_block_x3* blocks /*host array [depth]*/);
 #define ANYLOC_VIT_SPLIT_BF16 8u     /* block GEMMs on the bf16 matrix cores, fp32-level accuracy */
+
+/* Two-term fp16 execution of the block GEMMs (csrc/gemm_h3.hip: three fp16 matrix-core
+ * products per k-step, row-scaled operands): attach anyloc_split_h2 images + row scales
+ * of the same four matrices and pass ANYLOC_VIT_SPLIT_FP16 (takes precedence over
+ * ANYLOC_VIT_SPLIT_BF16).  blocks == NULL detaches. */
+typedef struct anyloc_vit_block_h2 {
+  const void* qkv_w2;  const float* qkv_inv;
+  const void* proj_w2; const float* proj_inv;
+  const void* fc1_w2;  const float* fc1_inv;
+  const void* fc2_w2;  const float* fc2_inv;
+} anyloc_vit_block_h2;
+int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*host array [depth]*/);
+#define ANYLOC_VIT_SPLIT_FP16 16u    /* block GEMMs as three fp16 products, fp32-level accuracy */
 
 #define ANYLOC_VIT_USE_CLS 1u        /* keep the CLS row (utilities.py:270-273) */
 #define ANYLOC_VIT_NORM_TAPS 2u      /* L2-normalise each tap (utilities.py:282-283) */

@@ -61,6 +61,54 @@ def test_gemm_x6_as_accurate_as_fp32(M, N, K, with_bias):
         assert err < 1.5 * e32 + 1e-7, (err, e32)                          # no worse than the fp32-MFMA kernel
 
 
+def h2_planes_from_image(img2, rows, K):
+    """Inverse of the h2 layout (csrc/gemm_h3.hip): [kb][plane][row][16] fp16 with the x3 half swap -> [2, rows, K]."""
+    k16 = K // 16
+    t = img2.view(torch.float16).reshape(k16, 2, rows, 2, 8).clone()
+    odd = ((torch.arange(rows, device=img2.device) >> 3) & 1).bool()
+    t[:, :, odd] = t[:, :, odd].flip(3)
+    return t.permute(1, 2, 0, 3, 4).reshape(2, rows, K).float()
+
+
+@pytest.mark.parametrize("shape", [(128, 16), (300, 96), (1000, 384), (77, 1536), (33, 4096)])
+def test_split_h2_row_scaling_and_precision(shape):
+    from anyloc_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(*shape, generator=g, device=DEV) * torch.exp(3 * torch.randn(shape[0], 1, generator=g, device=DEV))
+    x[:, ::7] *= 40.0                                                       # heavy-tailed columns in every row
+    x[5] = 0.0                                                              # an all-zero row
+    img, inv = ops.split_h2(x)
+    p = h2_planes_from_image(img, *shape)
+    amax = x.abs().amax(dim=1)
+    scaled = amax / inv                                                     # amax * 2^e
+    ok = amax > 0
+    assert bool(((scaled[ok] >= 2.0 ** 14) & (scaled[ok] < 2.0 ** 15)).all())
+    assert bool((torch.log2(inv) == torch.log2(inv).round()).all())         # powers of two
+    assert float(p.abs().max()) < 65504.0
+    back = (p[0].double() + p[1].double()) * inv.double()[:, None]
+    err = (back - x.double()).abs().amax(dim=1)
+    assert float((err / amax.clamp_min(1e-30)).max()) < 2.0 ** -22         # 22 bits relative to the row maximum
+    assert float(back[5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 48), (130, 515, 112), (2051, 1536, 1536), (64, 4608, 1536),
+                                   (4096, 1536, 4096)])
+def test_gemm_h3_as_accurate_as_fp32(M, N, K):
+    from anyloc_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device=DEV) * (0.25 + torch.rand(M, 1, generator=g, device=DEV))
+    a[:, ::53] *= 30.0
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    bias = torch.randn(N, generator=g, device=DEV)
+    c = ops.gemm_nt_h3(ops.split_h2(a), ops.split_h2(w), M, N, K, bias)
+    ref = a.double() @ w.double().t() + bias.double()
+    mag = a.double().abs() @ w.double().abs().t() + bias.double().abs()
+    err = float(((c.double() - ref).abs() / mag).max())
+    e32 = float(((ops.gemm_nt(a, w, bias).double() - ref).abs() / mag).max())
+    assert err < 1.5 * e32 + 1e-7, (err, e32)
+    assert torch.equal(c, ops.gemm_nt_h3(ops.split_h2(a), ops.split_h2(w), M, N, K, bias))
+
+
 def test_gemm_x6_deterministic_and_tail_rows_untouched():
     from anyloc_amd import ops
     g = torch.Generator(device=DEV).manual_seed(3)
@@ -82,14 +130,16 @@ def test_vit_tokens_agree_between_gemm_modes(monkeypatch, name, layer, depth):
     try:
         imgs = torch.cat(synth.synthetic_places(3, 1, 224, 224, seed=5)[:2]).to(DEV)
         out = {}
-        for mode in ("x6", "f32"):
+        for mode in ("x6", "h3", "f32"):
             monkeypatch.setenv("ANYLOC_GEMM", mode)
             ext = utilities.DinoV2ExtractFeatures(name, layer, "value", device=DEV)
             assert ext.dino_model.gemm == mode
             out[mode] = ext(imgs)
             out[mode + "_tok"] = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, device=DEV)(imgs)
-        assert float((out["x6"] - out["f32"]).abs().max()) < 2e-6          # unit-norm rows
-        assert float((out["x6_tok"] - out["f32_tok"]).abs().max()) < 2e-6
+        for mode in ("x6", "h3"):
+            assert float((out[mode] - out["f32"]).abs().max()) < 2e-6, mode          # unit-norm rows
+            assert float((out[mode + "_tok"] - out["f32_tok"]).abs().max()) < 2e-6, mode
+        assert not torch.equal(out["h3"], out["x6"])                       # really different kernels
     finally:
         weights.unregister_state_dict()
 
@@ -129,7 +179,7 @@ def test_golden_tokens_in_fp32_mfma_mode(monkeypatch, golden_dir):
     try:
         db, qu, _ = synth.synthetic_places(int(g1["n_db"]), int(g1["n_qu"]), int(g1["hw"]), int(g1["hw"]),
                                            seed=int(g1["images_seed"]))
-        for mode in ("f32", "x6"):
+        for mode in ("f32", "x6", "h3"):
             monkeypatch.setenv("ANYLOC_GEMM", mode)
             ext = utilities.DinoV2ExtractFeatures(name, 9, "value", device=DEV)
             one = ext(db[:1].to(DEV))
