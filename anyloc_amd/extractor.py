@@ -20,7 +20,7 @@ from torch.nn import functional as F
 from . import _lib, ops, weights
 from .synth import ARCH, PATCH, POS_GRID
 
-DEFAULT_GEMM = "x6"      # block-GEMM arithmetic when neither the constructor nor ANYLOC_GEMM says otherwise
+DEFAULT_GEMM = "h3"      # block-GEMM arithmetic when neither the constructor nor ANYLOC_GEMM says otherwise
 _DINO_V2_MODELS = ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14", "dinov2_vitg14")
 _DINO_FACETS = ("query", "key", "value", "token")
 INTERP_OFFSET = 0.1

@@ -17,6 +17,9 @@ for _ in range(6):
     ops.gemm_nt_x6(a3, w3, M, N, K)
 for _ in range(3):
     ops.gemm_nt(a, w)
+a2, w2 = ops.split_h2(a), ops.split_h2(w)
+for _ in range(6):
+    ops.gemm_nt_h3(a2, w2, M, N, K)
 torch.cuda.synchronize()
 qkv = torch.randn(61, 530, 3 * 1536, device=dev)
 for mode in ("1", "0"):
