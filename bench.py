@@ -209,8 +209,9 @@ def main():
                        ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
                       if x6 else "fp32 MFMA peak"),
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "clock_note": ("profiles/r01_pmc_x6.md: under the split-bf16 GEMM the chip runs 1.65 GHz (power limit) with the "
-                       "matrix cores busy 83.6 % of SIMD cycles; `peak` is the nominal 2.4 GHz figure") if x6 else None,
+        "clock_note": ("profiles/r01_pmc_x6.md: under these GEMMs the chip runs at its power limit (1.63 GHz with the matrix "
+                       "cores busy 70.9 % of SIMD cycles for h3; 1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz "
+                       "figure") if x6 else None,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"], "traffic": None,
         "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
                       "vs_fp32_mfma_peak": round(all_gemm / PEAK_FP32_MFMA_TFLOPS, 4),
