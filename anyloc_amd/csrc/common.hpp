@@ -150,6 +150,7 @@ struct H3Problem {
   const float* bias;
   const float* gamma;                       // EPI_LS_RESID
   const float* resid;                       // EPI_LS_RESID, leading dim ldc
+  int epi_lds;                              // EPI_LS_RESID: transposed 16-byte epilogue through LDS (set by gemm_h3)
   const char* tag;
 };
 size_t h2_bytes(int64_t rows, int64_t K);

@@ -148,6 +148,55 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   // ---- epilogue: acc * 2^-(e_row + e_col), then the same fused forms as gemm_x6.hip / gemm_f32.hip ----
   const int64_t wrow0 = m0 + wm * 32 * MI + 4 * (lane >> 5);
   const int64_t wcol0 = n0 + wn * 32 * NI + (lane & 31);
+  if constexpr (EPI == EPI_LS_RESID) {
+    if (p.epi_lds) {
+      // x += gamma * (acc * 2^-(e_row+e_col) + bias) with 16-byte global accesses: the C/D layout gives a lane one
+      // column of 16 rows (dword read-modify-write, 64 + 64 memory instructions per 32x64 block pair); instead each
+      // wave transposes 32 x 64 sub-blocks through its own 8.5 KiB of the (now idle) LDS ring and every lane handles
+      // four consecutive columns of a row: 8 + 8 memory instructions per sub-block.
+      __builtin_amdgcn_s_barrier();                       // nobody reads fragments from the ring any more
+      float* st = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+      const int lr0 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        float ai[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+          ai[r] = row < p.M ? p.a_inv[row] : 0.0f;
+        }
+#pragma unroll
+        for (int np = 0; np < NI / 2; ++np) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int ni = 2 * np + nb;
+            const int64_t col = wcol0 + ni * 32;
+            const bool cok = col < p.N;
+            const float bv = (cok && p.bias) ? p.bias[col] : 0.0f;
+            const float sw_ = cok ? p.w_inv[col] : 0.0f, gam = cok ? p.gamma[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 68 + nb * 32 + (lane & 31)] =
+                  (acc[mi][ni][r] * (ai[r] * sw_) + bv) * gam;
+          }
+          const int64_t colb = n0 + wn * 32 * NI + np * 64 + c4;
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int lr = it * 4 + lr0;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&st[lr * 68 + c4]);
+            const int64_t row = m0 + wm * 32 * MI + mi * 32 + lr;
+            if (row < p.M && colb < p.N) {
+              const int64_t o = row * p.ldc + colb;
+              f32x4 x4 = *reinterpret_cast<const f32x4*>(&p.resid[o]);
+              x4[0] += t[0]; x4[1] += t[1]; x4[2] += t[2]; x4[3] += t[3];
+              *reinterpret_cast<f32x4*>(&p.C[o]) = x4;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_SWIGLU) {
     float bg[NI / 2], bv[NI / 2], sg[NI / 2], sv[NI / 2];
     bool cok[NI / 2];
@@ -221,10 +270,46 @@ __device__ __forceinline__ float h2_row_scale(float amax, float& inv) {
 
 // the scaled values of 16 rows go through a 16 x 256 LDS tile, chunk by chunk, and are stored in IMAGE order
 // (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
+// store chunk i (256 columns) of 16 rows, already scaled and sitting in the LDS tile, in IMAGE order
+// (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
+__device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, int dim, int64_t row0, int64_t rows,
+                                               unsigned char* out, int64_t R) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = tid + 256 * u;
+    const int kbl = item >> 5, r = (item >> 1) & 15, half = item & 1;
+    const int k0 = 256 * i + 16 * kbl + 8 * half;
+    const int64_t row = row0 + r;
+    if (k0 < dim && row < rows) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
+      hu32x4 ph, plo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 pr;
+        pr[0] = j < 2 ? lo[2 * j] : hi[2 * j - 4];
+        pr[1] = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
+        const f16x2 h = __builtin_convertvector(pr, f16x2);
+        f32x2 res;
+        res[0] = pr[0] - (float)h[0];
+        res[1] = pr[1] - (float)h[1];
+        const f16x2 l = __builtin_convertvector(res, f16x2);
+        ph[j] = __builtin_bit_cast(unsigned, h);
+        plo[j] = __builtin_bit_cast(unsigned, l);
+      }
+      unsigned char* dst = out + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4);
+      *reinterpret_cast<hu32x4*>(dst) = ph;
+      *reinterpret_cast<hu32x4*>(dst + R * 32) = plo;
+    }
+  }
+}
+
+// rows held in registers: the scaled values of 16 rows go through the LDS tile chunk by chunk
 template <int NV>
 __device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[4][NV], const float (&scale)[4], float (*tile)[256 + 4],
                                               int dim, int64_t row0, int64_t rows, unsigned char* out, int64_t R) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n4 = dim >> 2;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -240,34 +325,48 @@ __device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[4][NV], const flo
       }
     }
     __syncthreads();
+    h2_store_chunk(tile, i, dim, row0, rows, out, R);
+  }
+}
+
+// wide rows (K > 2048): two passes over the row instead of holding it in registers -- pass 1 finds the maximum,
+// pass 2 re-reads the 16 rows (L2-resident: 16 x 4 K floats) and quantises; 8x the occupancy of the register version
+__global__ __launch_bounds__(256) void split_h2_stream_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
+                                                              unsigned char* __restrict__ out, float* __restrict__ inv,
+                                                              int64_t R) {
+  __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = dim >> 2;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const f32x4* xr[4];
+  float scale[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int item = tid + 256 * u;
-      const int kbl = item >> 5, r = (item >> 1) & 15, half = item & 1;
-      const int k0 = 256 * i + 16 * kbl + 8 * half;
-      const int64_t row = row0 + r;
-      if (k0 < dim && row < rows) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
-        hu32x4 ph, plo;
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
+    xr[q] = reinterpret_cast<const f32x4*>(x + row * ldx);
+    float amax = 0.f;
+    for (int idx = lane; idx < n4; idx += 64) {
+      const f32x4 t = xr[q][idx];
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))));
+    }
+    float iv;
+    scale[q] = h2_row_scale(wave_max(amax), iv);
+    if (lane == 0 && row0 + wave * 4 + q < rows) inv[row] = iv;
+  }
+  const int nchunks = (dim + 255) / 256;
+  for (int i = 0; i < nchunks; ++i) {
+    const int idx = lane + 64 * i;
+    if (i > 0) __syncthreads();
+    if (idx < n4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x2 pr;
-          pr[0] = j < 2 ? lo[2 * j] : hi[2 * j - 4];
-          pr[1] = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
-          const f16x2 h = __builtin_convertvector(pr, f16x2);
-          f32x2 res;
-          res[0] = pr[0] - (float)h[0];
-          res[1] = pr[1] - (float)h[1];
-          const f16x2 l = __builtin_convertvector(res, f16x2);
-          ph[j] = __builtin_bit_cast(unsigned, h);
-          plo[j] = __builtin_bit_cast(unsigned, l);
-        }
-        unsigned char* dst = out + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4);
-        *reinterpret_cast<hu32x4*>(dst) = ph;
-        *reinterpret_cast<hu32x4*>(dst + R * 32) = plo;
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o = xr[q][idx];
+        o[0] *= scale[q]; o[1] *= scale[q]; o[2] *= scale[q]; o[3] *= scale[q];
+        *reinterpret_cast<f32x4*>(&tile[wave * 4 + q][4 * lane]) = o;
       }
     }
+    __syncthreads();
+    h2_store_chunk(tile, i, dim, row0, rows, out, R);
   }
 }
 
@@ -368,12 +467,14 @@ int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, flo
   const int nv = (int)((K / 4 + 63) / 64);
 #define ANYLOC_SPLIT_H2(NVV) \
   hipLaunchKernelGGL(split_h2_kernel<NVV>, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, out, inv_scale, rows)
+  const char* force_reg = getenv("ANYLOC_H2_REG");          // A/B switch: rows in registers at every width
   if (nv <= 1) ANYLOC_SPLIT_H2(1);
   else if (nv <= 2) ANYLOC_SPLIT_H2(2);
   else if (nv <= 4) ANYLOC_SPLIT_H2(4);
   else if (nv <= 6) ANYLOC_SPLIT_H2(6);
   else if (nv <= 8) ANYLOC_SPLIT_H2(8);
-  else ANYLOC_SPLIT_H2(16);
+  else if (force_reg && atoi(force_reg) == 1) ANYLOC_SPLIT_H2(16);
+  else hipLaunchKernelGGL(split_h2_stream_kernel, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, out, inv_scale, rows);
 #undef ANYLOC_SPLIT_H2
   return launch_status("split_h2_kernel");
 }
@@ -441,9 +542,14 @@ int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream) {
   switch (epilogue) {
     case EPI_STORE: return dispatch_h3<EPI_STORE>(p, stream);
     case EPI_GELU: return dispatch_h3<EPI_GELU>(p, stream);
-    case EPI_LS_RESID:
+    case EPI_LS_RESID: {
       ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_h3: LS_RESID needs gamma and resid");
-      return dispatch_h3<EPI_LS_RESID>(p, stream);
+      H3Problem q = p;
+      const char* e = getenv("ANYLOC_H3_EPI_LDS");          // A/B switch: 0 = dword read-modify-write epilogue
+      q.epi_lds = !(e && atoi(e) == 0) && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
+      return dispatch_h3<EPI_LS_RESID>(q, stream);
+    }
     case EPI_SWIGLU:
       ANYLOC_CHECK_ARG(p.N % 64 == 0, "gemm_h3: SWIGLU needs N %% 64 == 0");
       return dispatch_h3<EPI_SWIGLU>(p, stream);

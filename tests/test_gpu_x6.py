@@ -109,6 +109,30 @@ def test_gemm_h3_as_accurate_as_fp32(M, N, K):
     assert torch.equal(c, ops.gemm_nt_h3(ops.split_h2(a), ops.split_h2(w), M, N, K, bias))
 
 
+@pytest.mark.parametrize("name,layer,depth,hw", [("dinov2_vitg14", 1, 2, (322, 322)), ("dinov2_vits14", 5, 6, (224, 308))])
+def test_h3_epilogue_and_quantiser_variants_are_bit_identical(monkeypatch, name, layer, depth, hw):
+    """The LDS-transposed 16-byte LayerScale-residual epilogue vs the dword one (ANYLOC_H3_EPI_LDS=0), and the
+    streaming two-pass quantiser for wide rows vs the rows-in-registers one (ANYLOC_H2_REG=1), do the same
+    arithmetic in the same order: identical bits."""
+    import utilities
+    monkeypatch.setenv("ANYLOC_GEMM", "h3")
+    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, depth=depth))
+    try:
+        imgs = torch.cat(synth.synthetic_places(4, 1, hw[0], hw[1], seed=13)[:2]).to(DEV)
+        base = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
+        monkeypatch.setenv("ANYLOC_H3_EPI_LDS", "0")
+        a = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
+        monkeypatch.delenv("ANYLOC_H3_EPI_LDS")
+        monkeypatch.setenv("ANYLOC_H2_REG", "1")
+        b = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
+        assert torch.isfinite(base).all()
+        assert torch.equal(base, a)
+        assert torch.equal(base, b)
+    finally:
+        weights.unregister_state_dict()
+
+
 def test_gemm_x6_deterministic_and_tail_rows_untouched():
     from anyloc_amd import ops
     g = torch.Generator(device=DEV).manual_seed(3)
