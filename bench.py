@@ -10,8 +10,10 @@ One *step* = one pass of the hot path over one batch of synthetic input, per ran
 Workload = BASELINE.json configs[1].  ``value`` = images/second of the whole job.
 
 The JSON line also carries
-  * roofline: fp32-MFMA roofline of the dominant kernel (per-launch algorithmic FLOPs /
-    average launch duration measured with HIP events on the launch stream in the timed region);
+  * roofline of the dominant kernel: per-launch ALGORITHMIC FLOPs / average launch duration measured with HIP
+    events on the launch stream in the timed region, against the peak of the arithmetic the block GEMMs run in
+    (--gemm h3, default: fp16 MFMA peak / 3 products; x6: bf16 MFMA peak / 6; f32: fp32 MFMA peak) and, always,
+    against the fp32-MFMA peak (`vs_fp32_mfma_peak`);
   * cpu_baseline (rank 0, N=1): the CPU oracle (reference algorithm restated, torch CPU)
     timed on this box's host cores on a bounded sample of the same workload, doubling as
     the parity check of the GPU run (``parity``).

@@ -1,6 +1,10 @@
-"""The split-bf16 ("x6") GEMM path through the C ABI (anyloc_split_x3 / anyloc_gemm_nt_x6 / anyloc_vit_attach_x3):
-the three-plane split is exact, the six-product GEMM is as accurate as an fp32 GEMM (measured against
-float64), and the ViT forward gives the same tokens in both GEMM modes and matches the golden vectors in each."""
+"""The split GEMM paths through the C ABI:
+  * x6 -- exact three-way bf16 splits, six bf16 MFMA products (anyloc_split_x3 / anyloc_gemm_nt_x6 / anyloc_vit_attach_x3),
+  * h3 -- row-scaled two-term fp16 splits, three fp16 MFMA products (anyloc_split_h2 / anyloc_gemm_nt_h3 /
+          anyloc_vit_attach_h2; the default of the Python surface).
+The splits are exact (x6) / 22-bit relative to the row maximum (h3), both GEMMs are as accurate as an fp32 GEMM
+(measured against float64), and the ViT forward gives the same tokens in all three GEMM modes and matches the golden
+vectors in each; fused / alternative kernel variants are bit-identical to the ones they replace."""
 import os
 
 import numpy as np
