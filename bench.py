@@ -320,7 +320,10 @@ def cpu_baseline_and_parity(sd, qu_img, vlad, db, ext, budget_s, warm, B):
                    "label_mismatches": int(flips.sum()), "labels": int(lab_r.numel()),
                    "largest_oracle_gap_of_a_mismatch": gap, "images_with_a_mismatch": int((~clean).sum()),
                    "top1_equal": bool(torch.equal(g_i[:, 0].cpu(), i_ref[:, 0])),
-                   "topk_index_mismatches": int((g_i.cpu() != i_ref).sum())},
+                   "topk_index_mismatches": int((g_i.cpu() != i_ref).sum()),
+                   # the same count restricted to images whose cluster ids all agree (a flipped fp32 tie moves one
+                   # token's residual between two VLAD blocks, which can reorder that image's deep ranks)
+                   "topk_index_mismatches_in_clean_images": int((g_i.cpu() != i_ref)[clean].sum())},
     }
 
 
