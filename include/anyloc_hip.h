@@ -84,7 +84,8 @@ int anyloc_gemm_nt_x6(const void* a3, const void* w3, const float* bias, float* 
  * row is scaled by a power of two into [2^14, 2^15) and split into two fp16 planes
  * (22 mantissa bits); the epilogue descales with inv_a[row] * inv_w[col]
  * (csrc/gemm_h3.hip, tools/split_fp16_study.py).
- *   anyloc_split_h2    fp32 [rows, K] (K % 16 == 0) -> plane image + inv_scale[rows]
+ *   anyloc_split_h2    fp32 [rows, K] (K % 16 == 0, K <= 4096, ldx % 4 == 0) -> plane image
+ *                      (anyloc_h2_bytes) + inv_scale[rows] (2^-e of each row)
  *   anyloc_gemm_nt_h3  C[M,N] = A W^T (+ bias[N]) from the two images */
 size_t anyloc_h2_bytes(int64_t rows, int64_t K);
 int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2,
@@ -111,8 +112,9 @@ int anyloc_pool_tokens(const float* tokens, const int64_t* offsets, int64_t n_im
                        void* stream);
 
 /* ------------------------------------------------------------- matmul ----
- * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N] when bias != NULL): the fp32 MFMA GEMM
- * all dense contractions of the path run on (torch Linear layout: both
+ * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N] when bias != NULL): the exact-fp32 MFMA GEMM
+ * (v_mfma_f32_32x32x2_f32) behind retrieval, the VLAD / k-means scores, the patch
+ * embedding and the ViT blocks of small batches (torch Linear layout: both
  * operands K-contiguous).  lda/ldw/ldc are row strides in floats.  Requires
  * K % 4 == 0 and 16-byte aligned rows.  Exposed for tests/benchmarks. */
 int anyloc_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw,
