@@ -101,7 +101,11 @@ enum GemmEpilogue {
   EPI_GELU = 1,       // C = gelu_erf(acc + bias)
   EPI_LS_RESID = 2,   // C = resid + gamma * (acc + bias)        (C may alias resid)
   EPI_SWIGLU = 3,     // C[:, n/2] = silu(acc_gate + b) * (acc_val + b), rows pair-interleaved
-  EPI_PATCH = 4       // C[b*T + 1 + p, :] = acc + bias + pos[1 + p, :]
+  EPI_PATCH = 4,      // C[b*T + 1 + p, :] = acc + bias + pos[1 + p, :]
+  // gemm_h3 only: the result leaves the kernel already quantised for its consumer (no fp32 round trip)
+  EPI_QKV_PLANES = 5, // q | k | v written as per-head two-plane fp16 tiles + one 2^-e per (32-row group, head): attention_h3
+  EPI_GELU_H2 = 6,    // gelu(acc + bias) written as the h2 image of the next GEMM, rows scaled by the caller's c_inv
+  EPI_SWIGLU_H2 = 7   // silu(gate) * value, the same
 };
 
 struct GemmProblem {
@@ -151,12 +155,36 @@ struct H3Problem {
   const float* gamma;                       // EPI_LS_RESID
   const float* resid;                       // EPI_LS_RESID, leading dim ldc
   int epi_lds;                              // EPI_LS_RESID: transposed 16-byte epilogue through LDS (set by gemm_h3)
+  // EPI_QKV_PLANES: N = 3 * heads * 64; see QkvPlanes below
+  unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
+  // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])
+  unsigned char* C2; int64_t RC; const float* c_inv;
   const char* tag;
 };
+
+// Layout of the Q / K / V operand tiles attention_h3 consumes (written by gemm_h3's EPI_QKV_PLANES epilogue).
+// Rows (tokens of all images, M = batch * T) are cut into GLOBAL groups of 32 rows (group g = rows 32g .. 32g+31,
+// independent of image boundaries); every (part p in {q,k,v}, head h, group g) owns one power-of-two scale
+//   inv[(p * heads + h) * groups + g] = 2^-e,  max |x| * 2^e in [2^14, 2^15)  over the 32 x 64 values of the tile,
+// and two fp16 planes (x * 2^e = hi + lo) of 4 KiB each at byte offset (((p * heads + h) * groups + g) * 2 + plane) * 4096:
+//   q, k:  [row 0..31][8 chunks of 8 d]   chunk c of row r sits at  r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
+//   v:     [d 0..63][4 chunks of 8 rows]  chunk (hh * 2 + s) of column d holds rows (j & 3) + 8 * (2 s + (j >> 2)) + 4 hh,
+//          j = 0..7 -- the order the MFMA C/D registers of a 32-row block hold them -- at d * 64 + ((chunk ^ ((d >> 2) & 3)) << 4)
+// Both images are what a wave reads conflict-free with ds_read_b128 after a linear global -> LDS DMA of the tile.
+inline size_t qkv_planes_bytes(int64_t rows, int heads) { return (size_t)3 * heads * ((rows + 31) / 32) * 2 * 4096; }
+inline size_t qkv_inv_count(int64_t rows, int heads) { return (size_t)3 * heads * ((rows + 31) / 32); }
 size_t h2_bytes(int64_t rows, int64_t K);
 int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream);
+// bound != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
+// (Cauchy-Schwarz: |fc1 output| <= ||ln(x)||_2 * max_j ||W_j||_2 + max |b|), bound = {gate_norm, gate_bias, val_norm, val_bias}
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
-                 float* inv_scale, hipStream_t stream);
+                 float* inv_scale, hipStream_t stream, const float* bound = nullptr, float* bound_inv = nullptr);
+// attention on the tiles of EPI_QKV_PLANES; writes the h2 image (+ per-row 2^-e) the projection GEMM reads
+int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, int T, int D, int heads,
+                 unsigned char* out2, float* out_inv, hipStream_t stream);
+// test / fallback producer of the same tiles from an fp32 [rows, 3D] buffer
+int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsigned char* planes, float* inv,
+                        hipStream_t stream);
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
 
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,

@@ -244,35 +244,40 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x,
 }
 
 // reference quirk (utilities.py:881-884): block k = sum_q sum_c w[q,k] * (xhat_q - c_c).
-// One block per (image, 256-col slice); each thread owns one column d and K accumulators in LDS:
-//   acc[k] += w[q,k] * (xhat[q,d] - c[c,d])  for every c (direct double sum, as the reference computes it)
-__global__ __launch_bounds__(SL) void soft_accumulate_kernel(const float* __restrict__ x,
-                                                             const int64_t* __restrict__ offsets, int D, int K,
-                                                             int kpad, const float* __restrict__ w,
-                                                             const float* __restrict__ nrm,
-                                                             const float* __restrict__ c, float* __restrict__ dst) {
-  extern __shared__ float acc[];   // [K][SL] accumulators, then [K][SL] centre slice
-  float* cs = acc + K * SL;
+// One block per (image, SLS-column slice); each thread owns one column d and K accumulators in LDS:
+//   acc[k] += w[q,k] * (xhat[q,d] - c[c,d])  for every c -- the reference's own double sum, term by term in fp32
+// (residual, then product), accumulated in float64 so that the result is the exact sum of the reference's fp32
+// terms: the reference adds its N*K terms with torch's pairwise fp32 summation, and a sequential fp32 chain of
+// N*K = 2 000 ... 90 000 adds with heavy cancellation would sit ~5e-5 away from it.
+constexpr int SLS = 128;
+__global__ __launch_bounds__(SLS) void soft_accumulate_kernel(const float* __restrict__ x,
+                                                              const int64_t* __restrict__ offsets, int D, int K,
+                                                              int kpad, const float* __restrict__ w,
+                                                              const float* __restrict__ nrm,
+                                                              const float* __restrict__ c, float* __restrict__ dst) {
+  extern __shared__ double acc64[];   // [K][SLS] accumulators (float64), then [K][SLS] centre slice (float32)
+  double* acc = acc64;
+  float* cs = reinterpret_cast<float*>(acc + K * SLS);
   const int tid = threadIdx.x;
-  const int d = blockIdx.x * SL + tid;
+  const int d = blockIdx.x * SLS + tid;
   const bool live = d < D;
   const int64_t g = blockIdx.y;
   const int64_t n0 = offsets[g], n1 = offsets[g + 1];
   for (int k = 0; k < K; ++k) {
-    acc[k * SL + tid] = 0.f;
-    cs[k * SL + tid] = live ? c[(int64_t)k * D + d] : 0.f;
+    acc[k * SLS + tid] = 0.0;
+    cs[k * SLS + tid] = live ? c[(int64_t)k * D + d] : 0.f;
   }
   for (int64_t n = n0; n < n1; ++n) {
     const float xh = live ? x[n * D + d] / nrm[n] : 0.f;
     const float* wr = w + n * kpad;
     for (int cc = 0; cc < K; ++cc) {
-      const float r = xh - cs[cc * SL + tid];
-      for (int k = 0; k < K; ++k) acc[k * SL + tid] += wr[k] * r;
+      const float r = xh - cs[cc * SLS + tid];
+      for (int k = 0; k < K; ++k) acc[k * SLS + tid] += (double)(wr[k] * r);
     }
   }
   if (live) {
     float* o = dst + g * (int64_t)K * D + d;
-    for (int k = 0; k < K; ++k) o[(int64_t)k * D] = acc[k * SL + tid];
+    for (int k = 0; k < K; ++k) o[(int64_t)k * D] = (float)acc[k * SLS + tid];
   }
 }
 
@@ -453,17 +458,17 @@ int anyloc_vlad_soft(const float* tokens, const int64_t* offsets, int64_t n_img,
     ANYLOC_TRY(launch_status("soft_weights_kernel"));
   }
   {
-    const size_t lds = (size_t)2 * K * SL * sizeof(float);
+    const size_t lds = (size_t)K * SLS * (sizeof(double) + sizeof(float));
     static bool attr = false;
     if (!attr) {
       ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(soft_accumulate_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * SL * (int)sizeof(float)));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * SLS * 12));
       attr = true;
     }
     ProfScope prof("vlad_soft_accumulate", stream, 2.0 * total_tokens * D * K * K, 4.0 * total_tokens * D);
     for (int64_t i0 = 0; i0 < n_img; i0 += 65535) {
       const int64_t cnt = std::min<int64_t>(65535, n_img - i0);
-      hipLaunchKernelGGL(soft_accumulate_kernel, dim3((unsigned)((D + SL - 1) / SL), (unsigned)cnt), dim3(SL), lds,
+      hipLaunchKernelGGL(soft_accumulate_kernel, dim3((unsigned)((D + SLS - 1) / SLS), (unsigned)cnt), dim3(SLS), lds,
                          stream, tokens, offsets + i0, (int)D, (int)K, kp, w.scores, w.nrm, centers,
                          out + i0 * K * D);
       ANYLOC_TRY(launch_status("soft_accumulate_kernel"));

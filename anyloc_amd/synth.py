@@ -126,3 +126,41 @@ def clustered_tokens(n_img, n_tok, dim, n_modes, seed=7, device="cpu", noise=0.3
     x = modes[pick] + (noise / math.sqrt(dim)) * torch.randn(
         n_img, n_tok, dim, generator=gen, device=device)
     return torch.nn.functional.normalize(x, dim=-1)
+
+
+def outlier_state_dict(sd, name, seed=0, gamma_boost=1000.0, resid_bias=600.0, cls_boost=100.0):
+    """Numerical-stress variant of a hub-layout state dict: the statistics real DINOv2 checkpoints
+    have and ``synthetic_state_dict`` does not (heavy-tailed LayerNorm gains, "massive activation"
+    residual channels, LayerScale gammas spread over five decades, a register-like token).
+
+      * LayerNorm gamma / beta of three channels x ``gamma_boost`` in every block, with the matching
+        COLUMNS of the consuming projection (qkv, fc1 / w12) divided by the same factor: the function
+        is preserved, but every GEMM operand row now spans three more decades (what a row-scaled
+        fixed-point split has to survive);
+      * ``blocks.0.attn.proj.bias`` of one channel = ``resid_bias``: a residual-stream channel that
+        dominates every token's LayerNorm statistics from block 0 on;
+      * a random third of the LayerScale gammas drawn log-uniformly from [1e-5, 1];
+      * the CLS token x ``cls_boost`` (one token whose norm is far above the others').
+    Returns a new dict; ``sd`` is not modified."""
+    dim = ARCH[name][0]
+    ffn = ARCH[name][3]
+    out = {k: v.clone() for k, v in sd.items()}
+    dev = out["cls_token"].device
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(seed)
+    hot = torch.randperm(dim, generator=gen)[:4].to(dev)
+    depth = 1 + max(int(k.split(".")[1]) for k in out if k.startswith("blocks."))
+    fc1 = "mlp.fc1.weight" if ffn == "mlp" else "mlp.w12.weight"
+    for i in range(depth):
+        p = f"blocks.{i}."
+        for norm, cons in (("norm1", "attn.qkv.weight"), ("norm2", fc1)):
+            out[p + norm + ".weight"][hot[:3]] *= gamma_boost
+            out[p + norm + ".bias"][hot[:3]] *= gamma_boost
+            out[p + cons][:, hot[:3]] /= gamma_boost
+        for ls in ("ls1.gamma", "ls2.gamma"):
+            pick = (torch.rand(dim, generator=gen) < 1.0 / 3.0).to(dev)
+            val = torch.pow(10.0, -5.0 * torch.rand(dim, generator=gen)).to(dev)
+            out[p + ls] = torch.where(pick, val, out[p + ls])
+    out["blocks.0.attn.proj.bias"][hot[3]] = resid_bias
+    out["cls_token"] = out["cls_token"] * cls_boost
+    return out
