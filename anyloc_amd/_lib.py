@@ -47,7 +47,7 @@ H2_FIELDS = ("qkv_w2", "qkv_inv", "proj_w2", "proj_inv", "fc1_w2", "fc1_inv", "f
 
 
 class VitBlockH2(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in H2_FIELDS]
+    _fields_ = [(n, C.c_void_p) for n in H2_FIELDS] + [("fc1_bound", C.c_float * 4)]
 
 
 # name -> (restype, argtypes); also the list the symbol-export test checks
@@ -69,6 +69,8 @@ SIGNATURES = {
                                  c_i64, c_i64, c_i64, C.c_void_p]),
     "anyloc_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),
     "anyloc_attention": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p]),
+    "anyloc_attention_h3_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "anyloc_attention_h3": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vlad_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "anyloc_vlad_hard": (C.c_int, [c_f32p, c_i64p, c_i64, c_i64, c_i64, c_f32p, c_i64, C.c_uint,
                                    c_f32p, c_i64p, C.c_void_p, c_sz, C.c_void_p]),

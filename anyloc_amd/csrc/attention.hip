@@ -427,7 +427,295 @@ __global__ __launch_bounds__(256, 2) void attention_x6_kernel(const float* __res
   }
 }
 
+
+// ---- "h3" attention: both matrix products as THREE fp16 matrix-core products of two-term fp16 operands ----
+// The arithmetic of gemm_h3.hip applied to softmax((q/8) k^T) v.  Q, K and V arrive already quantised: the QKV GEMM's
+// epilogue (EPI_QKV_PLANES) wrote them as per-(head, 32-row group) tiles of two fp16 planes with one power-of-two scale
+// per tile, in exactly the images this kernel wants in LDS (layout: common.hpp) -- so a key tile is staged by four
+// 1-KiB global -> LDS DMA instructions per wave, with no conversion, no VGPR round trip and no transposing store, and
+// nothing is re-quantised per workgroup.  Structure as attention_kernel: S^T = K Q^T per 32-key tile, online softmax
+// per lane, O^T += V^T P^T; P = exp2(.) * 2^14 is split into fp16 hi + lo in registers.  Key tiles are the GLOBAL
+// 32-row groups that intersect the image (first / last tile masked), the same groups the producer scaled.
+// The output goes straight into the h2 image of the projection GEMM: every row of an image is scaled by the same power
+// of two, 1 / max(V tile scales of the image) -- an attention output is a convex combination of V rows, so
+// |o| <= max |V| < 2^15 in scaled units -- hence no fp32 round trip and no separate quantiser pass.
+typedef _Float16 ah_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ah_f16x2 __attribute__((ext_vector_type(2)));
+#define ANYLOC_MFMA_F16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ah_f16x8, a), __builtin_bit_cast(ah_f16x8, b), c, 0, 0, 0)
+
+__device__ __forceinline__ void ah_pack2(float a, float b, unsigned& hi, unsigned& lo) {
+  f32x2 pr;
+  pr[0] = a; pr[1] = b;
+  const ah_f16x2 h = __builtin_convertvector(pr, ah_f16x2);
+  f32x2 res;
+  res[0] = pr[0] - (float)h[0];
+  res[1] = pr[1] - (float)h[1];
+  const ah_f16x2 l = __builtin_convertvector(res, ah_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float ah_pow2_recip(float inv) { return __uint_as_float((254u << 23) - __float_as_uint(inv)); }
+
+__device__ __forceinline__ void ah_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+constexpr int AH_STAGE = 16384;       // K hi | K lo | V hi | V lo, 4 KiB each
+
+__global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
+                                                              const float* __restrict__ inv, int T, int heads, int64_t G,
+                                                              unsigned char* __restrict__ out2, float* __restrict__ out_inv,
+                                                              int64_t R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];   // 2 stages + 16 bytes for the block reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t r0 = b * T, r1 = r0 + T;
+  const int64_t g_first = r0 >> 5, g_last = (r1 - 1) >> 5;
+  const int ng = (int)(g_last - g_first + 1);
+  const int64_t gq_raw = g_first + blockIdx.x * 4 + wave;
+  const bool wave_active = gq_raw <= g_last;
+  const int64_t gq = wave_active ? gq_raw : g_last;
+  const int ql = lane & 31, h2 = lane >> 5;
+  const int64_t tile_bytes = 8192;
+
+  // ---- scale of this image's output rows: the largest V-tile scale over all heads and key groups ----
+  float fm = 0.f;
+  for (int i = tid; i < heads * ng; i += 256) {
+    const int hh = i / ng, gg = i - hh * ng;
+    fm = fmaxf(fm, inv[((int64_t)2 * heads + hh) * G + g_first + gg]);
+  }
+  fm = wave_max(fm);
+  float* red = reinterpret_cast<float*>(ah_smem + 2 * AH_STAGE);
+  if (lane == 0) red[wave] = fm;
+  __syncthreads();
+  fm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+
+  // ---- Q fragments (B operand): lane (query ql, half h2), k-step s: d = 16 s + 8 h2 + j = chunk 2 s + h2 of row ql ----
+  attn_u32x4 qf[2][4];
+  const int64_t q_tile = ((int64_t)h) * G + gq;
+  const float fq = inv[q_tile];
+  {
+    const unsigned char* qb = planes + q_tile * tile_bytes + ql * 128;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        qf[pl][s] = *reinterpret_cast<const attn_u32x4*>(qb + pl * 4096 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
+  }
+
+  // ---- K / V staging: pure DMA, wave w moves bytes [w KiB, w KiB + 1 KiB) of each of the four 4-KiB plane tiles ----
+  const int64_t part_bytes = (int64_t)heads * G * tile_bytes;
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(planes + part_bytes), 0, (int)part_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(planes + 2 * part_bytes), 0, (int)part_bytes, 0x00020000);
+  const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
+  auto issue = [&](int t, int stage) {
+    const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
+    unsigned char* st = ah_smem + stage * AH_STAGE + wave * 1024;
+    ah_dma16(k_rsrc, st, voff, soff);
+    ah_dma16(k_rsrc, st + 4096, voff + 4096, soff);
+    ah_dma16(v_rsrc, st + 8192, voff, soff);
+    ah_dma16(v_rsrc, st + 12288, voff + 4096, soff);
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f, fv_run = 1.0f;
+
+  issue(0, 0);
+  __syncthreads();                      // drains the DMA counter (fence) and publishes stage 0
+
+  for (int t = 0; t < ng; ++t) {
+    const int stage = t & 1;
+    if (t + 1 < ng) issue(t + 1, stage ^ 1);
+    if (wave_active) {
+      const int64_t gk = g_first + t;
+      const unsigned char* Ks = ah_smem + stage * AH_STAGE;
+      const unsigned char* Vs = Ks + 8192;
+      const float fk = inv[((int64_t)heads + h) * G + gk];
+      const float fv = inv[((int64_t)2 * heads + h) * G + gk];
+      // S^T = K_tile (A: rows = keys) x Q^T (B: cols = queries): 4 k-steps of 16 d, lo*hi + hi*lo + hi*hi
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        attn_u32x4 kf[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
+        sacc = ANYLOC_MFMA_F16(kf[1], qf[0][s], sacc);
+        sacc = ANYLOC_MFMA_F16(kf[0], qf[1][s], sacc);
+        sacc = ANYLOC_MFMA_F16(kf[0], qf[0][s], sacc);
+      }
+      // V^T fragments: lane (d = db*32 + ql, half h2), k-step s2: the 8 keys register r = 8 s2 + j of the score block holds
+      attn_u32x4 vf[2][2][2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int d = db * 32 + ql;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
+        }
+      // scores in the exp2 domain: t = S_true * log2(e), S_true = sacc * fq * fk / 8
+      const float c = fq * fk * (0.125f * 1.44269504088896340736f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] *= c;
+      if (gk == g_first || gk == g_last) {
+        const int64_t kb = gk * 32 + 4 * h2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t key = kb + (r & 3) + 8 * (r >> 2);
+          if (key < r0 || key >= r1) sacc[r] = -INFINITY;
+        }
+      }
+      float mloc = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float moff = 14.0f - m_new;                    // P * 2^14: hi + lo in fp16, the factor cancels against l
+      float lsum = 0.f;
+      attn_u32x4 pf[2][2];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(sacc[r] + moff), p1 = __builtin_amdgcn_exp2f(sacc[r + 1] + moff);
+        lsum += p0;
+        lsum += p1;
+        unsigned hi, lo;
+        ah_pack2(p0, p1, hi, lo);
+        pf[0][r >> 3][(r & 7) >> 1] = hi;
+        pf[1][r >> 3][(r & 7) >> 1] = lo;
+      }
+      lsum += __shfl_xor(lsum, 32, 64);
+      l_run = l_run * alpha + lsum;
+      m_run = m_new;
+      // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
+      const float resc = alpha * (t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv));
+      fv_run = fv;
+      if (!__all(resc == 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= resc; oacc[1][r] *= resc; }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          oacc[db] = ANYLOC_MFMA_F16(vf[1][db][s2], pf[0][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[1][s2], oacc[db]);
+          oacc[db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[0][s2], oacc[db]);
+        }
+    }
+    __syncthreads();                    // everyone is done with this stage; the next tile's DMA has landed
+  }
+
+  // oacc[db][r] = O[q][db*32 + (r&3) + 8*(r>>2) + 4*h2] * l_run / fv_run (in P * 2^14 units, which cancel against l_run)
+  const int64_t row = gq * 32 + ql;
+  if (wave_active && row >= r0 && row < r1) {
+    const float f = fv_run * ah_pow2_recip(fm) / l_run;        // -> value * 2^e_img, |.| < 2^15
+    if (h == 0 && h2 == 0) out_inv[row] = fm;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
+        unsigned char* dst = out2 + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
+        uint2 ph, plo;
+        ah_pack2(oacc[db][4 * g + 0] * f, oacc[db][4 * g + 1] * f, ph.x, plo.x);
+        ah_pack2(oacc[db][4 * g + 2] * f, oacc[db][4 * g + 3] * f, ph.y, plo.y);
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + R * 32) = plo;
+      }
+  }
+}
+
+// fp32 [rows, 3D] (q | k | v, heads contiguous) -> the tiles of common.hpp (what gemm_h3's EPI_QKV_PLANES writes).
+// One block per (32-row group, head, part); used by the kernel tests and by callers that hold fp32 projections.
+__global__ __launch_bounds__(256) void qkv_planes_kernel(const float* __restrict__ qkv, int64_t rows, int D, int heads, int64_t G,
+                                                         unsigned char* __restrict__ planes, float* __restrict__ inv) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g = blockIdx.x;
+  const int h = blockIdx.y, part = blockIdx.z;
+  const int r = tid >> 3, c8 = (tid & 7) * 8;
+  const int64_t row = g * 32 + r;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = row < rows ? qkv[row * 3 * (int64_t)D + (int64_t)part * D + h * 64 + c8 + j] : 0.f;
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+  amax = wave_max(amax);
+  if (lane == 0) red[wave] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
+  const float scale = __uint_as_float((unsigned)(127 + e) << 23);
+  const int64_t tile = ((int64_t)part * heads + h) * G + g;
+  if (tid == 0) inv[tile] = __uint_as_float((unsigned)(127 - e) << 23);
+  unsigned char* dst = planes + tile * 8192;
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ah_pack2(v[2 * j] * scale, v[2 * j + 1] * scale, hi[j], lo[j]);
+  if (part < 2) {
+    unsigned char* o = dst + r * 128 + (((c8 >> 3) ^ ((r >> 1) & 7)) << 4);
+    attn_u32x4 a, bq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = hi[j]; bq[j] = lo[j]; }
+    *reinterpret_cast<attn_u32x4*>(o) = a;
+    *reinterpret_cast<attn_u32x4*>(o + 4096) = bq;
+  } else {
+    // row r = (j & 3) + 8 * (2 s2 + (j >> 2)) + 4 hh  ->  hh = (r >> 2) & 1, s2 = r >> 4, j = (r & 3) + 4 * ((r >> 3) & 1)
+    const int hh = (r >> 2) & 1, s2 = r >> 4, j = (r & 3) + 4 * ((r >> 3) & 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d = c8 + i;
+      unsigned char* o = dst + d * 64 + (((hh * 2 + s2) ^ ((d >> 2) & 3)) << 4) + j * 2;
+      *reinterpret_cast<unsigned short*>(o) = (unsigned short)(hi[i >> 1] >> (16 * (i & 1)));
+      *reinterpret_cast<unsigned short*>(o + 4096) = (unsigned short)(lo[i >> 1] >> (16 * (i & 1)));
+    }
+  }
+}
+
 }  // namespace
+
+int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsigned char* planes, float* inv, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(qkv && planes && inv && rows > 0 && D == heads * HD, "qkv_planes: bad arguments");
+  const int64_t G = (rows + 31) / 32;
+  ANYLOC_CHECK_ARG(G < (1ll << 31), "qkv_planes: too many rows");
+  hipLaunchKernelGGL(qkv_planes_kernel, dim3((unsigned)G, heads, 3), dim3(256), 0, stream, qkv, rows, D, heads, G, planes, inv);
+  return launch_status("qkv_planes_kernel");
+}
+
+int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, int T, int D, int heads, unsigned char* out2,
+                 float* out_inv, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(planes && inv && out2 && out_inv, "attention_h3: null pointer");
+  ANYLOC_CHECK_ARG(D == heads * HD, "attention_h3: head_dim must be 64 (D=%d heads=%d)", D, heads);
+  ANYLOC_CHECK_ARG(T > 0 && batch > 0 && batch < 65536, "attention_h3: bad T/batch");
+  const int64_t R = batch * T, G = (R + 31) / 32;
+  ANYLOC_CHECK_ARG((int64_t)heads * G * 8192 < (1ll << 31), "attention_h3: operand tiles exceed the 2 GiB buffer-addressing range");
+  const double flops = 4.0 * (double)batch * heads * (double)T * T * HD;
+  ProfScope prof("attention", stream, flops, 8.0 * batch * T * D * 2);
+  const int qgroups = (T + 31) / 32 + 1;                    // an image intersects at most this many 32-row groups
+  const size_t lds = 2 * AH_STAGE + 64;
+  static bool attr = false;
+  if (!attr) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(attention_h3_kernel, dim3((qgroups + 3) / 4, heads, (unsigned)batch), dim3(256), lds, stream, planes, inv, T,
+                     heads, G, out2, out_inv, R);
+  return launch_status("attention_h3_kernel");
+}
 
 // qkv [B*T, 3D] (q | k | v, each head-major 64-wide), out [B*T, D]
 int attention(const float* qkv, float* out, int64_t batch, int T, int D, int heads, hipStream_t stream,

@@ -175,7 +175,7 @@ inline size_t qkv_planes_bytes(int64_t rows, int heads) { return (size_t)3 * hea
 inline size_t qkv_inv_count(int64_t rows, int heads) { return (size_t)3 * heads * ((rows + 31) / 32); }
 size_t h2_bytes(int64_t rows, int64_t K);
 int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream);
-// bound != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
+// bound (HOST array of 4 floats) != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
 // (Cauchy-Schwarz: |fc1 output| <= ||ln(x)||_2 * max_j ||W_j||_2 + max |b|), bound = {gate_norm, gate_bias, val_norm, val_bias}
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
                  float* inv_scale, hipStream_t stream, const float* bound = nullptr, float* bound_inv = nullptr);

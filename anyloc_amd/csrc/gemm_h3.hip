@@ -57,6 +57,29 @@ struct H3Cfg {
   static_assert(BM % (32 * NW) == 0 && BN % (32 * NW) == 0, "each wave stages whole 32-row pieces");
 };
 
+
+// scale / inverse scale of a row (or tile) from its largest magnitude: amax * 2^e in [2^14, 2^15)
+__device__ __forceinline__ float h2_row_scale(float amax, float& inv) {
+  const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
+  inv = __uint_as_float((unsigned)(127 - e) << 23);
+  return __uint_as_float((unsigned)(127 + e) << 23);
+}
+// 2^e from a stored 2^-e (both normal powers of two: exact)
+__device__ __forceinline__ float h2_scale_of_inv(float inv) { return __uint_as_float((254u << 23) - __float_as_uint(inv)); }
+// two scaled values -> packed fp16 pair of the leading plane and of the residual plane
+__device__ __forceinline__ void h2_pack2(float a, float b, unsigned& hi, unsigned& lo) {
+  f32x2 pr;
+  pr[0] = a; pr[1] = b;
+  const f16x2 h = __builtin_convertvector(pr, f16x2);
+  f32x2 res;
+  res[0] = pr[0] - (float)h[0];
+  res[1] = pr[1] - (float)h[1];
+  const f16x2 l = __builtin_convertvector(res, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 __device__ __forceinline__ float h3_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float h3_silu(float v) { return v / (1.0f + expf(-v)); }
 
@@ -142,6 +165,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
     slab(kt, 0);
     if (kt + 1 < nk) slab(kt + 1, 1);
     if (STAGES > 2 && kt + 2 < nk) slab(kt + 2, 2);
+    if (STAGES > 3 && kt + 3 < nk) slab(kt + 3, 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -196,6 +220,169 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
       }
       return;
     }
+  }
+  if constexpr (EPI == EPI_QKV_PLANES) {
+    // q | k | v leave the kernel as the per-(head, 32-row group) two-plane fp16 tiles of attention_h3 (layout: common.hpp).
+    // A wave owns 32 MI rows x 32 NI columns = MI row groups x NI/2 heads of ONE part (D % (32 NI) == 0).  v tiles are
+    // written straight from the C/D layout (a lane holds one d and the 16 rows of its half in exactly the order the
+    // consumer's B fragments want); q / k tiles are row-major, so they are transposed through the idle LDS ring.
+    __builtin_amdgcn_s_barrier();
+    float* st = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    const int Dm = p.heads * 64;
+    const int64_t colw = n0 + wn * 32 * NI;
+    const int part = (int)(colw / Dm);
+    const int head0 = (int)((colw - (int64_t)part * Dm) >> 6);
+    const int hl = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int64_t rb = m0 + wm * 32 * MI + mi * 32;
+      if (rb >= p.M || colw >= p.N) continue;
+      float ai[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+        ai[r] = row < p.M ? p.a_inv[row] : 0.0f;
+      }
+#pragma unroll
+      for (int hh = 0; hh < NI / 2; ++hh) {
+        float v[2][16];
+        float amax = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int64_t col = wcol0 + (2 * hh + nb) * 32;
+          const float bv = p.bias ? p.bias[col] : 0.0f, sw_ = p.w_inv[col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            v[nb][r] = ai[r] != 0.0f ? acc[mi][2 * hh + nb][r] * (ai[r] * sw_) + bv : 0.0f;
+            amax = fmaxf(amax, fabsf(v[nb][r]));
+          }
+        }
+        amax = wave_max(amax);
+        float inv;
+        const float scale = h2_row_scale(amax, inv);
+        const int64_t tile = (int64_t)(part * p.heads + head0 + hh) * p.groups + (rb >> 5);
+        if (lane == 0) p.qkv_inv[tile] = inv;
+        unsigned char* dst = p.qkv_planes + tile * 8192;
+        if (part == 2) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int d = nb * 32 + (lane & 31);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              unsigned qh[4], ql[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                h2_pack2(v[nb][8 * s2 + 2 * j] * scale, v[nb][8 * s2 + 2 * j + 1] * scale, qh[j], ql[j]);
+              hu32x4 ph, plo;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { ph[j] = qh[j]; plo[j] = ql[j]; }
+              unsigned char* o = dst + d * 64 + (((hl * 2 + s2) ^ ((d >> 2) & 3)) << 4);
+              *reinterpret_cast<hu32x4*>(o) = ph;
+              *reinterpret_cast<hu32x4*>(o + 4096) = plo;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[((r & 3) + 8 * (r >> 2) + 4 * hl) * 68 + nb * 32 + (lane & 31)] = v[nb][r] * scale;
+          const int lr0 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int lr = it * 4 + lr0;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&st[lr * 68 + c4]);
+            uint2 ph, plo;
+            h2_pack2(t[0], t[1], ph.x, plo.x);
+            h2_pack2(t[2], t[3], ph.y, plo.y);
+            unsigned char* o = dst + lr * 128 + (((c4 >> 3) ^ ((lr >> 1) & 7)) << 4) + (c4 & 4) * 2;
+            *reinterpret_cast<uint2*>(o) = ph;
+            *reinterpret_cast<uint2*>(o + 4096) = plo;
+          }
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_GELU_H2 || EPI == EPI_SWIGLU_H2) {
+    // the FFN hidden activation leaves the kernel as the h2 image of the fc2 GEMM, every row scaled by the caller's
+    // power of two (1 / c_inv[row], an upper bound of the row: layernorm_h2).  32 x 64 sub-blocks are transposed through
+    // the idle LDS ring so that a lane owns eight consecutive k of a row = one 16-byte half of an image row per plane.
+    __builtin_amdgcn_s_barrier();
+    float* st = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    constexpr bool SW = EPI == EPI_SWIGLU_H2;
+    constexpr int OC = SW ? 16 * NI : 64;                  // output columns per transposed sub-block
+    constexpr int NSUB = SW ? 1 : NI / 2;
+    constexpr int LPR = OC / 8;                            // lanes per row when reading back
+    constexpr int RPI = 64 / LPR;                          // rows per read-back iteration
+    const int hl = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int64_t rb = m0 + wm * 32 * MI + mi * 32;
+      if (rb >= p.M) continue;
+      float ai[16], cs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+        ai[r] = row < p.M ? p.a_inv[row] : 0.0f;
+        cs[r] = row < p.M ? h2_scale_of_inv(p.c_inv[row]) : 0.0f;
+      }
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        int64_t ocol0;                                     // first output column of this sub-block
+        if constexpr (SW) {
+          ocol0 = (n0 + wn * 32 * NI) / 2;
+#pragma unroll
+          for (int nj = 0; nj < NI; nj += 2) {
+            const int64_t colg = wcol0 + nj * 32, colv = colg + 32;
+            const bool cok = colv < p.N;
+            const float bg = (cok && p.bias) ? p.bias[colg] : 0.0f, bv = (cok && p.bias) ? p.bias[colv] : 0.0f;
+            const float sg = cok ? p.w_inv[colg] : 0.0f, sv = cok ? p.w_inv[colv] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float g = acc[mi][nj][r] * (ai[r] * sg) + bg;
+              const float v = acc[mi][nj + 1][r] * (ai[r] * sv) + bv;
+              st[((r & 3) + 8 * (r >> 2) + 4 * hl) * 68 + (nj / 2) * 32 + (lane & 31)] = h3_silu(g) * v * cs[r];
+            }
+          }
+        } else {
+          ocol0 = n0 + wn * 32 * NI + sub * 64;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int64_t col = wcol0 + (2 * sub + nb) * 32;
+            const bool cok = col < p.N;
+            const float bv = (cok && p.bias) ? p.bias[col] : 0.0f, sw_ = cok ? p.w_inv[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[((r & 3) + 8 * (r >> 2) + 4 * hl) * 68 + nb * 32 + (lane & 31)] =
+                  h3_gelu_erf(acc[mi][2 * sub + nb][r] * (ai[r] * sw_) + bv) * cs[r];
+          }
+        }
+        const int lr0 = lane / LPR, c8 = (lane % LPR) * 8;
+        const int64_t kcol = ocol0 + c8;
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int lr = it * RPI + lr0;
+          const int64_t row = rb + lr;
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(&st[lr * 68 + c8]);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(&st[lr * 68 + c8 + 4]);
+          unsigned qh[4], ql[4];
+          h2_pack2(t0[0], t0[1], qh[0], ql[0]);
+          h2_pack2(t0[2], t0[3], qh[1], ql[1]);
+          h2_pack2(t1[0], t1[1], qh[2], ql[2]);
+          h2_pack2(t1[2], t1[3], qh[3], ql[3]);
+          hu32x4 ph, plo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ph[j] = qh[j]; plo[j] = ql[j]; }
+          if (row < p.M && kcol < (SW ? p.N / 2 : p.N)) {
+            unsigned char* o = p.C2 + (((kcol >> 4) * 2) * p.RC + row) * 32 + ((((kcol >> 3) & 1) ^ (int)((row >> 3) & 1)) << 4);
+            *reinterpret_cast<hu32x4*>(o) = ph;
+            *reinterpret_cast<hu32x4*>(o + p.RC * 32) = plo;
+          }
+        }
+      }
+    }
+    return;
   }
   if constexpr (EPI == EPI_SWIGLU) {
     float bg[NI / 2], bv[NI / 2], sg[NI / 2], sv[NI / 2];
@@ -260,14 +447,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
 }
 
 // ---- quantisers: rows held in registers (NV float4 per lane and row, 4 rows per wave, 16 rows per block) ----
-// scale / inverse scale of a row from its largest magnitude: amax * 2^e in [2^14, 2^15)
-__device__ __forceinline__ float h2_row_scale(float amax, float& inv) {
-  const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
-  const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
-  inv = __uint_as_float((unsigned)(127 - e) << 23);
-  return __uint_as_float((unsigned)(127 + e) << 23);
-}
-
 // the scaled values of 16 rows go through a 16 x 256 LDS tile, chunk by chunk, and are stored in IMAGE order
 // (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
 // store chunk i (256 columns) of 16 rows, already scaled and sitting in the LDS tile, in IMAGE order
@@ -401,10 +580,15 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
 }
 
 // LayerNorm (torch semantics, biased variance) whose output is quantised straight into the h2 image
+// bound_inv != nullptr (LN2 of a block whose FFN activation is quantised in the fc1 epilogue): also writes
+// bound_inv[row] = 2^-e, where 2^e scales an UPPER BOUND of |act(fc1(y_row))| into [2^14, 2^15).  Cauchy-Schwarz:
+// |fc1_j(y)| <= ||y||_2 max_j ||W_j||_2 + max_j |b_j|, |gelu(t)| <= |t|, |silu(g) v| <= |g| |v|; bound4 = {gate (or fc1)
+// row-norm maximum, gate bias maximum, value row-norm maximum, value bias maximum} (value pair 0 / 0: GELU MLP).
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, int dim, int64_t rows, float eps,
-                                                           unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R) {
+                                                           unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
+                                                           const f32x4 bound4, float* __restrict__ bound_inv) {
   __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n4 = dim >> 2;
@@ -433,7 +617,7 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
         qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
     const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
-    float amax = 0.f;
+    float amax = 0.f, ysq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = lane + 64 * i;
@@ -443,12 +627,21 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) {
           v[q][i][j] = (v[q][i][j] - mean) * rstd * wv[j] + bv[j];
           amax = fmaxf(amax, fabsf(v[q][i][j]));
+          ysq += v[q][i][j] * v[q][i][j];
         }
       }
     }
     float iv;
     scale[q] = h2_row_scale(wave_max(amax), iv);
     if (lane == 0 && row0 + wave * 4 + q < rows) inv[row] = iv;
+    if (bound_inv) {
+      const float yn = sqrtf(wave_sum(ysq)) * 1.001f;                 // 0.1 % head room for the fp32 roundings
+      const float bg = yn * bound4[0] + bound4[1];
+      const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
+      float biv;
+      h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
+      if (lane == 0 && row0 + wave * 4 + q < rows) bound_inv[row] = biv;
+    }
   }
   h2_store_rows<NV>(v, scale, tile, dim, row0, rows, out, R);
 }
@@ -480,14 +673,17 @@ int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, flo
 }
 
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
-                 float* inv_scale, hipStream_t stream) {
+                 float* inv_scale, hipStream_t stream, const float* bound, float* bound_inv) {
   ANYLOC_CHECK_ARG(dim % 16 == 0 && dim <= 2048, "layernorm_h2: dim %d (needs a multiple of 16, at most 2048)", dim);
   ProfScope prof("layernorm_h2", stream, 8.0 * rows * dim, 8.0 * rows * dim);
   const dim3 grid((unsigned)((rows + 15) / 16));
   unsigned char* out = static_cast<unsigned char*>(h2);
   const int nv = (dim / 4 + 63) / 64;
+  f32x4 b4;                                                  // bound: HOST array of 4 floats (or null)
+  for (int i = 0; i < 4; ++i) b4[i] = bound ? bound[i] : 0.0f;
 #define ANYLOC_LN_H2(NVV) \
-  hipLaunchKernelGGL(layernorm_h2_kernel<NVV>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, rows)
+  hipLaunchKernelGGL(layernorm_h2_kernel<NVV>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, rows, \
+                     b4, bound ? bound_inv : nullptr)
   if (nv <= 1) ANYLOC_LN_H2(1);
   else if (nv <= 2) ANYLOC_LN_H2(2);
   else if (nv <= 3) ANYLOC_LN_H2(3);
@@ -500,7 +696,8 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
 
 template <int EPI>
 int dispatch_h3(const H3Problem& p, hipStream_t stream) {
-  // ANYLOC_H3_CFG (micro-benchmarks): 0 = 128x256 tile, 3-deep ring (default; 128x128 when there are few tiles); 1 = 2-deep
+  // ANYLOC_H3_CFG (micro-benchmarks): 0 = 128x256 tile, 3-deep ring (default; 128x128 when there are few tiles); 1 = 2-deep;
+  // 2-5 = 256x256 tiles (see the switch)
   static int cfg = -1;
   if (cfg < 0) {
     const char* e = getenv("ANYLOC_H3_CFG");
@@ -526,6 +723,10 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
   }
   switch (cfg) {
     case 1: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 2, 2); break;
+    case 2: ANYLOC_LAUNCH_H3(2, 4, 4, 2, 3, 2); break;     // 256x256, 8 waves (2 per SIMD, one workgroup per CU), 96 KiB ring
+    case 3: ANYLOC_LAUNCH_H3(2, 4, 4, 2, 4, 2); break;     // the same, 4-deep ring (128 KiB)
+    case 4: ANYLOC_LAUNCH_H3(4, 4, 2, 2, 4, 1); break;     // 256x256, 4 waves of 128x128 (one per SIMD), 4-deep ring
+    case 5: ANYLOC_LAUNCH_H3(4, 4, 2, 2, 3, 1); break;     // the same, 3-deep ring
     default: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 3, 2); break;
   }
 #undef ANYLOC_LAUNCH_H3
@@ -533,7 +734,7 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
 }
 
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream) {
-  ANYLOC_CHECK_ARG(p.A2 && p.a_inv && p.W2 && p.w_inv && p.C, "gemm_h3: null operand");
+  ANYLOC_CHECK_ARG(p.A2 && p.a_inv && p.W2 && p.w_inv && (p.C || epilogue >= EPI_QKV_PLANES), "gemm_h3: null operand");
   ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K16 > 0 && p.RA >= p.M && p.RW >= p.N, "gemm_h3: bad shape");
   ANYLOC_CHECK_ARG((size_t)p.K16 * 2 * (size_t)p.RA * 32 < (1ull << 31) && (size_t)p.K16 * 2 * (size_t)p.RW * 32 < (1ull << 31),
                    "gemm_h3: operand image exceeds the 2 GiB buffer-addressing range");
@@ -553,6 +754,17 @@ int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream) {
     case EPI_SWIGLU:
       ANYLOC_CHECK_ARG(p.N % 64 == 0, "gemm_h3: SWIGLU needs N %% 64 == 0");
       return dispatch_h3<EPI_SWIGLU>(p, stream);
+    case EPI_QKV_PLANES:
+      ANYLOC_CHECK_ARG(p.qkv_planes && p.qkv_inv && p.heads > 0 && p.N == 3ll * p.heads * 64 && (p.heads * 64) % 128 == 0 &&
+                           p.groups == (p.M + 31) / 32,
+                       "gemm_h3: QKV_PLANES needs N = 3 * heads * 64, D %% 128 == 0 and groups = ceil(M / 32)");
+      return dispatch_h3<EPI_QKV_PLANES>(p, stream);
+    case EPI_GELU_H2:
+      ANYLOC_CHECK_ARG(p.C2 && p.c_inv && p.RC >= p.M && p.N % 64 == 0, "gemm_h3: GELU_H2 needs an output image, c_inv and N %% 64 == 0");
+      return dispatch_h3<EPI_GELU_H2>(p, stream);
+    case EPI_SWIGLU_H2:
+      ANYLOC_CHECK_ARG(p.C2 && p.c_inv && p.RC >= p.M && p.N % 128 == 0, "gemm_h3: SWIGLU_H2 needs an output image, c_inv and N %% 128 == 0");
+      return dispatch_h3<EPI_SWIGLU_H2>(p, stream);
     default: set_error("gemm_h3: unsupported epilogue %d", epilogue); return ANYLOC_ERR_INVALID_ARG;
   }
 }

@@ -41,6 +41,7 @@ struct VitWs {
   unsigned char* a3;        // split-bf16 mode: plane image of a D-wide activation operand (LN output, attention output)
   unsigned char* h3;        //                  plane image of the FFN hidden activation
   float *ainv, *hinv;       // fp16 mode: 2^-e per row of the images in a3 / h3
+  float* qinv;              // fp16 mode, fused attention: 2^-e per (part, head, 32-row group) tile of q | k | v (in qkv)
   size_t bytes;
 };
 
@@ -50,13 +51,15 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   VitWs w;
   w.x = a.take<float>(M * c.dim);
   w.y = a.take<float>(M * c.dim);
-  const int64_t qkv_elems = std::max<int64_t>(M * 3 * c.dim, batch * np * c.patch_k_pad);
+  // fp32 [M, 3D], or the im2col patches, or (fp16 mode) the q | k | v tiles of attention_h3: rows padded to 32
+  const int64_t qkv_elems = std::max<int64_t>((M + 31) / 32 * 32 * 3 * c.dim, batch * np * c.patch_k_pad);
   w.qkv = a.take<float>(qkv_elems);
   w.h = a.take<float>(M * c.ffn_hidden);
   w.a3 = a.take<unsigned char>(x3_bytes(M, c.dim));
   w.h3 = a.take<unsigned char>(x3_bytes(M, c.ffn_hidden));
   w.ainv = a.take<float>(M);
   w.hinv = a.take<float>(M);
+  w.qinv = a.take<float>(qkv_inv_count(M, c.heads));
   w.bytes = a.off;
   return w;
 }
@@ -79,6 +82,14 @@ int linear(const float* A, int64_t lda, const float* Wt, int64_t K, const float*
 bool x6_fused() {
   const char* e = getenv("ANYLOC_X6_FUSE");      // read per forward: tests flip it inside one process
   return !(e && atoi(e) == 0);
+}
+
+// ANYLOC_H3_FUSE=0: fp16 mode with fp32 q|k|v / attention output / FFN activation and separate quantiser passes (the
+// round-1 data flow; A/B measurements and tests)
+// 2 / 3 fuse only the attention / only the FFN side (bisecting)
+int h3_fused() {
+  const char* e = getenv("ANYLOC_H3_FUSE");
+  return e ? atoi(e) : 1;
 }
 
 int64_t x6_min_rows() {
@@ -111,9 +122,12 @@ int linear_x6(const float* A, int64_t K, unsigned char* a3, const void* w3, int6
 // quantised operand (written by layernorm_h2); otherwise A (fp32, row-major, width K) is quantised here first.
 int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const void* w2, const float* winv, int64_t w_rows,
               int64_t w_row0, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
-              const char* tag, hipStream_t stream) {
+              const char* tag, hipStream_t stream, unsigned char* c2 = nullptr, const float* c_inv = nullptr,
+              unsigned char* qkv_planes = nullptr, float* qkv_inv = nullptr, int heads = 0) {
   if (A) ANYLOC_TRY(split_h2(A, K, M, K, a2, ainv, stream));
   H3Problem g{};
+  g.C2 = c2; g.RC = M; g.c_inv = c_inv;
+  g.qkv_planes = qkv_planes; g.qkv_inv = qkv_inv; g.heads = heads; g.groups = (M + 31) / 32;
   g.A2 = a2; g.RA = M; g.a_inv = ainv;
   g.W2 = static_cast<const unsigned char*>(w2) + w_row0 * 32; g.RW = w_rows; g.w_inv = winv + w_row0;
   g.w_off = w_row0 * 32;
@@ -143,6 +157,29 @@ int anyloc_attention(const float* qkv, float* out, int64_t batch, int64_t tokens
                      void* stream) {
   ANYLOC_CHECK_ARG(qkv && out, "attention: null pointer");
   return attention(qkv, out, batch, (int)tokens, (int)dim, (int)heads, static_cast<hipStream_t>(stream));
+}
+
+size_t anyloc_attention_h3_workspace_bytes(int64_t batch, int64_t tokens, int64_t heads) {
+  if (batch <= 0 || tokens <= 0 || heads <= 0) return 0;
+  const int64_t rows = batch * tokens;
+  return align_up(qkv_planes_bytes(rows, (int)heads), 256) + align_up(qkv_inv_count(rows, (int)heads) * sizeof(float), 256) + 256;
+}
+
+int anyloc_attention_h3(const float* qkv, void* out_img, float* out_inv, int64_t batch, int64_t tokens, int64_t dim,
+                        int64_t heads, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(qkv && out_img && out_inv && workspace, "attention_h3: null pointer");
+  ANYLOC_CHECK_ARG(batch > 0 && tokens > 0 && heads > 0 && dim == heads * 64, "attention_h3: bad shape");
+  if (workspace_bytes < anyloc_attention_h3_workspace_bytes(batch, tokens, heads)) {
+    set_error("attention_h3: workspace %zu < %zu", workspace_bytes, anyloc_attention_h3_workspace_bytes(batch, tokens, heads));
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  Arena a(workspace, workspace_bytes);
+  const int64_t rows = batch * tokens;
+  unsigned char* planes = a.take<unsigned char>(qkv_planes_bytes(rows, (int)heads));
+  float* inv = a.take<float>(qkv_inv_count(rows, (int)heads));
+  ANYLOC_TRY(qkv_planes_from_f32(qkv, rows, (int)dim, (int)heads, planes, inv, stream));
+  return attention_h3(planes, inv, batch, (int)tokens, (int)dim, (int)heads, static_cast<unsigned char*>(out_img), out_inv, stream);
 }
 
 int anyloc_vit_create(anyloc_vit_t** out, const anyloc_vit_config* cfg, const float* patch_w, const float* patch_b,
@@ -246,6 +283,7 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
   const bool h3m = (flags & ANYLOC_VIT_SPLIT_FP16) && M >= x6_min_rows();
   const bool x6 = !h3m && (flags & ANYLOC_VIT_SPLIT_BF16) && M >= x6_min_rows();
   const bool fuse_x6 = x6 && x6_fused();
+  const int h3f = h3m ? h3_fused() : 0;
   const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
   const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;
   const int64_t ldo = (int64_t)n_taps * D;
@@ -301,32 +339,59 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
       }
       break;
     }
-    if (h3m)
-      ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M,
-                           3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
-    else if (x6)
-      ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr,
-                           "vit_qkv_gemm", stream));
-    else
-      ANYLOC_TRY(linear(w.y, D, b.qkv_w, D, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
+    bool qkv_tap = false;                       // a q / k / v tap of this layer needs the fp32 projection
     for (int t = 0; t < n_taps; ++t)
-      if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
-        ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
-                              norm_taps, 1e-12f, stream));
-    ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr, x6 || h3m));
-    if (h3m)     // the attention output is fp32: its rows span all heads, the row maximum is only known now
-      ANYLOC_TRY(linear_h3(w.y, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
+      if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN) qkv_tap = true;
+    const bool fuse_attn = (h3f == 1 || h3f == 2) && !qkv_tap && D % 128 == 0;
+    if (fuse_attn) {
+      // fp16 mode, fused: the QKV GEMM writes per-head two-plane fp16 tiles, attention_h3 consumes them by DMA and writes
+      // the image of the projection GEMM -- q, k, v and the attention output never exist in fp32
+      ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, nullptr, 3 * D, M,
+                           3 * D, EPI_QKV_PLANES, nullptr, "vit_qkv_gemm", stream, nullptr, nullptr,
+                           reinterpret_cast<unsigned char*>(w.qkv), w.qinv, c.heads));
+      ANYLOC_TRY(attention_h3(reinterpret_cast<const unsigned char*>(w.qkv), w.qinv, batch, T, D, c.heads, w.a3, w.ainv, stream));
+      ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
-    else if (x6)
-      ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
-                           "vit_proj_gemm", stream));
-    else
-      ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
-    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream));
+    } else {
+      if (h3m)
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M,
+                             3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
+      else if (x6)
+        ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr,
+                             "vit_qkv_gemm", stream));
+      else
+        ANYLOC_TRY(linear(w.y, D, b.qkv_w, D, b.qkv_b, w.qkv, 3 * D, M, 3 * D, EPI_STORE, nullptr, "vit_qkv_gemm", stream));
+      for (int t = 0; t < n_taps; ++t)
+        if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN)
+          ANYLOC_TRY(facet_rows(w.qkv, 3 * D, tap_facets[t] * D, out, ldo, t * D, batch, T, skip, rows_per_img, D,
+                                norm_taps, 1e-12f, stream));
+      ANYLOC_TRY(attention(w.qkv, w.y, batch, T, D, c.heads, stream, fuse ? w.a3 : nullptr, x6 || h3m));
+      if (h3m)     // the attention output is fp32: its rows span all heads, the row maximum is only known now
+        ANYLOC_TRY(linear_h3(w.y, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
+                             EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
+      else if (x6)
+        ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].proj_w3, D, 0, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1,
+                             "vit_proj_gemm", stream));
+      else
+        ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
+    }
+    const float* fb = (h3f == 1 || h3f == 3) ? h->h2[l].fc1_bound : nullptr;
+    const bool fuse_ffn = fb && (fb[0] > 0.f || fb[1] > 0.f);
+    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, fuse_ffn ? fb : nullptr, w.hinv));
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
-    if (h3m) {
+    if (h3m && fuse_ffn) {
+      // the hidden activation is quantised in the epilogue against the row bound LayerNorm 2 left in w.hinv
+      if (c.ffn_kind == 0)
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, nullptr, Hh, M, Hh,
+                             EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv));
+      else
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0, b.fc1_b, nullptr, Hh, M,
+                             2 * Hh, EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3, w.hinv));
+      ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
+                           EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
+    } else if (h3m) {
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, w.h, Hh, M, Hh,
                              EPI_GELU, nullptr, "vit_fc1_gemm", stream));

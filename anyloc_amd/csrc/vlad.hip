@@ -369,6 +369,9 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     return ANYLOC_ERR_WORKSPACE;
   }
   const int kp = (int)kpad_of(K);
+  // labels = kmeans.predict(tokens) in the metric the vocabulary was built with (reference utilities.py:849 with
+  // VLAD(dist_mode=...)): fpk cosine score, or fpk euclidean similarity 2ab - a^2 - b^2 (arg-max = nearest centre)
+  const int metric = (flags & ANYLOC_VLAD_EUCLIDEAN) ? 1 : 0;
   // One workgroup per image: below ~160 images the fused kernel cannot fill the 256 CUs and the
   // two-pass path (grid = images x column slices) is faster (61 images: 0.25 vs 0.48 ms);
   // ANYLOC_VLAD_FUSED=1 forces the fused kernel regardless.
@@ -376,7 +379,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     // single-pass fused kernel (vlad_fused.hip): tokens are read from HBM once
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
-      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, 0);
+      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, metric);
       ANYLOC_TRY(launch_status("center_prep_kernel"));
     }
     FusedArgs fa{};
@@ -391,10 +394,10 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   if (total_tokens > 0) {
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
-      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, 0);
+      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, metric);
       ANYLOC_TRY(launch_status("center_prep_kernel"));
     }
-    ANYLOC_TRY(run_scores(tokens, total_tokens, D, w, K, false, stream, "vlad_scores_gemm"));
+    ANYLOC_TRY(run_scores(tokens, total_tokens, D, w, K, metric == 1, stream, "vlad_scores_gemm"));
     {
       ProfScope prof("vlad_assign", stream, 0.0, 4.0 * total_tokens * (kp + 4));
       hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((total_tokens + 7) / 8)), dim3(256), 0, stream, w.scores,

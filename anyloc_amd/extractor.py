@@ -117,6 +117,18 @@ class HipDinoV2:
                     self._keep += [img2, inv]
                     setattr(h2[i], f + "_w2", img2.data_ptr())
                     setattr(h2[i], f + "_inv", inv.data_ptr())
+                # Cauchy-Schwarz constants of the FFN input projection: the fc1 / w12 epilogue quantises the hidden
+                # activation against a bound derived from them (include/anyloc_hip.h, anyloc_vit_block_h2.fc1_bound)
+                if self.ffn_kind == 0:
+                    w1 = dev(state_dict[p + "mlp.fc1.weight"]).double()
+                    b1 = dev(state_dict[p + "mlp.fc1.bias"]).double()
+                    bound = [float(w1.norm(dim=1).max()), float(b1.abs().max()), 0.0, 0.0]
+                else:
+                    w12d, b12d = dev(w12).double(), dev(b12).double()
+                    bound = [float(w12d[:hidden].norm(dim=1).max()), float(b12d[:hidden].abs().max()),
+                             float(w12d[hidden:].norm(dim=1).max()), float(b12d[hidden:].abs().max())]
+                for j in range(4):
+                    h2[i].fc1_bound[j] = bound[j] * (1.0 + 1e-6)
         cfg = _lib.VitConfig(dim, depth, heads, self.ffn_kind, hidden, PATCH, 3 * PATCH * PATCH)
         self._handle = C.c_void_p()
         lib = _lib.load()

@@ -12,6 +12,7 @@ from . import _lib
 
 VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
+VLAD_EUCLIDEAN = 4
 FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
 VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1, 2, 4, 8, 16
 
@@ -125,6 +126,33 @@ def attention(qkv, heads):
     return out
 
 
+def h2_image_to_f32(img, inv, rows, K):
+    """Inverse of the h2 layout (csrc/gemm_h3.hip): [k/16][plane][row][16] fp16 with the 16-byte halves of a row swapped
+    when (row >> 3) & 1, times the per-row 2^-e  ->  float64 [rows, K] (tests / debugging; plain torch indexing)."""
+    k16 = (K + 15) // 16
+    t = img.view(torch.float16)[:k16 * 2 * rows * 16].reshape(k16, 2, rows, 2, 8).clone()
+    odd = ((torch.arange(rows, device=img.device) >> 3) & 1).bool()
+    t[:, :, odd] = t[:, :, odd].flip(3)
+    planes = t.permute(1, 2, 0, 3, 4).reshape(2, rows, k16 * 16).double()
+    return ((planes[0] + planes[1]) * inv.double()[:, None])[:, :K]
+
+
+def attention_h3(qkv, heads):
+    """The two-term fp16 attention kernel of the h3 forward on a packed fp32 qkv [B, T, 3*D]: returns the (image, inv)
+    pair anyloc_gemm_nt_h3 takes as its A operand (decode with h2_image_to_f32)."""
+    _need_cuda(qkv)
+    qkv = _f32c(qkv)
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    lib = _lib.load()
+    img = torch.empty(lib.anyloc_h2_bytes(B * T, D), dtype=torch.uint8, device=qkv.device)
+    inv = torch.empty(B * T, dtype=torch.float32, device=qkv.device)
+    ws = _lib.workspace(lib.anyloc_attention_h3_workspace_bytes(B, T, heads), qkv.device, "attn_h3")
+    _lib.check(lib.anyloc_attention_h3(_lib.ptr(qkv), _lib.ptr(img), _lib.ptr(inv), B, T, D, heads, _lib.ptr(ws),
+                                       ws.numel(), _lib.stream_ptr()), "anyloc_attention_h3")
+    return img, inv
+
+
 def _offsets_for(tokens_list_or_tensor, device):
     """-> (packed [total,D] device tensor, offsets int64 device tensor, n_img, D)."""
     t = tokens_list_or_tensor
@@ -148,11 +176,12 @@ def _offsets_for(tokens_list_or_tensor, device):
 
 
 def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0,
-         return_labels=False):
+         return_labels=False, dist_mode="cosine"):
     """VLAD descriptors of a batch of images.
 
     tokens: device tensor [n_img, N, D] / [N, D], or a list of [N_i, D] tensors.
-    centers: [K, D].  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
+    centers: [K, D].  ``dist_mode``: the metric of the hard assignment (the VLAD object's ``dist_mode``; the soft
+    weights are always cosine, as in the reference).  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
     device = _lib.require_gpu()
     centers = _f32c(centers, device)
     K, D = centers.shape
@@ -163,7 +192,10 @@ def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_te
     out = torch.empty(n_img, K * D, dtype=torch.float32, device=device)
     labels = torch.empty(total, dtype=torch.int64, device=device) if (return_labels and mode == "hard") else None
     lib = _lib.load()
-    flags = (VLAD_NORM_DESCS if norm_descs else 0) | (VLAD_INTRA_NORM if intra_norm else 0)
+    if dist_mode not in ("cosine", "euclidean"):
+        raise NotImplementedError(f"dist_mode {dist_mode!r}")
+    flags = (VLAD_NORM_DESCS if norm_descs else 0) | (VLAD_INTRA_NORM if intra_norm else 0) | \
+        (VLAD_EUCLIDEAN if dist_mode == "euclidean" else 0)
     ws_bytes = lib.anyloc_vlad_workspace_bytes(total, n_img, D, K)
     ws = _lib.workspace(ws_bytes, device, "vlad")
     if mode == "hard":

@@ -192,7 +192,7 @@ class VLAD:
             multi_query = [_as_tensor(q) for q in multi_query]
         out = ops.vlad(multi_query, self._centers_dev(), mode=self.vlad_mode,
                        norm_descs=self.norm_descs, intra_norm=self.intra_norm,
-                       soft_temp=self.soft_temp)
+                       soft_temp=self.soft_temp, dist_mode=self.mode)
         return out if home.type == "cuda" else out.to(home)
 
     def generate(self, query_descs: Union[np.ndarray, torch.Tensor],

@@ -49,6 +49,58 @@ def flops_per_image(dim=1536, depth_hook=31, n_patch=529, hidden=4096):
     return 2 * n_patch * 588 * dim + depth_hook * f_block + 2 * t * dim * dim
 
 
+def roofline_of(prof, gemm, value_per_gpu, steps):
+    """Live roofline of the dominant kernel of a timed region from the per-kernel HIP-event profile."""
+    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = dom["ms"] / dom["calls"]
+    achieved = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
+    gemm_ms = sum(v["ms"] for k, v in prof.items() if k.endswith("_gemm"))
+    gemm_fl = sum(v["flops"] for k, v in prof.items() if k.endswith("_gemm"))
+    kern_ms = sum(v["ms"] for v in prof.values())
+    products = {"x6": 6, "h3": 3}.get(gemm)      # matrix-core products per fp32-accurate product
+    split = products is not None and dom_name.endswith("_gemm") and dom_name != "vit_patch_embed_gemm"
+    # split modes: every algorithmic flop costs `products` bf16/fp16-MFMA flops, so the roofline of the fp32-accurate
+    # contraction is the dense 16-bit peak / products; `achieved` stays ALGORITHMIC flops / time in every mode.
+    peak = PEAK_BF16_MFMA_TFLOPS / products if split else PEAK_FP32_MFMA_TFLOPS
+    all_gemm = gemm_fl / (gemm_ms * 1e-3) / 1e12
+    e2e = value_per_gpu * flops_per_image() / 1e12
+    traffic = pmc_traffic(dom_name, gemm)
+    return {
+        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
+        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "peak_note": ((f"dense 16-bit MFMA peak 2500 / {products} matrix-core products per fp32-accurate product (" +
+                       ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
+                      if split else "fp32 MFMA peak"),
+        "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+        "clock_note": ("profiles/r01_pmc_x6.md: under these GEMMs the chip runs at its power limit (1.63 GHz with the matrix "
+                       "cores busy 70.9 % of SIMD cycles for h3; 1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz "
+                       "figure") if split else None,
+        "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"],
+        "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+        "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
+                      "vs_fp32_mfma_peak": round(all_gemm / PEAK_FP32_MFMA_TFLOPS, 4),
+                      "share_of_kernel_time": round(gemm_ms / kern_ms, 4)},
+        "end_to_end": {"algorithmic_tflops_per_image": round(flops_per_image() / 1e12, 4),
+                       "achieved": round(e2e, 2), "frac": round(e2e / peak, 4),
+                       "vs_fp32_mfma_peak": round(e2e / PEAK_FP32_MFMA_TFLOPS, 4)},
+        "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in
+                                sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+
+
+def pmc_traffic(kernel, gemm):
+    """HBM-side traffic of one launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    cannot be read in-process): profiles/pmc_traffic.json, written by tools/pmc_traffic.py from the counter CSVs of the
+    same forward (B=61).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            tab = json.load(fh)
+        return tab[gemm][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def synthetic_db(n, k, d, device, seed):
     """Database VLADs generated directly on the device: per-cluster unit blocks, globally
     normalised (SURVEY 8d config 3 recipe) -- extracting 10k images is setup, not the metric."""
@@ -63,22 +115,8 @@ def synthetic_db(n, k, d, device, seed):
     return db
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
-    # 61 images = 32 330 token rows = 252.6 row-tiles of 128: the 253 x {12,36,64} GEMM tile grids are
-    # within 1.2 % of whole multiples of the 512 resident thread blocks (2 per CU) -- no tail wave
-    ap.add_argument("--batch", type=int, default=61, help="query images per step per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm", choices=["x6", "h3", "f32"], default=os.environ.get("ANYLOC_GEMM", DEFAULT_GEMM),
-                    help="block GEMMs: x6 = exact 3-way bf16 split, six bf16 MFMA products, fp32 accumulate "
-                         "(fp32-level accuracy); f32 = fp32 MFMA")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0)
-    args = ap.parse_args()
-    os.environ["ANYLOC_GEMM"] = args.gemm
-
+def init_ranks(args):
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE); backend "nccl" = RCCL."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -95,7 +133,118 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    return world, rank, torch.device("cuda", torch.cuda.current_device()), dist
+
+
+def main_config3(args):
+    """BASELINE.json configs[2]: 10 000 query VLADs against a 1 M-row database sharded 125 000 rows (24.6 GB) per GPU.
+    One step = the whole retrieval: query descriptors all-gathered over RCCL, per-shard normalise + top-20 on the HIP
+    kernels, [Q,20] lists gathered to rank 0 and merged on the host (retrieval.sharded_search).  At N < 8 the database
+    is the first N shards (weak scaling: per-GPU work is fixed); ``value`` = queries/s of the whole job."""
+    world, rank, dev, dist = init_ranks(args)
+    _lib.load()
+    NQ, NSHARD, KC, D = 10000, 125000, K_CLUSTERS, 1536
+    steps, warm = args.steps, args.warmup
+    t_setup = time.time()
+    db = synthetic_db(NSHARD, KC, D, dev, seed=100 + rank)
+    nq_local = NQ // world + (1 if rank < NQ % world else 0)
+    qu = synthetic_db(nq_local, KC, D, dev, seed=500 + rank)
+    n_plant = min(64, nq_local)
+    rows = torch.arange(n_plant, device=dev) * 17 + 5                     # query j of this rank depicts row 17 j + 5 of its own shard
+    qu[:n_plant] = 0.9 * db[rows] + 0.1 * qu[:n_plant]
+    shard_base = rank * NSHARD
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+    results = []
+
+    def step():
+        if world == 1:
+            d, i = retrieval.search(db, qu, TOPK)
+            results.append((d, i))
+        else:
+            d, i = retrieval.sharded_search(db, shard_base, qu, TOPK, group=None)
+            if rank == 0:
+                results.append((d, i))
+
+    for _ in range(warm):
+        step()
+    results.clear()
+    ops.profile_enable(True)
+    ops.profile_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    prof = ops.profile_dump()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    idx = results[-1][1]
+    idx = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
+    want = (np.arange(n_plant) * 17 + 5)                                  # rank 0's planted queries come first in the merged order
+    planted_ok = bool((idx[:n_plant, 0] == want).all())
+    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = dom["ms"] / dom["calls"]
+    achieved = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
+    out = {
+        "metric": "queries/sec (10k query VLADs x 1M-row database sharded 125k rows per GPU, top-20)",
+        "value": round(steps * NQ / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warm,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: 10k query x 1M-row db (49152-d VLADs) sharded across the GPUs, "
+                               "RCCL all-gather of the queries + per-shard top-k + host merge",
+                   "queries": NQ, "db_rows_per_gpu": NSHARD, "db_rows_total": NSHARD * world, "vlad_dim": KC * D, "k": TOPK,
+                   "parallelism": f"db-shard{world}"},
+        "planted_neighbours_found": planted_ok, "setup_s": round(t_setup, 1),
+        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4),
+                     "launches": dom["calls"], "traffic": None,
+                     "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in
+                                             sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}},
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    if not planted_ok:
+        print("PARITY VIOLATION: planted neighbours not retrieved", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    # 61 images = 32 330 token rows = 252.6 row-tiles of 128: the 253 x {12,36,64} GEMM tile grids are
+    # within 1.2 % of whole multiples of the 512 resident thread blocks (2 per CU) -- no tail wave
+    ap.add_argument("--batch", type=int, default=61, help="query images per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", choices=["x6", "h3", "f32"], default=os.environ.get("ANYLOC_GEMM", DEFAULT_GEMM),
+                    help="block GEMMs: x6 = exact 3-way bf16 split, six bf16 MFMA products, fp32 accumulate "
+                         "(fp32-level accuracy); f32 = fp32 MFMA")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--no-modes", action="store_true", help="skip the short timings of the other two GEMM arithmetics")
+    ap.add_argument("--mode-steps", type=int, default=3, help="timed steps of each of the other GEMM arithmetics")
+    ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
+                    help="config2 (default): BASELINE.json configs[1], the bench line; config3: configs[2], retrieval of "
+                         "10 000 queries against a database sharded 125 000 rows per GPU")
+    args = ap.parse_args()
+    os.environ["ANYLOC_GEMM"] = args.gemm
+    if args.workload == "config3":
+        return main_config3(args)
+
+    world, rank, dev, dist = init_ranks(args)
     _lib.load()
     import utilities
     B, steps, warm = args.batch, args.steps, args.warmup
@@ -131,7 +280,7 @@ def main():
     def step(i):
         blk = i % n_blocks
         imgs = qu_img[blk * B:(blk + 1) * B]
-        tokens = ext(imgs)                                   # [B,529,1536] on device
+        tokens = ext(imgs)                                   # [B,529,1536] on device (ext: the current mode's extractor)
         q = vlad.generate_multi(tokens)                      # [B,49152]
         if world == 1:
             d, idx = retrieval.search(db, q, TOPK)           # normalise + top-k, device tensors
@@ -190,40 +339,7 @@ def main():
                     n += 1
         rec = retrieval.recalls_from_indices([1, 5, 10], idx_all, gt_timed)
 
-    # ---------------- roofline of the dominant kernel --------------------------------------
-    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-    avg_ms = dom["ms"] / dom["calls"]
-    achieved = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
-    gemm_ms = sum(v["ms"] for k, v in prof.items() if k.endswith("_gemm"))
-    gemm_fl = sum(v["flops"] for k, v in prof.items() if k.endswith("_gemm"))
-    kern_ms = sum(v["ms"] for v in prof.values())
-    products = {"x6": 6, "h3": 3}.get(args.gemm)      # matrix-core products per fp32-accurate product
-    x6 = products is not None and dom_name.endswith("_gemm") and dom_name != "vit_patch_embed_gemm"
-    # split modes: every algorithmic flop costs `products` bf16/fp16-MFMA flops, so the roofline of the fp32-accurate
-    # contraction is the dense 16-bit peak / products; `achieved` stays ALGORITHMIC flops / time in every mode.
-    peak = PEAK_BF16_MFMA_TFLOPS / products if x6 else PEAK_FP32_MFMA_TFLOPS
-    all_gemm = gemm_fl / (gemm_ms * 1e-3) / 1e12
-    e2e = value / world * flops_per_image() / 1e12
-    roofline = {
-        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
-        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "peak_note": ((f"dense 16-bit MFMA peak 2500 / {products} matrix-core products per fp32-accurate product (" +
-                       ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
-                      if x6 else "fp32 MFMA peak"),
-        "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "clock_note": ("profiles/r01_pmc_x6.md: under these GEMMs the chip runs at its power limit (1.63 GHz with the matrix "
-                       "cores busy 70.9 % of SIMD cycles for h3; 1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz "
-                       "figure") if x6 else None,
-        "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"], "traffic": None,
-        "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
-                      "vs_fp32_mfma_peak": round(all_gemm / PEAK_FP32_MFMA_TFLOPS, 4),
-                      "share_of_kernel_time": round(gemm_ms / kern_ms, 4)},
-        "end_to_end": {"algorithmic_tflops_per_image": round(flops_per_image() / 1e12, 4),
-                       "achieved": round(e2e, 2), "frac": round(e2e / peak, 4),
-                       "vs_fp32_mfma_peak": round(e2e / PEAK_FP32_MFMA_TFLOPS, 4)},
-        "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in
-                                sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
-    }
+    roofline = roofline_of(prof, args.gemm, value / world, steps)
 
     out = {
         "metric": "images/sec (DINOv2->VLAD->top-k), ViT-G/14 L31 value K=32", "value": round(value, 3),
@@ -243,11 +359,67 @@ def main():
     }
 
     # ---------------- CPU baseline + parity on a bounded sample (N=1 only) -----------------
+    # ---------------- the other two GEMM arithmetics, timed briefly in the same run (N=1) -------
+    if world == 1 and not args.no_modes:
+        modes = {args.gemm: {"value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+                             "frac": roofline["frac"], "peak": roofline["peak"], "achieved": roofline["achieved"],
+                             "end_to_end_frac": roofline["end_to_end"]["frac"]}}
+        for mode in ("h3", "x6", "f32"):
+            if mode == args.gemm:
+                continue
+            os.environ["ANYLOC_GEMM"] = mode
+            ext_m = utilities.DinoV2ExtractFeatures(MODEL, LAYER, FACET, device=str(dev))
+            ext_prev, ext = ext, ext_m
+            try:
+                step(0)
+                results.clear()
+                ops.profile_enable(True)
+                ops.profile_reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.mode_steps):
+                    step(warm + i)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                ops.profile_enable(False)
+                r = roofline_of(ops.profile_dump(), mode, args.mode_steps * B / el, args.mode_steps)
+                modes[mode] = {"value": round(args.mode_steps * B / el, 3), "ms_per_step": round(el / args.mode_steps * 1e3, 3),
+                               "steps": args.mode_steps, "frac": r["frac"], "peak": r["peak"], "achieved": r["achieved"],
+                               "end_to_end_frac": r["end_to_end"]["frac"], "kernel": r["kernel"]}
+            finally:
+                ext = ext_prev
+                del ext_m
+                results.clear()
+        os.environ["ANYLOC_GEMM"] = args.gemm
+        out["modes"] = modes
+
+    failed = None
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_and_parity(sd, qu_img, vlad, db, ext, args.cpu_seconds, warm, B))
+        failed = parity_violation(out["parity"])
+        out["parity"]["ok"] = failed is None
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        print(f"PARITY VIOLATION: {failed}", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def parity_violation(p):
+    """north_star bar on the bench's own oracle sample: tokens <= 2e-5, VLAD <= 1e-5, cluster ids identical except at
+    oracle ties (< 1e-6 top-2 gap), top-1 identical, top-k indices identical for images without a tie flip."""
+    if p["token_max_abs_err"] > 2e-5:
+        return f"token error {p['token_max_abs_err']:.3e} > 2e-5"
+    if p["vlad_max_rel_err"] is not None and p["vlad_max_rel_err"] > 1e-5:
+        return f"VLAD relative error {p['vlad_max_rel_err']:.3e} > 1e-5"
+    if p["label_mismatches"] and p["largest_oracle_gap_of_a_mismatch"] >= 1e-6:
+        return f"cluster-id mismatch at an oracle gap of {p['largest_oracle_gap_of_a_mismatch']:.3e}"
+    if not p["top1_equal"]:
+        return "top-1 differs from the oracle"
+    if p["topk_index_mismatches_in_clean_images"]:
+        return f"{p['topk_index_mismatches_in_clean_images']} top-k indices differ in images without a tie flip"
+    return None
 
 
 def cpu_baseline_and_parity(sd, qu_img, vlad, db, ext, budget_s, warm, B):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 1
+#define ANYLOC_ABI_VERSION 2
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -129,6 +129,15 @@ int anyloc_layernorm(const float* x, float* y, const float* weight, const float*
                      int64_t rows, int64_t dim, float eps, void* stream);
 int anyloc_attention(const float* qkv, float* out, int64_t batch, int64_t tokens,
                      int64_t dim, int64_t heads, void* stream);
+/* The attention of the two-term fp16 ("h3") forward, exposed for unit tests: the same
+ * softmax((q/8) k^T) v from a packed fp32 QKV buffer, computed as three fp16 matrix-core
+ * products per contraction on per-(head, 32-row group) scaled operand tiles, and written
+ * as the two-plane fp16 image + per-row 2^-e that anyloc_gemm_nt_h3 takes as its A operand
+ * (out_img: anyloc_h2_bytes(batch*tokens, dim) bytes, out_inv: batch*tokens floats). */
+size_t anyloc_attention_h3_workspace_bytes(int64_t batch, int64_t tokens, int64_t heads);
+int anyloc_attention_h3(const float* qkv, void* out_img, float* out_inv, int64_t batch,
+                        int64_t tokens, int64_t dim, int64_t heads, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------- VLAD ----
  * Hard-assignment VLAD of `n_img` images in one call.
@@ -143,9 +152,12 @@ int anyloc_attention(const float* qkv, float* out, int64_t batch, int64_t tokens
  * flags: ANYLOC_VLAD_NORM_DESCS re-normalises tokens before the residual
  *   (utilities.py:959-960); ANYLOC_VLAD_INTRA_NORM normalises each cluster
  *   block (:859-860).  Labels are argmax_k of the fast-pytorch-kmeans cosine
- *   score of the tokens as passed (:849) -- ties -> lowest k. */
+ *   score of the tokens as passed (:849) -- ties -> lowest k; with
+ *   ANYLOC_VLAD_EUCLIDEAN, of its euclidean similarity 2ab - a^2 - b^2 (the metric
+ *   kmeans.predict uses when the VLAD object was built with dist_mode="euclidean"). */
 #define ANYLOC_VLAD_NORM_DESCS 1u
 #define ANYLOC_VLAD_INTRA_NORM 2u
+#define ANYLOC_VLAD_EUCLIDEAN 4u   /* labels by the fpk euclidean similarity (VLAD(dist_mode="euclidean")) instead of cosine */
 size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img,
                                    int64_t D, int64_t K);
 int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
@@ -256,6 +268,11 @@ typedef struct anyloc_vit_block_h2 {
   const void* proj_w2; const float* proj_inv;
   const void* fc1_w2;  const float* fc1_inv;
   const void* fc2_w2;  const float* fc2_inv;
+  /* Bounds that let the fc1 epilogue quantise the FFN activation for fc2 without an fp32 round trip
+   * (|fc1_j(y)| <= ||y||_2 max_j ||W_j||_2 + max_j |b_j|):  {max gate-row (mlp: fc1-row) L2 norm, max |gate bias|,
+   * max value-row L2 norm, max |value bias|}; the value pair is 0 for the GELU mlp.  All zero = not provided: the
+   * activation is then written as fp32 and quantised by a separate pass. */
+  float fc1_bound[4];
 } anyloc_vit_block_h2;
 int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*host array [depth]*/);
 #define ANYLOC_VIT_SPLIT_FP16 16u    /* block GEMMs as three fp16 products, fp32-level accuracy */

@@ -42,13 +42,15 @@ def install(monkeypatch):
     monkeypatch.setattr(_lib, "require_gpu", lambda: cpu)
     monkeypatch.setattr(ops, "l2norm_rows", lambda x, eps=1e-12, out=None: F.normalize(x.float(), dim=-1, eps=eps))
 
-    def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0, return_labels=False):
+    def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0, return_labels=False,
+             dist_mode="cosine"):
         parts = list(tokens) if not isinstance(tokens, torch.Tensor) else list(tokens if tokens.ndim == 3 else tokens[None])
         outs, labs = [], []
         for t in parts:
             t = torch.as_tensor(t).float()
             if mode == "hard":
-                v, l = vlad_ref.vlad_hard(t, centers.float(), norm_descs, intra_norm)
+                lab = None if dist_mode == "cosine" else fpk_kmeans.KMeans.euc_sim(t, centers.float()).max(dim=-1)[1]
+                v, l = vlad_ref.vlad_hard(t, centers.float(), norm_descs, intra_norm, labels=lab)
                 labs.append(l)
             else:
                 v, _ = vlad_ref.vlad_soft(t, centers.float(), soft_temp, norm_descs, intra_norm)

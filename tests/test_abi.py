@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.anyloc_version() == 1
+    assert lib.anyloc_version() == 2      # ANYLOC_ABI_VERSION of include/anyloc_hip.h
     assert isinstance(lib.anyloc_last_error(), bytes)
 
 

@@ -91,6 +91,35 @@ def test_attention(dev, B, T, heads, kernel, monkeypatch):
     assert _rel(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("B,T,heads", [(2, 257, 6), (1, 530, 24), (3, 33, 2), (1, 128, 1), (2, 1370, 2), (5, 530, 4)])
+def test_attention_h3(dev, B, T, heads):
+    """The attention kernel of the two-term fp16 forward (anyloc_attention_h3: per-(head, 32-row group) scaled fp16
+    tiles, three matrix-core products per contraction, output written as the h2 image of the projection GEMM)
+    against float64.  Tokens of very different magnitude share 32-row groups and images share groups (T % 32 != 0)."""
+    from anyloc_amd import ops
+    D = heads * 64
+    g = torch.Generator().manual_seed(B * T + heads)
+    qkv = torch.randn(B, T, 3 * D, generator=g) * 1.5
+    qkv[0, 3, :D] *= 6.0
+    qkv[0, T - 2, D:2 * D] *= 6.0
+    qkv[:, ::7] *= 0.05                                   # small-magnitude tokens next to ordinary ones
+    qkv[:, 5, 2 * D:] *= 40.0                             # one value row far above the others (sets the image scale)
+    img, inv = ops.attention_h3(qkv.to(dev), heads)
+    out = ops.h2_image_to_f32(img, inv, B * T, D).reshape(B, T, D).cpu()
+    q, k, v = qkv.double().reshape(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q * 0.125) @ k.transpose(-2, -1), dim=-1)
+    ref = (a @ v).transpose(1, 2).reshape(B, T, D)
+    # every row of an image carries 22 bits relative to the image's largest |v|: error <= 2^-22 of that bound
+    vmax = qkv[:, :, 2 * D:].abs().amax(dim=(1, 2)).double()
+    err = (out - ref).abs().amax(dim=(1, 2))
+    assert bool((err <= 3e-6 * vmax + 2e-6).all()), (err, vmax)
+    assert _rel(out, ref) < 5e-6
+    assert bool(torch.isfinite(out).all())
+    inv_c = inv.cpu().reshape(B, T)
+    assert bool((inv_c == inv_c[:, :1]).all())            # one power-of-two scale per image
+    assert bool((torch.log2(inv_c) == torch.log2(inv_c).round()).all())
+
+
 @pytest.mark.parametrize("H,W", [(224, 224), (333, 481), (126, 155)])
 def test_preprocess_u8_matches_totensor_normalize_centercrop(dev, H, W):
     """uint8 HWC -> float CHW ingest == ToTensor + Normalize + CenterCrop(h//14*14, w//14*14), bit-exact."""

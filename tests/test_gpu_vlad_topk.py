@@ -81,6 +81,40 @@ def test_vlad_hard_vs_oracle_flags_and_ragged(K, D, N):
         assert l2rel(out[i], vlad_ref.vlad_hard(parts[i], centers)[0]) < VLAD_RTOL
 
 
+@pytest.mark.parametrize("K,D,N", [(32, 1536, 529), (16, 384, 300), (40, 512, 257)])
+def test_vlad_hard_euclidean_assignment(K, D, N):
+    """VLAD(dist_mode='euclidean'): labels = kmeans.predict(tokens) with fpk's euclidean similarity on the tokens as
+    passed (reference utilities.py:849 with self.mode = 'euclidean'), on the fused kernel (D=1536/384) and on the
+    two-pass path (D=512).  Tokens are NOT unit norm, so the euclidean and the cosine assignment differ."""
+    import utilities
+    from anyloc_amd import ops
+    from oracle.fpk_kmeans import KMeans as RefKM
+    g = torch.Generator().manual_seed(K + D + N)
+    x = synth.clustered_tokens(3, N, D, n_modes=K, seed=K + N) * (0.3 + 1.4 * torch.rand(3, N, 1, generator=g))
+    centers = synth.clustered_tokens(1, K, D, n_modes=K, seed=K + N)[0] * (0.4 + torch.rand(K, 1, generator=g))
+    out, lab = ops.vlad(x.to(DEV), centers.to(DEV), return_labels=True, dist_mode="euclidean")
+    lab = lab.cpu().reshape(3, N)
+    n_diff_metric = 0
+    for i in range(3):
+        sim = RefKM.euc_sim(x[i], centers)
+        ref_lab = sim.max(dim=-1)[1]
+        bad = (lab[i] != ref_lab).nonzero().flatten()
+        if len(bad):      # tolerated only at fp32 ties of the oracle's own similarity (values are O(1))
+            top2 = sim[bad].topk(2, dim=1)[0]
+            assert float((top2[:, 0] - top2[:, 1]).max()) < 2e-6
+        v = vlad_ref.vlad_hard(x[i], centers, labels=lab[i])[0]
+        assert l2rel(out[i], v) < VLAD_RTOL
+        n_diff_metric += int((ref_lab != vlad_ref.hard_labels(x[i], centers)).sum())
+    assert n_diff_metric > 0                               # the case really separates the two metrics
+    # through the class surface: VLAD(dist_mode="euclidean").generate == the same labels
+    vl = utilities.VLAD(K, D, dist_mode="euclidean", cache_dir=None)
+    vl.c_centers = centers
+    vl.kmeans = utilities.KMeans(K, mode="euclidean")
+    vl.kmeans.centroids = centers
+    assert l2rel(vl.generate(x[0]), out[0]) < 1e-6
+    assert torch.equal(vl.kmeans.predict(x[0]), lab[0])
+
+
 def test_vlad_soft_vs_oracle():
     from anyloc_amd import ops
     K, D, N = 8, 384, 256
