@@ -120,8 +120,14 @@ struct GemmProblem {
   int patches;           // EPI_PATCH: patches per image (T = patches + 1)
   float* rowsq;          // optional: rowsq[m] = sum_k A[m,k]^2 (written by the n-block 0 column)
   const char* tag;       // profiling label
+  // split-K (gemm_nt_splitk): K is the SLICE length, slice s contracts columns [s K, (s+1) K) of both operands (row
+  // strides lda / ldw unchanged) into C + s * c_split_stride (and rowsq + s * M): the caller sums the slices
+  int ksplit; int64_t c_split_stride;
 };
 int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream);
+// C_s[M, N<=64] = A[:, slice s] W[:, slice s]^T for s < ksplit in ONE launch (grid.y = slice) on 128 x 64 tiles, with the
+// partial row sums of squares of A: few-query retrieval, where a plain GEMM would have too few tiles to stream HBM
+int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {

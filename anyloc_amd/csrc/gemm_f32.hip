@@ -98,6 +98,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  if (p.ksplit > 1) {                     // split-K: this block contracts K-slice blockIdx.y into its own output slab
+    const int64_t sl = blockIdx.y;
+    p.A += sl * p.K;
+    p.W += sl * p.K;
+    p.C += sl * p.c_split_stride;
+    if (ROWSQ) p.rowsq += sl * p.M;
+  }
   int tile_m, tile_n;
   tile_coords(blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
@@ -371,10 +378,12 @@ int launch_cfg(const GemmProblem& p, hipStream_t stream) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
-  const double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+  const double ks = p.ksplit > 1 ? p.ksplit : 1;
+  const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K * ks;
+  const double bytes = 4.0 * (((double)p.M * p.K + (double)p.N * p.K) * ks + (double)p.M * p.N * ks);
   ProfScope prof(p.tag ? p.tag : "gemm_nt", stream, flops, bytes);
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, stream, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, p.ksplit > 1 ? p.ksplit : 1), dim3(64 * WM * WN), lds, stream, p, tiles_m,
+                     tiles_n);
   return launch_status("gemm_nt_kernel");
 }
 
@@ -477,6 +486,16 @@ int launch_wide_k(const GemmProblem& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(p.A && p.W && p.C && p.rowsq, "gemm_nt_splitk: null operand");
+  ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.N <= 64 && p.K > 0 && p.K % 32 == 0 && p.ksplit >= 1 && p.ksplit < 65536,
+                   "gemm_nt_splitk: needs N <= 64, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
+  ANYLOC_CHECK_ARG(p.lda % 4 == 0 && p.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(p.W) & 15) == 0,
+                   "gemm_nt_splitk: operands must be 16-byte aligned with row strides that are multiples of 4");
+  return launch_cfg<128, 64, 4, 1, 32, 2, EPI_STORE, true, true>(p, stream);
+}
 
 int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream) {
   ANYLOC_CHECK_ARG(p.A && p.W && p.C, "gemm_nt: null operand");

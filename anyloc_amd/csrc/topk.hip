@@ -43,9 +43,12 @@ __global__ __launch_bounds__(256) void rownorm_sq_kernel(const float* __restrict
 
 // One block per query.  Running list (best first) lives in run_v/run_i [nq,k]; `first` != 0
 // initialises it to (-inf, -1).  metric 1: candidate value = -(qn + dn - 2 ip).
+// dnorm != nullptr: the database rows were scored RAW and are normalised here, score / dnorm[col]
+// (dnorm = max(||row||, 1e-12): F.normalize of the row, reference utilities.py:436, without a normalised copy).
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, int64_t ld, int64_t ncols,
                                                          int64_t col_base, int k, int metric,
                                                          const float* __restrict__ qn, const float* __restrict__ dn,
+                                                         const float* __restrict__ dnorm,
                                                          float* __restrict__ run_v, long long* __restrict__ run_i,
                                                          int first) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
       float v = -INFINITY;
       if (i < nc) {
         v = srow[c0 + i];
+        if (dnorm) v = v / dnorm[c0 + i];
         if (metric) v = -((qq + dn[c0 + i]) - 2.0f * v);
       }
       cv[i] = v;
@@ -117,6 +121,42 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
   }
 }
 
+// raw sums of squares -> dnorm = max(sqrt(ss), 1e-12) (F.normalize's denominator) and, for the L2 metric, the squared
+// norm of the normalised row dn = ss / dnorm^2
+__global__ void dbnorm_kernel(const float* __restrict__ ss, int64_t n, float* __restrict__ dnorm, float* __restrict__ dn) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float d = fmaxf(sqrtf(ss[i]), 1e-12f);
+  dnorm[i] = d;
+  dn[i] = (ss[i] / d) / d;
+}
+
+// few-query path: sum the split-K slices of C_s[row, 0..63] (and of the row sums of squares) in slice order and write
+// the [nq, ncols] score panel the merge kernel reads, plus the raw sum of squares of every database row
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ part, const float* __restrict__ rsq_part,
+                                                             int S, int64_t rows, int nq, float* __restrict__ scores,
+                                                             float* __restrict__ ss) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= rows) return;
+  float acc[64];
+#pragma unroll
+  for (int q = 0; q < 64; ++q) acc[q] = 0.f;
+  float r = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const f32x4* pr = reinterpret_cast<const f32x4*>(part + ((int64_t)s * rows + j) * 64);
+#pragma unroll
+    for (int q4 = 0; q4 < 16; ++q4) {
+      const f32x4 v = pr[q4];
+      acc[4 * q4] += v[0]; acc[4 * q4 + 1] += v[1]; acc[4 * q4 + 2] += v[2]; acc[4 * q4 + 3] += v[3];
+    }
+    r += rsq_part[(int64_t)s * rows + j];
+  }
+  ss[j] = r;
+#pragma unroll
+  for (int q = 0; q < 64; ++q)
+    if (q < nq) scores[(int64_t)q * rows + j] = acc[q];
+}
+
 // metric 1: stored values are negated squared distances -> flip sign; padding -> +inf
 __global__ void topk_finish_kernel(float* __restrict__ v, const long long* __restrict__ idx, int64_t n, int metric) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -124,17 +164,40 @@ __global__ void topk_finish_kernel(float* __restrict__ v, const long long* __res
   if (metric) v[i] = idx[i] < 0 ? INFINITY : -v[i];
 }
 
+// few queries (<= 64) against long rows: a [nq, panel] GEMM has too few tiles to stream the database, so the panel is
+// scored by a split-K launch with the database as the M operand (gemm_nt_splitk)
+constexpr int SPLITK_MAX = 16;
+bool few_queries(int64_t nq, int64_t dim) { return nq <= 64 && dim % 32 == 0 && dim >= 4096; }
+// number of K slices: a divisor of dim/32 that fills the 512 resident workgroups (2 per CU) best, slices >= 1024 long
+int choose_ksplit(int64_t rows, int64_t dim) {
+  const int64_t tiles = (rows + 127) / 128, kb = dim / 32;
+  int best = 1;
+  double best_u = 0.0;
+  for (int s = 1; s <= SPLITK_MAX; ++s) {
+    if (kb % s != 0 || dim / s < 1024) continue;
+    const int64_t blocks = tiles * s;
+    const double u = (double)blocks / (double)((blocks + 511) / 512 * 512) * (blocks >= 256 ? 1.0 : (double)blocks / 256.0);
+    if (u > best_u + 1e-9) { best_u = u; best = s; }
+  }
+  return best;
+}
+
 struct TopkWs {
-  float *scores, *qn, *dn;
+  float *scores, *qn, *dn, *dss, *dnorm, *part, *rsq_part;
   size_t bytes;
 };
-TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb) {
+TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim) {
   Arena a(ws, cap);
   TopkWs w;
   const int64_t panel = std::min<int64_t>(PANEL, std::max<int64_t>(ndb, 1));
   w.scores = a.take<float>(std::max<int64_t>(nq, 1) * panel);
   w.qn = a.take<float>(std::max<int64_t>(nq, 1));
   w.dn = a.take<float>(std::max<int64_t>(ndb, 1));
+  w.dss = a.take<float>(std::max<int64_t>(ndb, 1));
+  w.dnorm = a.take<float>(std::max<int64_t>(ndb, 1));
+  const bool few = few_queries(nq, dim);
+  w.part = a.take<float>(few ? (size_t)SPLITK_MAX * panel * 64 : 1);
+  w.rsq_part = a.take<float>(few ? (size_t)SPLITK_MAX * panel : 1);
   w.bytes = a.off;
   return w;
 }
@@ -147,12 +210,12 @@ using namespace anyloc;
 extern "C" {
 
 size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k) {
-  (void)dim; (void)k;
-  return carve(nullptr, 0, nq, ndb).bytes + 256;
+  (void)k;
+  return carve(nullptr, 0, nq, ndb, dim).bytes + 256;
 }
 
 int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, int64_t dim, int64_t k, int metric,
-                int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
+                unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
                 void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ANYLOC_CHECK_ARG(nq >= 0 && ndb >= 0, "topk: negative size");
@@ -163,7 +226,10 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
   ANYLOC_CHECK_ARG(metric == 0 || metric == 1, "topk: metric %d", metric);
   ANYLOC_CHECK_ARG(dim >= 4 && dim % 4 == 0, "topk: dim %lld must be a positive multiple of 4", (long long)dim);
   ANYLOC_CHECK_ARG(nq < (1ll << 31), "topk: too many queries");
-  TopkWs w = carve(workspace, workspace_bytes, nq, ndb);
+  ANYLOC_CHECK_ARG((flags & ~ANYLOC_TOPK_NORMALIZE_DB) == 0, "topk: unknown flags %u", flags);
+  TopkWs w = carve(workspace, workspace_bytes, nq, ndb, dim);
+  const bool norm_db = (flags & ANYLOC_TOPK_NORMALIZE_DB) != 0;
+  const bool few = few_queries(nq, dim);
   if (!workspace || w.bytes > workspace_bytes) {
     set_error("topk: workspace %zu < %zu", workspace_bytes, w.bytes);
     return ANYLOC_ERR_WORKSPACE;
@@ -179,10 +245,18 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
   if (metric == 1) {
     hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)nq), dim3(256), 0, stream, queries, dim, w.qn);
     ANYLOC_TRY(launch_status("rownorm_sq_kernel(q)"));
+  }
+  if ((metric == 1 || norm_db) && !few) {       // (the few-query path gets the row sums of squares from its GEMM)
+    ProfScope prof("topk_db_norms", stream, 2.0 * ndb * dim, 4.0 * ndb * dim);
+    float* ss = norm_db ? w.dss : w.dn;
     for (int64_t r0 = 0; r0 < ndb; r0 += (1ll << 30)) {
       const int64_t cnt = std::min<int64_t>(1ll << 30, ndb - r0);
-      hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, db + r0 * dim, dim, w.dn + r0);
+      hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, db + r0 * dim, dim, ss + r0);
       ANYLOC_TRY(launch_status("rownorm_sq_kernel(db)"));
+    }
+    if (norm_db && ndb > 0) {
+      hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((ndb + 255) / 256)), dim3(256), 0, stream, w.dss, ndb, w.dnorm, w.dn);
+      ANYLOC_TRY(launch_status("dbnorm_kernel"));
     }
   }
   long long* idx_ll = reinterpret_cast<long long*>(idx);
@@ -190,22 +264,45 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
   if (ndb == 0) {
     // nothing to search: emit the padding list
     hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.scores, (int64_t)0,
-                       (int64_t)0, index_base, (int)k, metric, w.qn, w.dn, dist, idx_ll, 1);
+                       (int64_t)0, index_base, (int)k, metric, w.qn, w.dn, (const float*)nullptr, dist, idx_ll, 1);
     ANYLOC_TRY(launch_status("topk_merge_kernel"));
   }
   for (int64_t c0 = 0; c0 < ndb; c0 += PANEL) {
     const int64_t pc = std::min<int64_t>(PANEL, ndb - c0);
     GemmProblem g{};
-    g.A = queries; g.lda = dim;
-    g.W = db + c0 * dim; g.ldw = dim;
-    g.C = w.scores; g.ldc = pc;
-    g.M = nq; g.N = pc; g.K = dim;
     g.tag = "topk_scores_gemm";
-    ANYLOC_TRY(gemm_nt(g, EPI_STORE, stream));
+    if (few) {
+      // database rows as the M operand, the (<= 64) queries as N, K cut into slices: enough workgroups to stream the
+      // panel at HBM rate; the row sums of squares of the database come out of the same pass
+      const int S = choose_ksplit(pc, dim);
+      g.A = db + c0 * dim; g.lda = dim;
+      g.W = queries; g.ldw = dim;
+      g.C = w.part; g.ldc = 64;
+      g.M = pc; g.N = nq; g.K = dim / S;
+      g.ksplit = S; g.c_split_stride = pc * 64;
+      g.rowsq = w.rsq_part;
+      ANYLOC_TRY(gemm_nt_splitk(g, stream));
+      ProfScope prof("topk_combine", stream, (double)S * pc * 64, 4.0 * ((double)S * pc * 65 + (double)nq * pc));
+      hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, w.part, w.rsq_part, S,
+                         pc, (int)nq, w.scores, (norm_db ? w.dss : w.dn) + c0);
+      ANYLOC_TRY(launch_status("splitk_combine_kernel"));
+      if (norm_db) {
+        hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, w.dss + c0, pc, w.dnorm + c0,
+                           w.dn + c0);
+        ANYLOC_TRY(launch_status("dbnorm_kernel"));
+      }
+    } else {
+      g.A = queries; g.lda = dim;
+      g.W = db + c0 * dim; g.ldw = dim;
+      g.C = w.scores; g.ldc = pc;
+      g.M = nq; g.N = pc; g.K = dim;
+      ANYLOC_TRY(gemm_nt(g, EPI_STORE, stream));
+    }
     {
       ProfScope prof("topk_merge", stream, 0.0, 4.0 * nq * pc);
       hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.scores, pc, pc,
-                         index_base + c0, (int)k, metric, w.qn, w.dn + c0, dist, idx_ll, first);
+                         index_base + c0, (int)k, metric, w.qn, w.dn + c0, norm_db ? w.dnorm + c0 : (const float*)nullptr, dist,
+                         idx_ll, first);
       ANYLOC_TRY(launch_status("topk_merge_kernel"));
     }
     first = 0;

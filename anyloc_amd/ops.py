@@ -262,8 +262,12 @@ def kmeans_step(x, centers, mode="cosine", want_labels=False):
     return sums, counts, labels
 
 
-def topk(queries, db, k, metric="ip", index_base=0):
-    """Exact top-k of db rows for every query: (dist [nq,k] f32, idx [nq,k] i64), best first."""
+TOPK_NORMALIZE_DB = 1
+
+
+def topk(queries, db, k, metric="ip", index_base=0, normalize_db=False):
+    """Exact top-k of db rows for every query: (dist [nq,k] f32, idx [nq,k] i64), best first.
+    ``normalize_db``: score against F.normalize(db) without materialising it (ANYLOC_TOPK_NORMALIZE_DB)."""
     _need_cuda(queries, db)
     queries, db = _f32c(queries), _f32c(db)
     nq, dim = queries.shape
@@ -274,7 +278,8 @@ def topk(queries, db, k, metric="ip", index_base=0):
     ws_bytes = lib.anyloc_topk_workspace_bytes(nq, ndb, dim, k)
     ws = _lib.workspace(ws_bytes, queries.device, "topk")
     _lib.check(lib.anyloc_topk(_lib.ptr(queries), nq, _lib.ptr(db), ndb, dim, k,
-                               0 if metric == "ip" else 1, index_base, _lib.ptr(dist), _lib.ptr(idx),
+                               0 if metric == "ip" else 1, TOPK_NORMALIZE_DB if normalize_db else 0, index_base,
+                               _lib.ptr(dist), _lib.ptr(idx),
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_topk")
     return dist, idx
 

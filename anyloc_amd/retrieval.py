@@ -34,15 +34,17 @@ def search(db, qu, k, method="cosine", norm_descs=True):
     """Normalise (optionally) and search: returns device tensors (dist, idx)."""
     dev = _lib.require_gpu()
     db_d, qu_d = ops._f32c(db, dev), ops._f32c(qu, dev)
-    if norm_descs:
-        db_d, qu_d = ops.l2norm_rows(db_d), ops.l2norm_rows(qu_d)
     if method == "cosine":
         metric = "ip"
     elif method == "l2":
         metric = "l2"
     else:
         raise NotImplementedError(f"Method: {method}")
-    return ops.topk(qu_d, db_d, int(k), metric)
+    if norm_descs:
+        # F.normalize of both sides (reference utilities.py:436-437): the queries are normalised here, the database
+        # rows inside the search (their norms come out of the scoring pass; no normalised copy of the database)
+        qu_d = ops.l2norm_rows(qu_d)
+    return ops.topk(qu_d, db_d, int(k), metric, normalize_db=bool(norm_descs))
 
 
 def get_top_k_recall(top_k: List[int], db: torch.Tensor, qu: torch.Tensor, gt_pos: np.ndarray,

@@ -194,10 +194,16 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
  *   metric 0: inner product, best = largest;  1: squared L2, best = smallest.
  *   dist [nq,k] fp32 and idx [nq,k] int64, best first; idx = index_base + row.
  *   If k > ndb the tail is padded with idx -1 (faiss behaviour).
- *   Ties are broken towards the lower database index. */
+ *   Ties are broken towards the lower database index.
+ *   flags: ANYLOC_TOPK_NORMALIZE_DB -- the database is given RAW and every row is used as
+ *   row / max(||row||_2, 1e-12), i.e. the F.normalize(db) of utilities.py:436 is applied to the
+ *   scores instead of materialising a normalised copy of the database (queries are taken as given).
+ *   With <= 64 queries of >= 4096 dimensions the database is streamed once by a split-K launch
+ *   (HBM-bound); otherwise scores are fp32-MFMA GEMM panels (MFMA-bound). */
+#define ANYLOC_TOPK_NORMALIZE_DB 1u
 size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k);
 int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb,
-                int64_t dim, int64_t k, int metric, int64_t index_base,
+                int64_t dim, int64_t k, int metric, unsigned flags, int64_t index_base,
                 float* dist, int64_t* idx, void* workspace,
                 size_t workspace_bytes, void* stream);
 

@@ -81,6 +81,7 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "vlad", vlad)
     monkeypatch.setattr(ops, "kmeans_step", kmeans_step)
     monkeypatch.setattr(kmeans, "_local_step", kmeans_step)
-    monkeypatch.setattr(ops, "topk", lambda q, db, k, metric="ip", index_base=0:
-                        faiss_flat.flat_search(q.float(), db.float(), k, metric))
+    monkeypatch.setattr(ops, "topk", lambda q, db, k, metric="ip", index_base=0, normalize_db=False:
+                        faiss_flat.flat_search(q.float(), F.normalize(db.float(), dim=-1) if normalize_db else db.float(),
+                                               k, metric))
     monkeypatch.setattr(extractor, "HipDinoV2", OracleDinoV2)

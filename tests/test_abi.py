@@ -39,7 +39,7 @@ def test_version_and_error_string(lib):
 
 def test_argument_validation_needs_no_gpu(lib):
     # invalid arguments are rejected before any HIP call
-    st = lib.anyloc_topk(None, 4, None, 4, 7, 1, 0, 0, None, None, None, 0, None)
+    st = lib.anyloc_topk(None, 4, None, 4, 7, 1, 0, 0, 0, None, None, None, 0, None)
     assert st == -1 and b"topk" in lib.anyloc_last_error()
     st = lib.anyloc_vlad_hard(None, None, 1, 0, 16, None, 4, 3, None, None, None, 0, None)
     assert st == -1

@@ -227,6 +227,42 @@ def test_topk_vs_oracle(nq, ndb, dim, k, metric):
     assert torch.equal(torch.where(i2.cpu() >= 0, i2.cpu() - 1000, i2.cpu()), i)
 
 
+@pytest.mark.parametrize("nq,ndb,dim,k,metric", [(61, 3000, 4096, 20, "ip"), (61, 3000, 4096, 20, "l2"), (64, 700, 8192, 7, "ip"),
+                                                  (1, 130, 49152, 20, "ip"), (5, 33000, 4096, 20, "ip"),
+                                                  (200, 2000, 4096, 10, "ip"), (9, 103, 64, 12, "l2")])
+def test_topk_normalize_db_vs_oracle(nq, ndb, dim, k, metric):
+    """ANYLOC_TOPK_NORMALIZE_DB: the database is passed RAW and F.normalize(db) (reference utilities.py:436) is applied to
+    the scores.  Covers the few-query split-K path (<= 64 queries, dim >= 4096: database rows as the GEMM's M operand,
+    row norms from the same pass, several panels) and the panel-GEMM path, against normalise-then-flat-search."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(nq + ndb + dim)
+    db = torch.randn(ndb, dim, generator=g) * (0.2 + 3.0 * torch.rand(ndb, 1, generator=g))   # norms all over the place
+    qu = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g))
+    db[11] = 0.0                                        # a zero row stays zero under F.normalize
+    db[40] = 2.5 * db[7]                                # same direction, different norm: an exact tie after normalising?
+    qu[0] = torch.nn.functional.normalize(db[7], dim=0)
+    d, i = ops.topk(qu.to(DEV), db.to(DEV), k, metric, normalize_db=True)
+    dbn = torch.nn.functional.normalize(db)
+    d_ref, i_ref = faiss_flat.flat_search(qu, dbn, k, metric)
+    d64 = qu.double() @ torch.nn.functional.normalize(db.double()).t()
+    if metric == "l2":
+        d64 = 2.0 - 2.0 * d64
+        d64[:, 11] = 1.0                                # |q|^2 + 0 - 0 for the zero row
+    d, i = d.cpu(), i.cpu()
+    kk = min(k, ndb)
+    got64 = torch.gather(d64, 1, i[:, :kk])
+    np.testing.assert_allclose(d[:, :kk].double().numpy(), got64.numpy(), atol=3e-6)      # each distance is the true one
+    mism = i[:, :kk] != i_ref[:, :kk]
+    if mism.any():                                      # only near-ties may swap
+        assert float((d_ref[:, :kk][mism] - d[:, :kk][mism]).abs().max()) < 1e-5
+    assert {int(i[0, 0]), int(i[0, 1])} == {7, 40}      # the two rows of the query's own direction come first
+    assert bool((d[:, :kk - 1] >= d[:, 1:kk]).all()) if metric == "ip" else bool((d[:, :kk - 1] <= d[:, 1:kk]).all())
+    # identical to normalising first and searching without the flag, up to fp32 noise
+    d2, i2 = ops.topk(qu.to(DEV), dbn.to(DEV), k, metric)
+    assert float((d2.cpu()[:, :kk] - d[:, :kk]).abs().max()) < 5e-6
+    assert float((i2.cpu()[:, :kk] != i[:, :kk]).float().mean()) < 0.02
+
+
 def test_get_top_k_recall_surface():
     import utilities
     g = torch.Generator().manual_seed(5)
