@@ -57,6 +57,8 @@ SIGNATURES = {
     "anyloc_l2norm_rows": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),
     "anyloc_preprocess_u8": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(C.c_float),
                                        C.POINTER(C.c_float), c_f32p, C.c_void_p]),
+    "anyloc_resize_bicubic": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32p,
+                                        C.c_void_p]),
     "anyloc_pool_tokens": (C.c_int, [c_f32p, C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.c_float, c_f32p, C.c_void_p]),
     "anyloc_x3_bytes": (C.c_size_t, [c_i64, c_i64]),
     "anyloc_split_x3": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
@@ -76,6 +78,11 @@ SIGNATURES = {
                                    c_f32p, c_i64p, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vlad_soft": (C.c_int, [c_f32p, c_i64p, c_i64, c_i64, c_i64, c_f32p, c_i64, C.c_float,
                                    C.c_uint, c_f32p, C.c_void_p, c_sz, C.c_void_p]),
+    "anyloc_vlad_soft_weights": (C.c_int, [c_f32p, c_i64, c_i64, c_f32p, c_i64, C.c_float, c_f32p, C.c_void_p, c_sz,
+                                           C.c_void_p]),
+    "anyloc_vlad_residuals": (C.c_int, [c_f32p, c_i64, c_i64, c_f32p, c_i64, C.c_uint, c_f32p, C.c_void_p]),
+    "anyloc_vlad_assigned": (C.c_int, [c_f32p, c_i64, c_i64, c_f32p, c_i64, c_i64p, c_f32p, C.c_uint, c_f32p,
+                                       C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_kmeans_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "anyloc_kmeans_step": (C.c_int, [c_f32p, c_i64, c_i64, c_f32p, c_i64, C.c_int, c_f32p, c_f32p,
                                      c_i64p, C.c_void_p, c_sz, C.c_void_p]),
@@ -143,7 +150,10 @@ _workspaces = {}
 
 
 def workspace(nbytes, device, tag="default"):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """Growing scratch buffer per (device, stream, tag): two streams never share one (kernels of different streams
+    would race on it), consecutive calls on one stream reuse it (stream order serialises them)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

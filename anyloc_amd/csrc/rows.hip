@@ -218,6 +218,70 @@ extern "C" int anyloc_preprocess_u8(const unsigned char* img_hwc, int64_t batch,
                                static_cast<hipStream_t>(stream));
 }
 
+
+namespace anyloc {
+namespace {
+
+// torch's bicubic kernel (A = -0.75), align_corners = False, no antialias: the convolution torchvision's
+// resize(..., BICUBIC) applies to a float tensor (reference demo/anyloc_vlad_generate.py:175-176)
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+  const float A = -0.75f;
+  float x = t + 1.0f;
+  c[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+  x = t;
+  c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  x = 1.0f - t;
+  c[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  x = 2.0f - t;
+  c[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+
+// out[b,c,y,x] = resized[b,c,top+y,left+x], resized = bicubic(in[b,c], size (rh, rw)); one thread per output pixel
+__global__ __launch_bounds__(256) void resize_bicubic_kernel(const float* __restrict__ in, int H, int W, int rh, int rw,
+                                                             int top, int left, int ch, int cw, float* __restrict__ out) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cw) return;
+  const int64_t plane = blockIdx.z;
+  const float sy = (float)H / (float)rh, sx = (float)W / (float)rw;
+  const float fy = sy * ((float)(top + y) + 0.5f) - 0.5f, fx = sx * ((float)(left + x) + 0.5f) - 0.5f;
+  const float y0f = floorf(fy), x0f = floorf(fx);
+  float cy[4], cx[4];
+  cubic_coeffs(fy - y0f, cy);
+  cubic_coeffs(fx - x0f, cx);
+  const int y0 = (int)y0f, x0 = (int)x0f;
+  const float* src = in + plane * (int64_t)H * W;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* r = src + (int64_t)min(max(y0 - 1 + i, 0), H - 1) * W;
+    float row = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row += r[min(max(x0 - 1 + j, 0), W - 1)] * cx[j];
+    acc += row * cy[i];
+  }
+  out[(plane * ch + y) * (int64_t)cw + x] = acc;
+}
+
+}  // namespace
+}  // namespace anyloc
+
+extern "C" int anyloc_resize_bicubic(const float* in, int64_t planes, int64_t height, int64_t width, int64_t out_h,
+                                     int64_t out_w, int64_t crop_top, int64_t crop_left, int64_t crop_h, int64_t crop_w,
+                                     float* out, void* stream) {
+  ANYLOC_CHECK_ARG(in && out, "resize_bicubic: null pointer");
+  ANYLOC_CHECK_ARG(planes > 0 && planes < 65536 && height > 0 && width > 0 && out_h > 0 && out_w > 0 && out_h < 65536,
+                   "resize_bicubic: bad size");
+  ANYLOC_CHECK_ARG(crop_top >= 0 && crop_left >= 0 && crop_h > 0 && crop_w > 0 && crop_top + crop_h <= out_h &&
+                       crop_left + crop_w <= out_w, "resize_bicubic: crop window outside the resized image");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  anyloc::ProfScope prof("resize_bicubic", s, 40.0 * planes * crop_h * crop_w, 4.0 * planes * (height * width + crop_h * crop_w));
+  hipLaunchKernelGGL(anyloc::resize_bicubic_kernel, dim3((unsigned)((crop_w + 255) / 256), (unsigned)crop_h, (unsigned)planes),
+                     dim3(256), 0, s, in, (int)height, (int)width, (int)out_h, (int)out_w, (int)crop_top, (int)crop_left,
+                     (int)crop_h, (int)crop_w, out);
+  return anyloc::launch_status("resize_bicubic_kernel");
+}
+
 extern "C" int anyloc_l2norm_rows(const float* x, float* out, int64_t rows, int64_t dim, float eps, void* stream) {
   return anyloc::l2norm_rows(x, dim, out, dim, rows, dim, eps, static_cast<hipStream_t>(stream));
 }

@@ -106,9 +106,10 @@ __global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict_
                                                         const int* __restrict__ lab, const float* __restrict__ nrm,
                                                         const float* __restrict__ c, float* __restrict__ dst,
                                                         unsigned* __restrict__ cnt_part) {
-  extern __shared__ float acc[];   // [K][SL] (+ [K] label histogram for the k-means column-slice 0)
+  extern __shared__ float acc[];   // [K][sl] (+ [K] label histogram for the k-means column-slice 0)
+  const int sl = blockDim.x;       // feature columns of this block: SL, or SL/2 when K > 128 (LDS: K * sl floats)
   const int tid = threadIdx.x;
-  const int d = blockIdx.x * SL + tid;
+  const int d = blockIdx.x * sl + tid;
   const int64_t g = blockIdx.y;
   int64_t n0, n1;
   if (KMEANS) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict_
     n0 = offsets[g];
     n1 = offsets[g + 1];
   }
-  for (int k = 0; k < K; ++k) acc[k * SL + tid] = 0.f;
+  for (int k = 0; k < K; ++k) acc[k * sl + tid] = 0.f;
   const bool live = d < D;
   const float* xp = x + (live ? d : 0);
   int64_t n = n0;
@@ -130,10 +131,10 @@ __global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict_
     for (int u = 0; u < 8; ++u) {
       const int k = lab[n + u];
       if (KMEANS) {
-        acc[k * SL + tid] += v[u];
+        acc[k * sl + tid] += v[u];
       } else {
         const float cv = live ? c[(int64_t)k * D + d] : 0.f;
-        acc[k * SL + tid] += v[u] / nrm[n + u] - cv;
+        acc[k * sl + tid] += v[u] / nrm[n + u] - cv;
       }
     }
   }
@@ -141,24 +142,24 @@ __global__ __launch_bounds__(SL) void accumulate_kernel(const float* __restrict_
     const float v = live ? xp[n * D] : 0.f;
     const int k = lab[n];
     if (KMEANS) {
-      acc[k * SL + tid] += v;
+      acc[k * sl + tid] += v;
     } else {
       const float cv = live ? c[(int64_t)k * D + d] : 0.f;
-      acc[k * SL + tid] += v / nrm[n] - cv;
+      acc[k * sl + tid] += v / nrm[n] - cv;
     }
   }
   if (live) {
     float* o = dst + g * (int64_t)K * D + d;
-    for (int k = 0; k < K; ++k) o[(int64_t)k * D] = acc[k * SL + tid];
+    for (int k = 0; k < K; ++k) o[(int64_t)k * D] = acc[k * sl + tid];
   }
   if (KMEANS && blockIdx.x == 0 && cnt_part) {
     // per-chunk label histogram (LDS atomics), reduced over chunks in a fixed order afterwards
-    unsigned* hist = reinterpret_cast<unsigned*>(acc + K * SL);
-    for (int k = tid; k < K; k += SL) hist[k] = 0u;
+    unsigned* hist = reinterpret_cast<unsigned*>(acc + K * sl);
+    for (int k = tid; k < K; k += sl) hist[k] = 0u;
     __syncthreads();
-    for (int64_t i = n0 + tid; i < n1; i += SL) atomicAdd(&hist[lab[i]], 1u);
+    for (int64_t i = n0 + tid; i < n1; i += sl) atomicAdd(&hist[lab[i]], 1u);
     __syncthreads();
-    for (int k = tid; k < K; k += SL) cnt_part[g * K + k] = hist[k];
+    for (int k = tid; k < K; k += sl) cnt_part[g * K + k] = hist[k];
   }
 }
 
@@ -278,6 +279,56 @@ __global__ __launch_bounds__(SLS) void soft_accumulate_kernel(const float* __res
   if (live) {
     float* o = dst + g * (int64_t)K * D + d;
     for (int k = 0; k < K; ++k) o[(int64_t)k * D] = (float)acc[k * SLS + tid];
+  }
+}
+
+
+// residual tensor of VLAD.generate_res_vec (reference utilities.py:959-962): out[n,k,:] = x_n / max(||x_n||, 1e-12) - c_k
+// (x_n as given when !norm_descs).  One block per token; a pure HBM write of K*D floats per token.
+__global__ __launch_bounds__(256) void residuals_kernel(const float* __restrict__ x, int D, int K, const float* __restrict__ c,
+                                                        int norm_descs, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int64_t n = blockIdx.x;
+  const float* r = x + n * D;
+  float den = 1.0f;
+  if (norm_descs) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) ss += r[i] * r[i];
+    den = fmaxf(sqrtf(block_sum256(ss, red)), 1e-12f);
+  }
+  float* o = out + n * (int64_t)K * D;
+  const int d4 = D >> 2;
+  for (int i = threadIdx.x; i < d4; i += 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(r)[i];
+    v[0] /= den; v[1] /= den; v[2] /= den; v[3] /= den;
+    for (int k = 0; k < K; ++k) {
+      const f32x4 cv = reinterpret_cast<const f32x4*>(c + (int64_t)k * D)[i];
+      f32x4 t;
+      t[0] = v[0] - cv[0]; t[1] = v[1] - cv[1]; t[2] = v[2] - cv[2]; t[3] = v[3] - cv[3];
+      reinterpret_cast<f32x4*>(o + (int64_t)k * D)[i] = t;
+    }
+  }
+}
+
+// VLAD from a GIVEN assignment (cache restore, reference utilities.py:843-847 / :864-868): per token the row norm
+// (F.normalize denominator) and the int32 copy of its label; also the [0, n] offsets of the single image
+__global__ __launch_bounds__(256) void assigned_prep_kernel(const float* __restrict__ x, int D, int64_t n, int K,
+                                                            const int64_t* __restrict__ labels, int norm_descs,
+                                                            float* __restrict__ nrm, int* __restrict__ lab32,
+                                                            int64_t* __restrict__ offsets) {
+  __shared__ float red[4];
+  const int64_t t = blockIdx.x;
+  float den = 1.0f;
+  if (norm_descs) {
+    const float* r = x + t * D;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) ss += r[i] * r[i];
+    den = fmaxf(sqrtf(block_sum256(ss, red)), 1e-12f);
+  }
+  if (threadIdx.x == 0) {
+    nrm[t] = den;
+    if (labels) lab32[t] = (int)min<int64_t>(max<int64_t>(labels[t], 0), K - 1);
+    if (t == 0) { offsets[0] = 0; offsets[1] = n; }
   }
 }
 
@@ -407,20 +458,20 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     }
   }
   {
-    const size_t lds = (size_t)K * SL * sizeof(float);
+    const int sl = K > 128 ? SL / 2 : SL;           // K up to 256: half-width column slices keep K * sl floats in LDS
+    const size_t lds = (size_t)K * sl * sizeof(float);
     static bool attr = false;
     if (!attr) {
       ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 256 * SL * (int)sizeof(float) / 2));
       attr = true;
     }
-    ANYLOC_CHECK_ARG(lds <= 128 * 1024, "vlad_hard: K=%lld needs %zu B of LDS (max 131072)", (long long)K, lds);
     const double bytes = 4.0 * ((double)total_tokens * D + 2.0 * (double)n_img * K * D);
     ProfScope prof("vlad_accumulate", stream, 2.0 * total_tokens * D, bytes);
     // grid.y is limited to 65535: loop over image groups
     for (int64_t i0 = 0; i0 < n_img; i0 += 65535) {
       const int64_t cnt = std::min<int64_t>(65535, n_img - i0);
-      hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((D + SL - 1) / SL), (unsigned)cnt), dim3(SL), lds,
+      hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((D + sl - 1) / sl), (unsigned)cnt), dim3(sl), lds,
                          stream, tokens, offsets + i0, (int64_t)0, total_tokens, (int)D, (int)K, w.lab32, w.nrm,
                          centers, out + i0 * K * D, (unsigned*)nullptr);
       ANYLOC_TRY(launch_status("accumulate_kernel"));
@@ -478,6 +529,87 @@ int anyloc_vlad_soft(const float* tokens, const int64_t* offsets, int64_t n_img,
     }
   }
   hipLaunchKernelGGL(vlad_finalize_kernel, dim3((unsigned)n_img), dim3(1024), 0, stream, out, (int)K, (int)D,
+                     (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0);
+  return launch_status("vlad_finalize_kernel");
+}
+
+
+int anyloc_vlad_soft_weights(const float* tokens, int64_t n_tok, int64_t D, const float* centers, int64_t K, float soft_temp,
+                             float* weights, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(centers && weights && (tokens || n_tok == 0), "vlad_soft_weights: null pointer");
+  ANYLOC_CHECK_ARG(n_tok >= 0 && K >= 1 && K <= 64 && D >= 4 && D % 4 == 0, "vlad_soft_weights: bad shape (K <= 64)");
+  if (n_tok == 0) return ANYLOC_OK;
+  VladWs w = carve(workspace, workspace_bytes, n_tok, D, K);
+  if (!workspace || w.bytes > workspace_bytes) {
+    set_error("vlad_soft_weights: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  const int kp = (int)kpad_of(K);
+  ANYLOC_HIP(hipMemsetAsync(w.chat, 0, sizeof(float) * kp * D, stream));
+  ANYLOC_HIP(hipMemcpyAsync(w.chat, centers, sizeof(float) * K * D, hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(rowsq_kernel, dim3((unsigned)K), dim3(256), 0, stream, centers, (int)D, w.cb);
+  ANYLOC_TRY(launch_status("rowsq_kernel"));
+  ANYLOC_TRY(run_scores(tokens, n_tok, D, w, K, false, stream, "vlad_soft_scores_gemm"));
+  hipLaunchKernelGGL(soft_weights_kernel, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, stream, w.scores, kp, (int)K,
+                     w.rowsq, w.cb, n_tok, soft_temp, w.nrm, 0);
+  ANYLOC_TRY(launch_status("soft_weights_kernel"));
+  ANYLOC_HIP(hipMemcpy2DAsync(weights, sizeof(float) * K, w.scores, sizeof(float) * kp, sizeof(float) * K, (size_t)n_tok,
+                              hipMemcpyDeviceToDevice, stream));
+  return ANYLOC_OK;
+}
+
+int anyloc_vlad_residuals(const float* tokens, int64_t n_tok, int64_t D, const float* centers, int64_t K, unsigned flags,
+                          float* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(centers && out && (tokens || n_tok == 0), "vlad_residuals: null pointer");
+  ANYLOC_CHECK_ARG(n_tok >= 0 && n_tok < (1ll << 31) && K >= 1 && D >= 4 && D % 4 == 0, "vlad_residuals: bad shape");
+  if (n_tok == 0) return ANYLOC_OK;
+  ProfScope prof("vlad_residuals", stream, (double)n_tok * K * D, 4.0 * ((double)n_tok * D * (K + 1) + (double)K * D));
+  hipLaunchKernelGGL(residuals_kernel, dim3((unsigned)n_tok), dim3(256), 0, stream, tokens, (int)D, (int)K, centers,
+                     (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0, out);
+  return launch_status("residuals_kernel");
+}
+
+int anyloc_vlad_assigned(const float* tokens, int64_t n_tok, int64_t D, const float* centers, int64_t K,
+                         const int64_t* labels, const float* soft_weights, unsigned flags, float* out, void* workspace,
+                         size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(centers && out && (tokens || n_tok == 0), "vlad_assigned: null pointer");
+  ANYLOC_CHECK_ARG((labels != nullptr) != (soft_weights != nullptr), "vlad_assigned: pass labels (hard) or soft weights, not both");
+  ANYLOC_CHECK_ARG(n_tok >= 0 && n_tok < (1ll << 31) && K >= 1 && K <= 256 && D >= 4 && D % 4 == 0, "vlad_assigned: bad shape");
+  ANYLOC_CHECK_ARG(labels || K <= 64, "vlad_assigned: soft weights need K <= 64");
+  VladWs w = carve(workspace, workspace_bytes, n_tok, D, K);
+  if (!workspace || w.bytes > workspace_bytes) {
+    set_error("vlad_assigned: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  int64_t* offsets = reinterpret_cast<int64_t*>(w.cb);        // 16 bytes of the (>= 128-byte) bias slot
+  if (n_tok == 0) {
+    ANYLOC_HIP(hipMemsetAsync(out, 0, sizeof(float) * K * D, stream));
+    return ANYLOC_OK;
+  }
+  const int norm = (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0;
+  hipLaunchKernelGGL(assigned_prep_kernel, dim3((unsigned)n_tok), dim3(256), 0, stream, tokens, (int)D, n_tok, (int)K, labels, norm,
+                     w.nrm, w.lab32, offsets);
+  ANYLOC_TRY(launch_status("assigned_prep_kernel"));
+  if (labels) {
+    const int sl = K > 128 ? SL / 2 : SL;
+    const size_t lds = (size_t)K * sl * sizeof(float);
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 256 * SL * (int)sizeof(float) / 2));
+    hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((D + sl - 1) / sl), 1u), dim3(sl), lds, stream, tokens, offsets,
+                       (int64_t)0, n_tok, (int)D, (int)K, w.lab32, w.nrm, centers, out, (unsigned*)nullptr);
+    ANYLOC_TRY(launch_status("accumulate_kernel"));
+  } else {
+    const size_t lds = (size_t)K * SLS * (sizeof(double) + sizeof(float));
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(soft_accumulate_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * SLS * 12));
+    hipLaunchKernelGGL(soft_accumulate_kernel, dim3((unsigned)((D + SLS - 1) / SLS), 1u), dim3(SLS), lds, stream, tokens, offsets,
+                       (int)D, (int)K, (int)K, soft_weights, w.nrm, centers, out);
+    ANYLOC_TRY(launch_status("soft_accumulate_kernel"));
+  }
+  hipLaunchKernelGGL(vlad_finalize_kernel, dim3(1u), dim3(1024), 0, stream, out, (int)K, (int)D,
                      (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0);
   return launch_status("vlad_finalize_kernel");
 }
@@ -542,16 +674,16 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
     ANYLOC_TRY(launch_status("assign_kernel"));
   }
   {
-    const size_t lds = (size_t)K * SL * sizeof(float) + (size_t)K * sizeof(unsigned);
+    const int sl = K > 128 ? SL / 2 : SL;
+    const size_t lds = (size_t)K * sl * sizeof(float) + (size_t)K * sizeof(unsigned);
     static bool attr = false;
     if (!attr) {
       ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 129 * 1024));
       attr = true;
     }
-    ANYLOC_CHECK_ARG(lds <= 129 * 1024, "kmeans_step: K=%lld needs %zu B of LDS", (long long)K, lds);
     ProfScope prof("kmeans_accumulate", stream, 1.0 * n * D, 4.0 * ((double)n * D + (double)chunks * K * D));
-    hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((D + SL - 1) / SL), (unsigned)chunks), dim3(SL), lds,
+    hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((D + sl - 1) / sl), (unsigned)chunks), dim3(sl), lds,
                        stream, x, (const int64_t*)nullptr, rows, n, (int)D, (int)K, w.lab32, (const float*)nullptr,
                        (const float*)nullptr, part, cnt_part);
     ANYLOC_TRY(launch_status("accumulate_kernel<kmeans>"));

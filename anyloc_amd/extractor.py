@@ -183,10 +183,18 @@ class HipDinoV2:
         assert H % PATCH == 0, f"Input image height {H} is not a multiple of patch height {PATCH}"
         assert W % PATCH == 0, f"Input image width {W} is not a multiple of patch width: {PATCH}"
         img = ops._f32c(img, self.device)
-        taps = sorted(taps, key=lambda t: t[0])
+        taps = list(taps)
         for layer, facet in taps:
             if not 0 <= layer < self.depth:
                 raise IndexError(f"layer {layer} outside the {self.depth} loaded blocks")
+        order = sorted(range(len(taps)), key=lambda i: taps[i][0])        # the forward visits layers in ascending order
+        if order != list(range(len(taps))):
+            # ... and the caller gets its feature blocks in the order it asked for ("l n d -> n (l d)", reference
+            # scripts/dino_v2_vlad_viz.py:175-196); every normalisation is invariant to the block order
+            res = self.forward_taps(img, [taps[i] for i in order], use_cls, norm_taps, norm_concat)
+            blocks = res.reshape(res.shape[0], res.shape[1], len(taps), self.dim)
+            inv = [order.index(i) for i in range(len(taps))]
+            return blocks[:, :, inv].reshape(res.shape[0], res.shape[1], -1).contiguous()
         n_taps = len(taps)
         np_ = (H // PATCH) * (W // PATCH)
         rows = np_ + 1 if use_cls else np_
@@ -242,11 +250,12 @@ class DinoV2ExtractFeatures:
             raise ValueError(f"facet must be one of {_DINO_FACETS}")
         self.vit_type: str = dino_model
         self.device = torch.device(device)
-        gpu = _lib.require_gpu() if self.device.type != "cuda" else \
-            torch.device("cuda", self.device.index if self.device.index is not None
-                         else torch.cuda.current_device())
-        if self.device.type == "cuda":
-            _lib.require_gpu()
+        gpu = _lib.require_gpu()
+        if self.device.type == "cuda" and self.device.index is not None and self.device.index != gpu.index:
+            # kernels are launched on the CURRENT HIP device and stream (one process per GPU): weights on another
+            # device would be reached through peer access at best
+            raise ValueError(f"device {self.device} is not the current ROCm device ({gpu}); this library drives one GPU "
+                             f"per process -- call torch.cuda.set_device({self.device.index}) first")
         self._gpu = gpu
         self.layer: int = layer
         self.facet = facet

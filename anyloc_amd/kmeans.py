@@ -49,11 +49,41 @@ class KMeans:
         return t.to(torch.float32)
 
     def _all_reduce(self, *tensors):
+        """Sum over the ranks of ``process_group`` in place (RCCL; gloo groups are staged through the host, gloo has
+        no device all-reduce for every dtype / build)."""
         if self.process_group is None:
             return
         import torch.distributed as dist
+        host = dist.get_backend(self.process_group) == "gloo"
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+            if host and t.is_cuda:
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.process_group)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def _sharded_init(self, x):
+        """Initial centroids of a row-sharded fit, identical to the flat fit on the concatenated rows: rank 0 draws
+        ``np.random.choice(N_total, K, replace=False)`` from NumPy's global RNG (what fpk does on the whole array),
+        the draw is broadcast, every rank contributes the drawn rows it owns and the [K, D] table is all-reduced."""
+        import torch.distributed as dist
+        g = self.process_group
+        world, rank = dist.get_world_size(g), dist.get_rank(g)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64), group=g)
+        counts = [int(c) for c in counts]
+        n_total, off = sum(counts), sum(counts[:rank])
+        pick = torch.zeros(self.n_clusters, dtype=torch.int64)
+        if rank == 0:
+            pick = torch.from_numpy(np.random.choice(n_total, size=[self.n_clusters], replace=False)).to(torch.int64)
+        dist.broadcast(pick, src=dist.get_global_rank(g, 0) if g is not dist.group.WORLD else 0, group=g)
+        c = torch.zeros(self.n_clusters, x.shape[1], dtype=torch.float32, device=x.device)
+        mine = (pick >= off) & (pick < off + x.shape[0])
+        if bool(mine.any()):
+            c[mine.to(x.device)] = x[(pick[mine] - off).to(x.device)]
+        self._all_reduce(c)
+        return c
 
     # -- fpk surface -----------------------------------------------------------
     def fit_predict(self, X, centroids=None):
@@ -62,10 +92,10 @@ class KMeans:
         n = x.shape[0]
         if centroids is None:
             if self.process_group is not None:
-                raise ValueError("sharded fit needs explicit initial centroids "
-                                 "(draw the init rows once and broadcast them)")
-            pick = np.random.choice(n, size=[self.n_clusters], replace=False)
-            c = x[torch.as_tensor(pick, device=x.device)].clone()
+                c = self._sharded_init(x)
+            else:
+                pick = np.random.choice(n, size=[self.n_clusters], replace=False)
+                c = x[torch.as_tensor(pick, device=x.device)].clone()
         else:
             c = self._to_dev(centroids).clone()
         labels = None

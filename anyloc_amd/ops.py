@@ -211,6 +211,60 @@ def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_te
     return (out, labels) if return_labels else out
 
 
+def vlad_soft_weights(tokens, centers, soft_temp=1.0):
+    """softmax_k(soft_temp * cosine_similarity(x_n, c_k)) -> [N, K] (what the reference stores as <id>_s.pt)."""
+    device = _lib.require_gpu()
+    tokens, centers = _f32c(tokens, device), _f32c(centers, device)
+    n, D = tokens.shape
+    K = centers.shape[0]
+    out = torch.empty(n, K, dtype=torch.float32, device=device)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.anyloc_vlad_workspace_bytes(n, 1, D, K), device, "vlad")
+    _lib.check(lib.anyloc_vlad_soft_weights(_lib.ptr(tokens), n, D, _lib.ptr(centers), K, float(soft_temp), _lib.ptr(out),
+                                            _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_vlad_soft_weights")
+    return out
+
+
+def vlad_residuals(tokens, centers, norm_descs=True):
+    """[N, D] tokens -> the residual tensor [N, K, D] = normalise(x)[:, None, :] - centers[None] (device)."""
+    device = _lib.require_gpu()
+    tokens, centers = _f32c(tokens, device), _f32c(centers, device)
+    n, D = tokens.shape
+    K = centers.shape[0]
+    if centers.shape[1] != D:
+        raise ValueError(f"descriptor dim {D} != cluster centre dim {centers.shape[1]}")
+    out = torch.empty(n, K, D, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().anyloc_vlad_residuals(_lib.ptr(tokens), n, D, _lib.ptr(centers), K,
+                                                 VLAD_NORM_DESCS if norm_descs else 0, _lib.ptr(out), _lib.stream_ptr()),
+               "anyloc_vlad_residuals")
+    return out
+
+
+def vlad_assigned(tokens, centers, labels=None, soft=None, norm_descs=True, intra_norm=True):
+    """VLAD [K*D] of one image from a given assignment: ``labels`` int64 [N] (hard) or ``soft`` fp32 [N, K] weights."""
+    device = _lib.require_gpu()
+    tokens, centers = _f32c(tokens, device), _f32c(centers, device)
+    n, D = tokens.shape
+    K = centers.shape[0]
+    if (labels is None) == (soft is None):
+        raise ValueError("pass labels or soft weights")
+    if labels is not None:
+        labels = labels.to(device, torch.int64).contiguous()
+        if labels.numel() != n or (n and (int(labels.min()) < 0 or int(labels.max()) >= K)):
+            raise ValueError("labels must be [N] with values in [0, K)")
+    else:
+        soft = _f32c(soft, device)
+        if tuple(soft.shape) != (n, K):
+            raise ValueError(f"soft weights must be [{n}, {K}], got {tuple(soft.shape)}")
+    out = torch.empty(K * D, dtype=torch.float32, device=device)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.anyloc_vlad_workspace_bytes(n, 1, D, K), device, "vlad")
+    flags = (VLAD_NORM_DESCS if norm_descs else 0) | (VLAD_INTRA_NORM if intra_norm else 0)
+    _lib.check(lib.anyloc_vlad_assigned(_lib.ptr(tokens), n, D, _lib.ptr(centers), K, _lib.ptr(labels), _lib.ptr(soft), flags,
+                                        _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_vlad_assigned")
+    return out
+
+
 POOL_MODES = {"average": 0, "avg": 0, "max": 1, "gem": 2, "gem_abs": 3}
 
 
@@ -270,6 +324,11 @@ def topk(queries, db, k, metric="ip", index_base=0, normalize_db=False):
     ``normalize_db``: score against F.normalize(db) without materialising it (ANYLOC_TOPK_NORMALIZE_DB)."""
     _need_cuda(queries, db)
     queries, db = _f32c(queries), _f32c(db)
+    if queries.shape[1] % 4:          # the kernels read 16-byte groups: zero columns change neither metric
+        pad = -queries.shape[1] % 4
+        queries, db = torch.nn.functional.pad(queries, (0, pad)), torch.nn.functional.pad(db, (0, pad))
+    if not 1 <= int(k) <= 1024:
+        raise ValueError(f"k={k} outside [1, 1024] (candidate lists are merged in LDS)")
     nq, dim = queries.shape
     ndb = db.shape[0]
     dist = torch.empty(nq, k, dtype=torch.float32, device=queries.device)

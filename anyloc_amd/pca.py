@@ -12,8 +12,8 @@ run on the fp32 MFMA GEMM of the library (``anyloc_gemm_nt``):
   eigendecomposition (float64, ``torch.linalg.eigh`` -- a dense-solver library call, not a kernel of this
   package) gives the singular values and one side of the SVD; for the Gram side the principal axes follow
   from one more GEMM, V^T = diag(1/s) U^T Xc.
-  Signs follow sklearn's ``svd_flip(u_based_decision=False)``: the largest-magnitude entry of every axis is
-  positive.
+  Signs follow sklearn's ``svd_flip``: by default the convention of sklearn >= 1.5 (largest-magnitude entry of
+  every axis positive); ``sign_convention="u"`` gives the u-based rule of the sklearn versions the reference pins.
 * transform:  one GEMM with the bias epilogue,  X W^T - W mean,  W = components (/ sqrt(explained variance)
   when whitening) -- the order sklearn's ``_BasePCA._transform`` uses.
 
@@ -36,7 +36,15 @@ def _gemm(a, w, bias=None):
 
 
 class PCA:
-    def __init__(self, n_components: int, whiten: bool = False, precise: bool = True):
+    def __init__(self, n_components: int, whiten: bool = False, precise: bool = True, sign_convention: str = "v"):
+        """``sign_convention``: which factor of the SVD fixes the sign of every axis -- "v" (default): the
+        largest-magnitude entry of each principal axis is positive, sklearn >= 1.5 (``svd_flip(u, vt,
+        u_based_decision=False)``; the version installed next to this package); "u": the largest-magnitude entry of each
+        column of U is positive, sklearn < 1.5 incl. the 0.24.2 / 1.0.2 the reference pins.  Projected coordinates differ
+        by a per-axis sign between the two; retrieval is unaffected, element-wise comparison of dumps is not."""
+        if sign_convention not in ("v", "u"):
+            raise ValueError("sign_convention must be 'v' or 'u'")
+        self.sign_convention = sign_convention
         self.n_components = int(n_components)
         self.whiten = bool(whiten)
         # The Gram / scatter matrix squares the condition number: formed with fp32 sums, the axes whose variance is
@@ -82,12 +90,22 @@ class PCA:
             lam, vec = self._eigh_desc(scatter)
             s = lam.clamp_min(0).sqrt()
             axes = vec[:, :k].t().to(torch.float32).contiguous()
+        # axes of (numerically) zero variance -- rank-deficient data, e.g. n_components == n_samples after centring -- carry
+        # no direction: U^T Xc / s would divide noise by ~0.  They are set to zero (every projection onto them is 0,
+        # also under whitening) instead of being blown up to inf / NaN.
+        dead = s[:k] <= s[0] * max(n, f) * torch.finfo(torch.float64).eps
+        axes = torch.where(dead[:, None].to(axes.device), torch.zeros_like(axes), axes)
         # unit length in fp32 (the GEMM above leaves ~1e-7 of drift) and sklearn's sign rule
         axes = torch.nn.functional.normalize(axes, dim=1)
-        piv = axes.abs().argmax(dim=1)
-        sign = torch.sign(axes[torch.arange(k, device=device), piv])
+        if self.sign_convention == "v":
+            piv = axes.abs().argmax(dim=1)
+            sign = torch.sign(axes[torch.arange(k, device=device), piv])
+        else:
+            u = _gemm(xc, axes.contiguous())                               # [n, k] = U diag(s): same signs as U
+            sign = torch.sign(u[u.abs().argmax(dim=0), torch.arange(k, device=device)])
         sign = torch.where(sign == 0, torch.ones_like(sign), sign)
         self.components_ = (axes * sign[:, None]).contiguous()
+        self._dead = dead
         self.singular_values_ = s[:k].to(torch.float32)
         self.explained_variance_ = (lam[:k].clamp_min(0) / max(n - 1, 1)).to(torch.float32)
         total = float(lam.clamp_min(0).sum() / max(n - 1, 1))
@@ -107,7 +125,7 @@ class PCA:
             w = self.components_
             if self.whiten:
                 scale = self.explained_variance_.sqrt().clamp_min(torch.finfo(torch.float32).eps)
-                w = w / scale[:, None]
+                w = w / scale[:, None]                                      # (dead axes are zero rows: 0 / eps = 0)
             w = w.contiguous()
             self._w = (w, -(w.double() @ self.mean_.double()).to(torch.float32))
         return self._w
@@ -126,6 +144,34 @@ class PCA:
 
     def fit_transform(self, X):
         return self.fit(X).transform(X)
+
+
+def joint_pca_project(db_descs, qu_descs, lower_dim: int = 512, whiten: bool = False, sign_convention: str = "v"):
+    """Joint PCA projection of several datasets' global descriptors (reference ``scripts/joint_pca_project.py:62-101``):
+    ONE PCA is fitted on the concatenation of all database descriptor sets, and every database / query set is projected
+    with it.  ``db_descs`` / ``qu_descs``: lists of [n_i, f] tensors (or arrays), one entry per dataset, as the script
+    loads them from ``db-<name>.pt`` / ``qu-<name>.pt``.  Returns (list of projected database sets, list of projected
+    query sets, the fitted PCA), each set on the device / in the container type it came in."""
+    as_np = [isinstance(d, np.ndarray) for d in db_descs]
+    dbs = [torch.as_tensor(d) for d in db_descs]
+    qus = [torch.as_tensor(q) for q in qu_descs]
+    if len(dbs) != len(qus) or not dbs:
+        raise ValueError("need one database and one query descriptor set per dataset")
+    pca = PCA(lower_dim, whiten=whiten, sign_convention=sign_convention)
+    dev = _lib.require_gpu()
+    down_db = pca.fit_transform(torch.cat([ops._f32c(d, dev) for d in dbs], dim=0))
+    down_qu = pca.transform(torch.cat([ops._f32c(q, dev) for q in qus], dim=0))
+    out_db, out_qu, i_db, i_qu = [], [], 0, 0
+    for d, q, np_in in zip(dbs, qus, as_np):
+        a, b = down_db[i_db:i_db + d.shape[0]], down_qu[i_qu:i_qu + q.shape[0]]
+        i_db, i_qu = i_db + d.shape[0], i_qu + q.shape[0]
+        if np_in:
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+        else:
+            a, b = a.to(d.device), b.to(q.device)
+        out_db.append(a)
+        out_qu.append(b)
+    return out_db, out_qu, pca
 
 
 def reduce_pca(train_descs, test_descs, lower_dim: int, low_factor: float = 0.0, fallback: int = 256,

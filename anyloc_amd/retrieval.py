@@ -100,25 +100,28 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    counts = [torch.zeros(1, dtype=torch.int64, device=qu_local.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([qu_local.shape[0]], dtype=torch.int64,
-                                         device=qu_local.device), group=group)
+    # RCCL moves device tensors over xGMI; a gloo group (CPU tests, single-GPU tests) is staged through the host
+    comm = torch.device("cpu") if dist.get_backend(group) == "gloo" else qu_local.device
+    counts = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([qu_local.shape[0]], dtype=torch.int64, device=comm), group=group)
     counts = [int(c) for c in counts]
     mx = max(counts)
-    padded = torch.zeros(mx, qu_local.shape[1], dtype=torch.float32, device=qu_local.device)
-    padded[:qu_local.shape[0]] = qu_local
+    padded = torch.zeros(mx, qu_local.shape[1], dtype=torch.float32, device=comm)
+    padded[:qu_local.shape[0]] = qu_local.to(comm)
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded, group=group)
-    qu_all = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0)
+    qu_all = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0).to(qu_local.device)
     if search_fn is None:
         d, i = search(db_shard, qu_all, k, method, norm_descs)
         i = torch.where(i >= 0, i + shard_base, i)
     else:
         d, i = search_fn(db_shard, qu_all, k, method, norm_descs, shard_base)
+    d, i = d.to(comm), i.to(comm)
     out_d = [torch.empty_like(d) for _ in range(world)] if rank == 0 else None
     out_i = [torch.empty_like(i) for _ in range(world)] if rank == 0 else None
-    dist.gather(d, out_d, dst=0, group=group)
-    dist.gather(i, out_i, dst=0, group=group)
+    dst = 0 if group is None or group is dist.group.WORLD else dist.get_global_rank(group, 0)
+    dist.gather(d, out_d, dst=dst, group=group)
+    dist.gather(i, out_i, dst=dst, group=group)
     if rank != 0:
         return None, None
     return merge_shard_topk([x.cpu().numpy() for x in out_d], [x.cpu().numpy() for x in out_i], k,

@@ -14,6 +14,10 @@ import torch
 from . import _lib, ops
 from .kmeans import KMeans
 
+# compact <id>_r.pt: {"format": LAZY_FORMAT, "tokens": normalised tokens [N,D], "num_clusters": K}; the [N,K,D] residual
+# tensor of the reference is tokens[:, None, :] - c_centers[None] and is only formed when generate_res_vec is asked for it
+LAZY_FORMAT = "anyloc_amd.lazy_residuals.v1"
+
 
 def _as_tensor(x):
     if isinstance(x, np.ndarray):
@@ -45,6 +49,8 @@ class VLAD:
         self.c_centers = None
         self.kmeans = None
         # Set the caching
+        # "lazy" (default; ANYLOC_CACHE_FORMAT) or "reference": how <id>_r.pt is WRITTEN; both are read
+        self.cache_format = os.environ.get("ANYLOC_CACHE_FORMAT", "lazy")
         self.cache_dir = cache_dir
         if self.cache_dir is not None:
             self.cache_dir = os.path.abspath(os.path.expanduser(self.cache_dir))
@@ -87,9 +93,13 @@ class VLAD:
         return True
 
     # ------------------------------------------------------------ vocabulary
-    def fit(self, train_descs: Union[np.ndarray, torch.Tensor, None]):
-        """Build (or restore from ``cache_dir/c_centers.pt``) the cluster centres."""
-        self.kmeans = KMeans(self.num_clusters, mode=self.mode)
+    def fit(self, train_descs: Union[np.ndarray, torch.Tensor, None], process_group=None):
+        """Build (or restore from ``cache_dir/c_centers.pt``) the cluster centres.
+
+        ``process_group`` (additive, multi-GPU vocabulary build): ``train_descs`` is this rank's shard of
+        the rows; every k-means iteration all-reduces the [K,D] sums and [K] counts, all ranks end with the same
+        centres (identical to the flat fit on the concatenated rows) and rank 0 writes the cache."""
+        self.kmeans = KMeans(self.num_clusters, mode=self.mode, process_group=process_group)
         if self.can_use_cache_vlad():
             print("Using cached cluster centers")
             self.c_centers = torch.load(f"{self.cache_dir}/c_centers.pt")
@@ -111,8 +121,15 @@ class VLAD:
             self.kmeans.centroids = self.kmeans.centroids.to(home)
             self.c_centers = self.kmeans.centroids
             if self.cache_dir is not None:
-                print("Caching cluster centers")
-                torch.save(self.c_centers, f"{self.cache_dir}/c_centers.pt")
+                rank0 = True
+                if process_group is not None:
+                    import torch.distributed as dist
+                    rank0 = dist.get_rank(process_group) == 0
+                if rank0:
+                    print("Caching cluster centers")
+                    torch.save(self.c_centers, f"{self.cache_dir}/c_centers.pt")
+                if process_group is not None:
+                    dist.barrier(group=process_group)
 
     def fit_and_generate(self, train_descs: Union[np.ndarray, torch.Tensor]) -> torch.Tensor:
         """``fit`` on [num_imgs, num_descs, desc_dim] then VLADs of every image."""
@@ -137,34 +154,57 @@ class VLAD:
         base = f"{self.cache_dir}/{cache_id}"
         return base + "_r.pt", base + "_l.pt", base + "_s.pt"
 
+    def _load_residual_file(self, r_path):
+        """``<id>_r.pt`` -> ("lazy", normalised tokens [N,D]) for the compact format this class writes, or
+        ("dense", residual tensor [N,K,D]) for a file written by the reference itself (utilities.py:963-970)."""
+        obj = torch.load(r_path)
+        if isinstance(obj, dict) and obj.get("format") == LAZY_FORMAT:
+            return "lazy", obj["tokens"]
+        return "dense", obj
+
     def _from_cache(self, cache_id):
-        """Rebuild one VLAD from ``<id>_r.pt`` (+ ``_l`` / ``_s``) exactly as the reference
-        does when a cache hit occurs (utilities.py:843-847, :864-868, :951-954): a restore path,
-        not the hot path -- the stored [N,K,D] residual tensor is reduced with torch on the GPU."""
+        """Rebuild one VLAD on a cache hit (reference utilities.py:843-847 hard, :864-868 soft) WITHOUT the [N,K,D]
+        residual tensor: the compact ``_r`` file holds the normalised tokens and the HIP kernel behind
+        ``ops.vlad_assigned`` sums ``token - centre`` under the cached labels / soft weights.  A dense ``_r`` file
+        written by the reference is honoured too: only the slice ``residuals[n, label_n]`` of every token is read
+        (hard), i.e. N*D of its N*K*D values."""
         r_path, l_path, s_path = self._cached_paths(cache_id)
-        dev = _lib.require_gpu()
-        residuals = torch.load(r_path).to(dev, torch.float32)       # [N,K,D]
+        kind, data = self._load_residual_file(r_path)
         K, D = self.num_clusters, self.desc_dim
-        un_vlad = torch.zeros(K, D, device=dev)
+        c = self._centers_dev()
         if self.vlad_mode == "hard":
-            labels = torch.load(l_path).to(dev) if os.path.isfile(l_path) else None
-            if labels is None:
+            if not os.path.isfile(l_path):
                 return None
-            picked = residuals[torch.arange(residuals.shape[0], device=dev), labels]   # [N,D]
-            un_vlad.index_add_(0, labels, picked)
+            labels = torch.load(l_path).to(torch.int64)
+            if kind == "lazy":
+                out = ops.vlad_assigned(data, c, labels=labels, norm_descs=False, intra_norm=self.intra_norm)
+            else:           # own-cluster residual of every token; summing it needs no centre any more
+                picked = data[torch.arange(data.shape[0]), labels.cpu()].to(torch.float32)
+                out = ops.vlad_assigned(picked, torch.zeros_like(c), labels=labels, norm_descs=False,
+                                        intra_norm=self.intra_norm)
         else:
-            soft = torch.load(s_path).to(dev, torch.float32) if os.path.isfile(s_path) else None
-            if soft is None:
+            if not os.path.isfile(s_path):
                 return None
-            # reference quirk: block k sums w[q,k] * residual over ALL clusters c (utilities.py:881-884)
-            un_vlad = torch.einsum("qk,qd->kd", soft, residuals.sum(1))
-        if self.intra_norm:
-            un_vlad = ops.l2norm_rows(un_vlad)
-        return ops.l2norm_rows(un_vlad.reshape(1, K * D))[0].cpu()
+            soft = torch.load(s_path).to(torch.float32)
+            if kind == "lazy":
+                out = ops.vlad_assigned(data, c, soft=soft, norm_descs=False, intra_norm=self.intra_norm)
+            else:
+                # a dense file of the reference in soft mode: its quirk sums every cluster's residual (utilities.py:881-884),
+                # so all N*K*D stored values are needed; reduced once over the cluster axis on the host, the rest on the
+                # device (interchange path for files the reference wrote, not the hot path)
+                dev = _lib.require_gpu()
+                r_sum = data.to(torch.float32).sum(1).to(dev)                           # [N,D]
+                un = (soft.to(dev).t() @ r_sum)
+                if self.intra_norm:
+                    un = ops.l2norm_rows(un)
+                out = ops.l2norm_rows(un.reshape(1, K * D))[0]
+        return out.cpu()
 
     def _write_cache(self, cache_id, descs_home):
-        """Store what the reference stores when ``cache_id`` is given and the cache dir is valid
-        (utilities.py:850-852, :876-878, :963-970): residuals [N,K,D], labels / soft weights."""
+        """Store what a later cache hit needs (reference utilities.py:850-852, :876-878, :963-970): ``_r`` + ``_l``
+        (hard) / ``_s`` (soft).  ``_r`` is written in the compact lazy format -- the normalised tokens [N,D], from which
+        ``residual[n,k] = token[n] - c_centers[k]`` is recomputed on demand, 3.25 MB instead of 104 MB per image at the
+        headline shape -- unless ``cache_format == "reference"`` asks for the reference's dense [N,K,D] tensor."""
         r_path, l_path, s_path = self._cached_paths(cache_id)
         cid_dir = f"{self.cache_dir}/" f"{os.path.split(cache_id)[0]}"
         if not os.path.isdir(cid_dir):
@@ -172,16 +212,21 @@ class VLAD:
             print(f"Created directory: {cid_dir}")
         dev = _lib.require_gpu()
         x = ops._f32c(descs_home, dev)
-        xh = ops.l2norm_rows(x) if self.norm_descs else x
         c = self._centers_dev()
         if not os.path.isfile(r_path):
-            torch.save((xh[:, None, :] - c[None, :, :]).cpu(), r_path)
+            self._save_residuals(x, r_path)
         if self.vlad_mode == "hard":
             if not os.path.isfile(l_path):
                 torch.save(self.kmeans.predict(x).cpu(), l_path)
         elif not os.path.isfile(s_path):
-            cos = torch.nn.functional.cosine_similarity(x[:, None, :], c[None, :, :], dim=2)
-            torch.save(torch.softmax(self.soft_temp * cos, dim=1).cpu(), s_path)
+            torch.save(ops.vlad_soft_weights(x, c, self.soft_temp).cpu(), s_path)
+
+    def _save_residuals(self, x_dev, r_path):
+        if self.cache_format == "reference":
+            torch.save(ops.vlad_residuals(x_dev, self._centers_dev(), self.norm_descs).cpu(), r_path)
+        else:
+            xh = ops.l2norm_rows(x_dev) if self.norm_descs else x_dev
+            torch.save({"format": LAZY_FORMAT, "tokens": xh.cpu(), "num_clusters": self.num_clusters}, r_path)
 
     def _generate_batch(self, multi_query):
         """[n_img,N,D] tensor or list of [N_i,D] -> [n_img, K*D] on the inputs' device."""
@@ -237,24 +282,27 @@ class VLAD:
     def generate_res_vec(self, query_descs: Union[np.ndarray, torch.Tensor],
                          cache_id: Union[str, None] = None) -> torch.Tensor:
         """Residual tensor [n_q, n_c, d] = normalise(q)[:,None,:] - c_centers[None] (reference
-        utilities.py:928-972).  Kept for surface parity: the HIP VLAD path never materialises
-        it; this method does, on request, with a broadcast subtraction on the device."""
+        utilities.py:928-972).  The VLAD path of this class never forms it; this method does, on request, with the
+        HIP kernel behind ``ops.vlad_residuals`` (a pure HBM write).  A cached ``<id>_r.pt`` is honoured in both
+        formats; a new cache entry is written in the compact format (see ``_write_cache``)."""
         self._check_fitted()
         if cache_id is not None and self.can_use_cache_vlad() and \
                 os.path.isfile(f"{self.cache_dir}/{cache_id}_r.pt"):
-            return torch.load(f"{self.cache_dir}/{cache_id}_r.pt")
+            kind, data = self._load_residual_file(f"{self.cache_dir}/{cache_id}_r.pt")
+            if kind == "dense":
+                return data
+            return ops.vlad_residuals(data, self._centers_dev(), norm_descs=False).to(data.device)
         query_descs = _as_tensor(query_descs)
         home = query_descs.device
         x = ops._f32c(query_descs, _lib.require_gpu())
-        if self.norm_descs:
-            x = ops.l2norm_rows(x)
-        residuals = (x[:, None, :] - self._centers_dev()[None, :, :]).to(home)
+        residuals = ops.vlad_residuals(x, self._centers_dev(), self.norm_descs)
+        residuals = residuals if home.type == "cuda" else residuals.to(home)
         if cache_id is not None and self.can_use_cache_vlad():
             cid_dir = f"{self.cache_dir}/" f"{os.path.split(cache_id)[0]}"
             if not os.path.isdir(cid_dir):
                 os.makedirs(cid_dir)
                 print(f"Created directory: {cid_dir}")
-            torch.save(residuals, f"{self.cache_dir}/{cache_id}_r.pt")
+            self._save_residuals(x, f"{self.cache_dir}/{cache_id}_r.pt")
         return residuals
 
     def generate_multi_res_vec(self, multi_query: Union[np.ndarray, torch.Tensor, list],

@@ -64,6 +64,16 @@ int anyloc_preprocess_u8(const unsigned char* img_hwc, int64_t batch, int64_t he
                          int64_t width, int64_t crop_h, int64_t crop_w,
                          const float* mean3, const float* std3, float* out, void* stream);
 
+/* Optional downscale of the ingest (demo/anyloc_vlad_generate.py:163-181: images whose longer side exceeds
+ * max_img_size are resized with torchvision's BICUBIC on the normalised float tensor, then centre-cropped to
+ * multiples of 14).  in [planes, H, W] fp32 (planes = B*3) is resized to (out_h, out_w) with torch's bicubic
+ * convolution (A = -0.75, align_corners = False, no antialias) and only the window
+ * [crop_top, crop_top + crop_h) x [crop_left, crop_left + crop_w) of the resized image is written:
+ * out [planes, crop_h, crop_w]. */
+int anyloc_resize_bicubic(const float* in, int64_t planes, int64_t height, int64_t width,
+                          int64_t out_h, int64_t out_w, int64_t crop_top, int64_t crop_left,
+                          int64_t crop_h, int64_t crop_w, float* out, void* stream);
+
 /* ------------------------------------------------- split-bf16 matmul ----
  * The same contraction as anyloc_gemm_nt (torch Linear layout, reference
  * utilities.py:269 model forward) on the bf16 matrix cores with fp32-level
@@ -171,6 +181,29 @@ int anyloc_vlad_soft(const float* tokens, const int64_t* offsets, int64_t n_img,
                      int64_t total_tokens, int64_t D, const float* centers,
                      int64_t K, float soft_temp, unsigned flags, float* out,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The soft-assignment weights alone (what the reference caches as <id>_s.pt, utilities.py:870-878):
+ * weights[n, k] = softmax_k(soft_temp * F.cosine_similarity(x_n, c_k)), [n_tok, K] fp32, K <= 64.
+ * Workspace: anyloc_vlad_workspace_bytes(n_tok, 1, D, K). */
+int anyloc_vlad_soft_weights(const float* tokens, int64_t n_tok, int64_t D, const float* centers,
+                             int64_t K, float soft_temp, float* weights, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* The residual tensor itself (VLAD.generate_res_vec, utilities.py:928-972; the reference materialises it for every
+ * image, this library only on request): out[n,k,:] = normalise(x_n) - centers[k]  ([n_tok, K, D]; flag
+ * ANYLOC_VLAD_NORM_DESCS as above; the other flags are ignored). */
+int anyloc_vlad_residuals(const float* tokens, int64_t n_tok, int64_t D, const float* centers,
+                          int64_t K, unsigned flags, float* out, void* stream);
+
+/* VLAD of ONE image from a GIVEN assignment -- the cache-hit branches of VLAD.generate
+ * (utilities.py:843-847 hard: labels int64 [n_tok]; :864-868 soft: weights fp32 [n_tok, K]; pass exactly one,
+ * the other NULL): per-cluster sums of normalise(x_n) - centers (hard: own cluster; soft: the reference's
+ * all-cluster sum), intra-norm, global norm.  The [n_tok, K, D] residual tensor is never formed: tokens are
+ * what a lazy cache stores.  Workspace: anyloc_vlad_workspace_bytes(n_tok, 1, D, K). */
+int anyloc_vlad_assigned(const float* tokens, int64_t n_tok, int64_t D, const float* centers,
+                         int64_t K, const int64_t* labels, const float* soft_weights,
+                         unsigned flags, float* out, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* ------------------------------------------------------------ k-means ----
  * One fast-pytorch-kmeans iteration (cosine or euclidean mode):

@@ -75,6 +75,32 @@ def install(monkeypatch):
                         else pool_ref.gem_descriptors(t, gem_p, method == "gem_abs")[0])
         return torch.stack(outs)
 
+    def vlad_residuals(tokens, centers, norm_descs=True):
+        x = tokens.float()
+        return (F.normalize(x, dim=-1) if norm_descs else x)[:, None, :] - centers.float()[None]
+
+    def vlad_assigned(tokens, centers, labels=None, soft=None, norm_descs=True, intra_norm=True):
+        x, c = tokens.float(), centers.float()
+        xh = F.normalize(x, dim=-1) if norm_descs else x
+        K, D = c.shape
+        if labels is not None:
+            out = torch.zeros(K, D)
+            for k in sorted(set(labels.tolist())):
+                out[k] = (xh[labels == k] - c[k]).sum(0)
+        else:
+            res = xh[:, None, :] - c[None]
+            out = torch.stack([(soft[:, k, None, None] * res).reshape(-1, D).sum(0) for k in range(K)])
+        if intra_norm:
+            out = F.normalize(out, dim=1)
+        return F.normalize(out.reshape(-1), dim=0)
+
+    def vlad_soft_weights(tokens, centers, soft_temp=1.0):
+        cos = F.cosine_similarity(tokens.float()[:, None, :], centers.float()[None], dim=2)
+        return F.softmax(soft_temp * cos, dim=1)
+
+    monkeypatch.setattr(ops, "vlad_residuals", vlad_residuals)
+    monkeypatch.setattr(ops, "vlad_assigned", vlad_assigned)
+    monkeypatch.setattr(ops, "vlad_soft_weights", vlad_soft_weights)
     monkeypatch.setattr(ops, "pool", pool)
     monkeypatch.setattr(ops, "gemm_nt", lambda a, w, bias=None: a.float() @ w.float().t() + (0 if bias is None else bias))
     monkeypatch.setattr(ops, "_f32c", lambda t, device=None: t.detach().to("cpu", torch.float32).contiguous())

@@ -82,8 +82,16 @@ def _kmeans_job(rank, world, out_dir):
     assert km.n_iter_ == ref.n_iter_
     assert float((km.centroids - ref.centroids).abs().max()) < 1e-5   # same result as the flat fit
     assert torch.equal(lab, lab_ref[:half] if rank == 0 else lab_ref[half:])
-    with pytest.raises(ValueError):
-        hk.KMeans(7, mode="cosine", process_group=dist.group.WORLD, step_fn=step).fit(x_loc)
+    # no explicit init: rank 0 draws np.random.choice over ALL rows, the draw is broadcast and the rows are collected --
+    # the same centroids as the flat fit started from the same NumPy RNG state
+    np.random.seed(123)
+    km2 = hk.KMeans(7, mode="cosine", process_group=dist.group.WORLD, step_fn=step)
+    km2.fit(x_loc)
+    np.random.seed(123)
+    ref2 = fpk_kmeans.KMeans(7, mode="cosine")
+    ref2.fit(x)
+    assert km2.n_iter_ == ref2.n_iter_
+    assert float((km2.centroids - ref2.centroids).abs().max()) < 1e-5
     if rank == 0:
         open(os.path.join(out_dir, "kmeans_ok"), "w").write("1")
 

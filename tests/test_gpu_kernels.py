@@ -136,3 +136,33 @@ def test_preprocess_u8_matches_totensor_normalize_centercrop(dev, H, W):
     ref = x[..., t:t + th, l:l + tw]
     assert out.shape == ref.shape
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("H,W,max_size", [(480, 640, 322), (700, 500, 448), (333, 1024, 1024), (2000, 1500, 1024)])
+def test_ingest_with_bicubic_downscale(dev, H, W, max_size):
+    """uint8 ingest with the demo's downscale rule (demo/anyloc_vlad_generate.py:163-181): ToTensor + Normalize, bicubic
+    resize so the longer side is max_img_size (aspect kept), CenterCrop to multiples of 14 -- vs the same steps in torch."""
+    from anyloc_amd import preprocess, synth
+    g = torch.Generator().manual_seed(H * 3 + W)
+    u8 = (torch.rand(2, H // 8, W // 8, 3, generator=g) * 255).to(torch.uint8)
+    u8 = torch.nn.functional.interpolate(u8.permute(0, 3, 1, 2).float(), size=(H, W), mode="bilinear").permute(0, 2, 3, 1)
+    u8 = (u8 + 8 * torch.rand(2, H, W, 3, generator=g)).clamp(0, 255).to(torch.uint8)
+    out = preprocess.images_to_input(u8, max_img_size=max_size).cpu()
+    x = u8.permute(0, 3, 1, 2).float().div(255)
+    x = (x - torch.tensor(synth.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(synth.IMAGENET_STD).view(1, 3, 1, 1)
+    if max(H, W) > max_size:
+        if H == max(H, W):
+            w2, h2 = int(W * max_size / H), max_size
+        else:
+            h2, w2 = int(H * max_size / W), max_size
+        x = torch.nn.functional.interpolate(x, size=(h2, w2), mode="bicubic", align_corners=False)
+    h, w = x.shape[-2:]
+    th, tw = h // 14 * 14, w // 14 * 14
+    t, l = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+    ref = x[..., t:t + th, l:l + tw]
+    assert out.shape == ref.shape and out.shape[-1] % 14 == 0 and out.shape[-2] % 14 == 0
+    assert float((out - ref).abs().max()) < 2e-5
+    # the resize alone, an upscale too
+    y = torch.randn(1, 3, 37, 53, generator=g)
+    up = preprocess.resize_bicubic(y.to(dev), (90, 61)).cpu()
+    assert float((up - torch.nn.functional.interpolate(y, size=(90, 61), mode="bicubic", align_corners=False)).abs().max()) < 1e-5

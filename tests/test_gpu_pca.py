@@ -77,3 +77,44 @@ def test_pca_then_retrieval_keeps_ranking():
     d1, i1 = ops.topk(red_qu, red_db, 5, "ip")
     assert torch.equal(i0[:, 0], torch.arange(0, 600, 10, device=DEV))
     assert float((i0 != i1).float().mean()) < 0.01 and float((d0 - d1).abs().max()) < 1e-4
+
+
+def test_joint_pca_project_matches_reference_script_expression():
+    """scripts/joint_pca_project.py:62-101: one PCA fitted on the concatenated databases of several datasets, every
+    database / query set projected with it and split back."""
+    from sklearn.decomposition import PCA as SkPCA
+    from anyloc_amd import pca
+    dbs = [decaying(120, 1024, seed=11, rank=60), decaying(90, 1024, seed=12, rank=60)]
+    qus = [decaying(20, 1024, seed=13, rank=20), decaying(31, 1024, seed=14, rank=31)]
+    sk = SkPCA(n_components=48, whiten=True)
+    want_db = sk.fit_transform(np.concatenate([d.double().numpy() for d in dbs]))
+    want_qu = sk.transform(np.concatenate([q.double().numpy() for q in qus]))
+    out_db, out_qu, fitted = pca.joint_pca_project(dbs, qus, 48, whiten=True)
+    assert [tuple(o.shape) for o in out_db] == [(120, 48), (90, 48)] and [tuple(o.shape) for o in out_qu] == [(20, 48), (31, 48)]
+    assert out_db[0].device.type == "cpu"                              # CPU tensors in -> CPU tensors out
+    got_db, got_qu = torch.cat(out_db).numpy(), torch.cat(out_qu).numpy()
+    scale = np.abs(want_db).max()
+    assert np.abs(got_db - want_db).max() < 5e-4 * scale and np.abs(got_qu - want_qu).max() < 5e-4 * max(scale, np.abs(want_qu).max())
+    a, b, _ = pca.joint_pca_project([d.numpy() for d in dbs], [q.numpy() for q in qus], 48)
+    assert isinstance(a[1], np.ndarray) and a[1].shape == (90, 48)
+
+
+def test_pca_u_based_sign_rule_and_rank_deficient_axes():
+    """sign_convention='u' = svd_flip of the sklearn versions the reference pins (largest |entry| of every U column
+    positive); n_components == n_samples leaves one direction without variance after centring -- it must come out as a
+    zero axis (zero coordinates, also when whitening), not inf / NaN."""
+    from anyloc_amd import pca
+    x = decaying(40, 512, seed=21, rank=40)
+    xc = (x - x.mean(0)).double()
+    u, s, vt = torch.linalg.svd(xc, full_matrices=False)
+    sign_u = torch.sign(u[u.abs().argmax(dim=0), torch.arange(u.shape[1])])          # u-based svd_flip
+    want = (vt * sign_u[:, None])[:12]
+    ours = pca.PCA(12, sign_convention="u").fit(x.to(DEV))
+    assert float((ours.components_.cpu().double() - want).abs().max()) < 2e-5
+    v_rule = pca.PCA(12).fit(x.to(DEV)).components_.cpu()
+    assert float((v_rule.abs() - ours.components_.cpu().abs()).abs().max()) < 2e-5   # same axes up to sign
+    full = pca.PCA(40, whiten=True).fit(x.to(DEV))                                     # rank 39 after centring
+    z = full.transform(x.to(DEV))
+    assert bool(torch.isfinite(z).all()) and bool(torch.isfinite(full.components_).all())
+    assert float(z[:, -1].abs().max()) == 0.0 and float(full.components_[-1].abs().max()) == 0.0
+    assert float((z[:, :39].var(dim=0, unbiased=True) - 1.0).abs().max()) < 1e-2      # whitened: unit variance

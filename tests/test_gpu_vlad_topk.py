@@ -56,7 +56,7 @@ def test_vlad_hard_golden(golden_dir, tag):
             assert float(out[0, k * D:(k + 1) * D].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("K,D,N", [(8, 384, 256), (32, 1536, 529), (64, 1024, 300), (5, 64, 77), (128, 128, 500)])
+@pytest.mark.parametrize("K,D,N", [(8, 384, 256), (32, 1536, 529), (64, 1024, 300), (5, 64, 77), (128, 128, 500), (200, 256, 700)])
 def test_vlad_hard_vs_oracle_flags_and_ragged(K, D, N):
     from anyloc_amd import ops
     g = torch.Generator().manual_seed(K * D + N)
