@@ -563,22 +563,22 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
           for (int s2 = 0; s2 < 2; ++s2)
             vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
         }
-      // scores in the exp2 domain: t = S_true * log2(e), S_true = sacc * fq * fk / 8
+      // scores in the exp2 domain: t = S_true * log2(e) = sacc * c, c = fq * fk * log2(e) / 8 > 0 -- the maximum is taken
+      // on the raw accumulators (a positive scale commutes with max) and the scale rides in the exponent's FMA
       const float c = fq * fk * (0.125f * 1.44269504088896340736f);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] *= c;
-      if (gk == g_first || gk == g_last) {
-        const int64_t kb = gk * 32 + 4 * h2;
+      if (gk == g_first || gk == g_last) {                  // wave-uniform: only the image's first / last key group
+        asm volatile("" ::: "memory");                      // (keeps the compiler from if-converting the block into 48 selects per tile)
+        const int klo = (int)(r0 - gk * 32) - 4 * h2, khi = (int)(r1 - gk * 32) - 4 * h2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t key = kb + (r & 3) + 8 * (r >> 2);
-          if (key < r0 || key >= r1) sacc[r] = -INFINITY;
+          const int ko = (r & 3) + 8 * (r >> 2);
+          if (ko < klo || ko >= khi) sacc[r] = -INFINITY;
         }
       }
       float mloc = sacc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c;
       const float m_new = fmaxf(m_run, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       const float moff = 14.0f - m_new;                    // P * 2^14: hi + lo in fp16, the factor cancels against l
@@ -586,7 +586,8 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
       attn_u32x4 pf[2][2];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(sacc[r] + moff), p1 = __builtin_amdgcn_exp2f(sacc[r + 1] + moff);
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c, moff));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r + 1], c, moff));
         lsum += p0;
         lsum += p1;
         unsigned hi, lo;
@@ -600,7 +601,8 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
       // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
       const float resc = alpha * (t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv));
       fv_run = fv;
-      if (!__all(resc == 1.0f)) {
+      if (!__all(resc == 1.0f)) {                           // rare after the first tiles: keep it a real branch
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[0][r] *= resc; oacc[1][r] *= resc; }
       }

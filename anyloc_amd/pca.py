@@ -93,7 +93,8 @@ class PCA:
         # axes of (numerically) zero variance -- rank-deficient data, e.g. n_components == n_samples after centring -- carry
         # no direction: U^T Xc / s would divide noise by ~0.  They are set to zero (every projection onto them is 0,
         # also under whitening) instead of being blown up to inf / NaN.
-        dead = s[:k] <= s[0] * max(n, f) * torch.finfo(torch.float64).eps
+        # (threshold: the singular values rounding noise of the fp32 data itself reaches, ~ eps32 * sqrt(max(n, f)) * s_0)
+        dead = s[:k] <= s[0] * 4.0 * float(max(n, f)) ** 0.5 * torch.finfo(torch.float32).eps
         axes = torch.where(dead[:, None].to(axes.device), torch.zeros_like(axes), axes)
         # unit length in fp32 (the GEMM above leaves ~1e-7 of drift) and sklearn's sign rule
         axes = torch.nn.functional.normalize(axes, dim=1)

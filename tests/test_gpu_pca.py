@@ -86,17 +86,21 @@ def test_joint_pca_project_matches_reference_script_expression():
     from anyloc_amd import pca
     dbs = [decaying(120, 1024, seed=11, rank=60), decaying(90, 1024, seed=12, rank=60)]
     qus = [decaying(20, 1024, seed=13, rank=20), decaying(31, 1024, seed=14, rank=31)]
-    sk = SkPCA(n_components=48, whiten=True)
+    sk = SkPCA(n_components=48, whiten=False)
     want_db = sk.fit_transform(np.concatenate([d.double().numpy() for d in dbs]))
     want_qu = sk.transform(np.concatenate([q.double().numpy() for q in qus]))
-    out_db, out_qu, fitted = pca.joint_pca_project(dbs, qus, 48, whiten=True)
+    out_db, out_qu, fitted = pca.joint_pca_project(dbs, qus, 48, whiten=False)
     assert [tuple(o.shape) for o in out_db] == [(120, 48), (90, 48)] and [tuple(o.shape) for o in out_qu] == [(20, 48), (31, 48)]
     assert out_db[0].device.type == "cpu"                              # CPU tensors in -> CPU tensors out
     got_db, got_qu = torch.cat(out_db).numpy(), torch.cat(out_qu).numpy()
     scale = np.abs(want_db).max()
     assert np.abs(got_db - want_db).max() < 5e-4 * scale and np.abs(got_qu - want_qu).max() < 5e-4 * max(scale, np.abs(want_qu).max())
-    a, b, _ = pca.joint_pca_project([d.numpy() for d in dbs], [q.numpy() for q in qus], 48)
+    a, b, _ = pca.joint_pca_project([d.numpy() for d in dbs], [q.numpy() for q in qus], 48, whiten=True)
     assert isinstance(a[1], np.ndarray) and a[1].shape == (90, 48)
+    skw = SkPCA(n_components=48, whiten=True).fit(np.concatenate([d.double().numpy() for d in dbs]))
+    want_w = skw.transform(np.concatenate([q.double().numpy() for q in qus]))
+    # whitening divides the trailing axes' fp32 projections by a standard deviation ~100x below the leading one
+    assert np.abs(np.concatenate(b) - want_w).max() < 5e-3 * np.abs(want_w).max()
 
 
 def test_pca_u_based_sign_rule_and_rank_deficient_axes():
