@@ -463,10 +463,17 @@ __device__ __forceinline__ void ah_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned c
 
 constexpr int AH_STAGE = 16384;       // K hi | K lo | V hi | V lo, 4 KiB each
 
-__global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
-                                                              const float* __restrict__ inv, int T, int heads, int64_t G,
-                                                              unsigned char* __restrict__ out2, float* __restrict__ out_inv,
-                                                              int64_t R) {
+// QG = 32-query groups per wave (1 or 2), NW = waves per workgroup; a workgroup always covers QG * NW = 4 consecutive
+// groups (128 queries) of one (image, head).  QG = 2: a wave's K / V fragments serve 64 queries, i.e. half the LDS reads,
+// DMA issues and barriers per unit of work, at 2 waves per SIMD.
+template <int QG, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
+                                                                  const float* __restrict__ inv, int T, int heads, int64_t G,
+                                                                  unsigned char* __restrict__ out2, float* __restrict__ out_inv,
+                                                                  int64_t R) {
+  static_assert(QG * NW == 4 && (QG == 1 || QG == 2), "a workgroup covers four 32-query groups");
+  constexpr int NT = 64 * NW;
+  constexpr int PIECES = 16 / NW;       // 1-KiB DMA pieces per wave and key tile
   extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];   // 2 stages + 16 bytes for the block reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y;
@@ -474,15 +481,14 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
   const int64_t r0 = b * T, r1 = r0 + T;
   const int64_t g_first = r0 >> 5, g_last = (r1 - 1) >> 5;
   const int ng = (int)(g_last - g_first + 1);
-  const int64_t gq_raw = g_first + blockIdx.x * 4 + wave;
-  const bool wave_active = gq_raw <= g_last;
-  const int64_t gq = wave_active ? gq_raw : g_last;
+  const int64_t gq0 = g_first + blockIdx.x * 4 + wave * QG;
+  const bool wave_active = gq0 <= g_last;
   const int ql = lane & 31, h2 = lane >> 5;
   const int64_t tile_bytes = 8192;
 
   // ---- scale of this image's output rows: the largest V-tile scale over all heads and key groups ----
   float fm = 0.f;
-  for (int i = tid; i < heads * ng; i += 256) {
+  for (int i = tid; i < heads * ng; i += NT) {
     const int hh = i / ng, gg = i - hh * ng;
     fm = fmaxf(fm, inv[((int64_t)2 * heads + hh) * G + g_first + gg]);
   }
@@ -490,41 +496,61 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
   float* red = reinterpret_cast<float*>(ah_smem + 2 * AH_STAGE);
   if (lane == 0) red[wave] = fm;
   __syncthreads();
-  fm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  fm = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) fm = fmaxf(fm, red[w]);
 
   // ---- Q fragments (B operand): lane (query ql, half h2), k-step s: d = 16 s + 8 h2 + j = chunk 2 s + h2 of row ql ----
-  attn_u32x4 qf[2][4];
-  const int64_t q_tile = ((int64_t)h) * G + gq;
-  const float fq = inv[q_tile];
-  {
+  attn_u32x4 qf[QG][2][4];
+  float fq[QG];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const int64_t gq = min(gq0 + qg, g_last);
+    const int64_t q_tile = ((int64_t)h) * G + gq;
+    fq[qg] = inv[q_tile];
     const unsigned char* qb = planes + q_tile * tile_bytes + ql * 128;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        qf[pl][s] = *reinterpret_cast<const attn_u32x4*>(qb + pl * 4096 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
+        qf[qg][pl][s] = *reinterpret_cast<const attn_u32x4*>(qb + pl * 4096 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
   }
 
-  // ---- K / V staging: pure DMA, wave w moves bytes [w KiB, w KiB + 1 KiB) of each of the four 4-KiB plane tiles ----
+  // ---- K / V staging: pure DMA of the four 4-KiB plane tiles [K hi | K lo | V hi | V lo], 1 KiB per wave instruction ----
   const int64_t part_bytes = (int64_t)heads * G * tile_bytes;
   const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(planes + part_bytes), 0, (int)part_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(planes + 2 * part_bytes), 0, (int)part_bytes, 0x00020000);
-  const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
   auto issue = [&](int t, int stage) {
     const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
-    unsigned char* st = ah_smem + stage * AH_STAGE + wave * 1024;
-    ah_dma16(k_rsrc, st, voff, soff);
-    ah_dma16(k_rsrc, st + 4096, voff + 4096, soff);
-    ah_dma16(v_rsrc, st + 8192, voff, soff);
-    ah_dma16(v_rsrc, st + 12288, voff + 4096, soff);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int piece = i * NW + wave;                     // 0..7: K planes, 8..15: V planes
+      unsigned char* st = ah_smem + stage * AH_STAGE + piece * 1024;
+      const unsigned voff = (unsigned)((piece & 7) * 1024 + lane * 16);
+      if (i * NW < 8) ah_dma16(k_rsrc, st, voff, soff);
+      else ah_dma16(v_rsrc, st, voff, soff);
+    }
   };
 
-  f32x16 oacc[2];
+  // per-tile K / V scales: lane t keeps those of key tile t (ng <= 64 for T <= 1984; longer images fall back to loads)
+  float fk_lane = 1.0f, fv_lane = 1.0f;
+  if (lane < ng) {
+    fk_lane = inv[((int64_t)heads + h) * G + g_first + lane];
+    fv_lane = inv[((int64_t)2 * heads + h) * G + g_first + lane];
+  }
+
+  f32x16 oacc[QG][2];
+  float m_run[QG], l_run[QG];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f, fv_run = 1.0f;
+  for (int qg = 0; qg < QG; ++qg) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[qg][0][r] = 0.f; oacc[qg][1][r] = 0.f; }
+    m_run[qg] = -INFINITY;
+    l_run[qg] = 0.f;
+  }
+  float fv_run = 1.0f;
 
   issue(0, 0);
   __syncthreads();                      // drains the DMA counter (fence) and publishes stage 0
@@ -536,21 +562,32 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
       const int64_t gk = g_first + t;
       const unsigned char* Ks = ah_smem + stage * AH_STAGE;
       const unsigned char* Vs = Ks + 8192;
-      const float fk = inv[((int64_t)heads + h) * G + gk];
-      const float fv = inv[((int64_t)2 * heads + h) * G + gk];
+      float fk, fv;
+      if (ng <= 64) {                   // wave-uniform lane index: v_readlane, no memory access in the loop
+        fk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fk_lane), t));
+        fv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fv_lane), t));
+      } else {
+        fk = inv[((int64_t)heads + h) * G + gk];
+        fv = inv[((int64_t)2 * heads + h) * G + gk];
+      }
       // S^T = K_tile (A: rows = keys) x Q^T (B: cols = queries): 4 k-steps of 16 d, lo*hi + hi*lo + hi*hi
-      f32x16 sacc;
+      f32x16 sacc[QG];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[qg][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         attn_u32x4 kf[2];
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
           kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
-        sacc = ANYLOC_MFMA_F16(kf[1], qf[0][s], sacc);
-        sacc = ANYLOC_MFMA_F16(kf[0], qf[1][s], sacc);
-        sacc = ANYLOC_MFMA_F16(kf[0], qf[0][s], sacc);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+          sacc[qg] = ANYLOC_MFMA_F16(kf[1], qf[qg][0][s], sacc[qg]);
+          sacc[qg] = ANYLOC_MFMA_F16(kf[0], qf[qg][1][s], sacc[qg]);
+          sacc[qg] = ANYLOC_MFMA_F16(kf[0], qf[qg][0][s], sacc[qg]);
+        }
       }
       // V^T fragments: lane (d = db*32 + ql, half h2), k-step s2: the 8 keys register r = 8 s2 + j of the score block holds
       attn_u32x4 vf[2][2][2];
@@ -563,78 +600,86 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const unsigned cha
           for (int s2 = 0; s2 < 2; ++s2)
             vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
         }
-      // scores in the exp2 domain: t = S_true * log2(e) = sacc * c, c = fq * fk * log2(e) / 8 > 0 -- the maximum is taken
-      // on the raw accumulators (a positive scale commutes with max) and the scale rides in the exponent's FMA
-      const float c = fq * fk * (0.125f * 1.44269504088896340736f);
-      if (gk == g_first || gk == g_last) {                  // wave-uniform: only the image's first / last key group
-        asm volatile("" ::: "memory");                      // (keeps the compiler from if-converting the block into 48 selects per tile)
-        const int klo = (int)(r0 - gk * 32) - 4 * h2, khi = (int)(r1 - gk * 32) - 4 * h2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ko = (r & 3) + 8 * (r >> 2);
-          if (ko < klo || ko >= khi) sacc[r] = -INFINITY;
-        }
-      }
-      float mloc = sacc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c;
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      const float moff = 14.0f - m_new;                    // P * 2^14: hi + lo in fp16, the factor cancels against l
-      float lsum = 0.f;
-      attn_u32x4 pf[2][2];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c, moff));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r + 1], c, moff));
-        lsum += p0;
-        lsum += p1;
-        unsigned hi, lo;
-        ah_pack2(p0, p1, hi, lo);
-        pf[0][r >> 3][(r & 7) >> 1] = hi;
-        pf[1][r >> 3][(r & 7) >> 1] = lo;
-      }
-      lsum += __shfl_xor(lsum, 32, 64);
-      l_run = l_run * alpha + lsum;
-      m_run = m_new;
+      const bool edge = gk == g_first || gk == g_last;      // wave-uniform: only the image's first / last key group
       // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
-      const float resc = alpha * (t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv));
+      const float vratio = t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv);
       fv_run = fv;
-      if (!__all(resc == 1.0f)) {                           // rare after the first tiles: keep it a real branch
-        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[0][r] *= resc; oacc[1][r] *= resc; }
-      }
+      for (int qg = 0; qg < QG; ++qg) {
+        // scores in the exp2 domain: t = S_true * log2(e) = sacc * c, c = fq * fk * log2(e) / 8 > 0 -- the maximum is
+        // taken on the raw accumulators (a positive scale commutes with max), the scale rides in the exponent's FMA
+        const float c = fq[qg] * fk * (0.125f * 1.44269504088896340736f);
+        if (edge) {
+          asm volatile("" ::: "memory");                    // (keeps the compiler from if-converting the block into selects)
+          const int klo = (int)(r0 - gk * 32) - 4 * h2, khi = (int)(r1 - gk * 32) - 4 * h2;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          oacc[db] = ANYLOC_MFMA_F16(vf[1][db][s2], pf[0][s2], oacc[db]);
-          oacc[db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[1][s2], oacc[db]);
-          oacc[db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[0][s2], oacc[db]);
+          for (int r = 0; r < 16; ++r) {
+            const int ko = (r & 3) + 8 * (r >> 2);
+            if (ko < klo || ko >= khi) sacc[qg][r] = -INFINITY;
+          }
         }
+        float mloc = sacc[qg][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[qg][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c;
+        const float m_new = fmaxf(m_run[qg], mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
+        const float moff = 14.0f - m_new;                  // P * 2^14: hi + lo in fp16, the factor cancels against l
+        float lsum = 0.f;
+        attn_u32x4 pf[2][2];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][r], c, moff));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][r + 1], c, moff));
+          lsum += p0;
+          lsum += p1;
+          unsigned hi, lo;
+          ah_pack2(p0, p1, hi, lo);
+          pf[0][r >> 3][(r & 7) >> 1] = hi;
+          pf[1][r >> 3][(r & 7) >> 1] = lo;
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run[qg] = l_run[qg] * alpha + lsum;
+        m_run[qg] = m_new;
+        const float resc = alpha * vratio;
+        if (!__all(resc == 1.0f)) {                         // rare after the first tiles: keep it a real branch
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { oacc[qg][0][r] *= resc; oacc[qg][1][r] *= resc; }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            oacc[qg][db] = ANYLOC_MFMA_F16(vf[1][db][s2], pf[0][s2], oacc[qg][db]);
+            oacc[qg][db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[1][s2], oacc[qg][db]);
+            oacc[qg][db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[0][s2], oacc[qg][db]);
+          }
+      }
     }
     __syncthreads();                    // everyone is done with this stage; the next tile's DMA has landed
   }
 
   // oacc[db][r] = O[q][db*32 + (r&3) + 8*(r>>2) + 4*h2] * l_run / fv_run (in P * 2^14 units, which cancel against l_run)
-  const int64_t row = gq * 32 + ql;
-  if (wave_active && row >= r0 && row < r1) {
-    const float f = fv_run * ah_pow2_recip(fm) / l_run;        // -> value * 2^e_img, |.| < 2^15
-    if (h == 0 && h2 == 0) out_inv[row] = fm;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int qg = 0; qg < QG; ++qg) {
+    const int64_t row = (gq0 + qg) * 32 + ql;
+    if (wave_active && gq0 + qg <= g_last && row >= r0 && row < r1) {
+      const float f = fv_run * ah_pow2_recip(fm) / l_run[qg];        // -> value * 2^e_img, |.| < 2^15
+      if (h == 0 && h2 == 0) out_inv[row] = fm;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
-        unsigned char* dst = out2 + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
-        uint2 ph, plo;
-        ah_pack2(oacc[db][4 * g + 0] * f, oacc[db][4 * g + 1] * f, ph.x, plo.x);
-        ah_pack2(oacc[db][4 * g + 2] * f, oacc[db][4 * g + 3] * f, ph.y, plo.y);
-        *reinterpret_cast<uint2*>(dst) = ph;
-        *reinterpret_cast<uint2*>(dst + R * 32) = plo;
-      }
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
+          unsigned char* dst = out2 + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
+          uint2 ph, plo;
+          ah_pack2(oacc[qg][db][4 * g + 0] * f, oacc[qg][db][4 * g + 1] * f, ph.x, plo.x);
+          ah_pack2(oacc[qg][db][4 * g + 2] * f, oacc[qg][db][4 * g + 3] * f, ph.y, plo.y);
+          *reinterpret_cast<uint2*>(dst) = ph;
+          *reinterpret_cast<uint2*>(dst + R * 32) = plo;
+        }
+    }
   }
 }
 
@@ -708,14 +753,18 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   ProfScope prof("attention", stream, flops, 8.0 * batch * T * D * 2);
   const int qgroups = (T + 31) / 32 + 1;                    // an image intersects at most this many 32-row groups
   const size_t lds = 2 * AH_STAGE + 64;
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    attr = true;
+  // ANYLOC_ATTN_H3_CFG (A/B): 0 (default) = four waves of 32 queries per workgroup, 1 = two waves of 64 queries
+  // (measured at B=61: 12.7 vs 13.7 ms per step)
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("ANYLOC_ATTN_H3_CFG");
+    cfg = e ? atoi(e) : 0;
   }
-  hipLaunchKernelGGL(attention_h3_kernel, dim3((qgroups + 3) / 4, heads, (unsigned)batch), dim3(256), lds, stream, planes, inv, T,
-                     heads, G, out2, out_inv, R);
+  const dim3 grid((qgroups + 3) / 4, heads, (unsigned)batch);
+  if (cfg == 0)
+    hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
+  else
+    hipLaunchKernelGGL((attention_h3_kernel<2, 2>), grid, dim3(128), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
   return launch_status("attention_h3_kernel");
 }
 
