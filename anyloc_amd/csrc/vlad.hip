@@ -343,6 +343,16 @@ inline bool fused_forced() {
   return v == 1;
 }
 
+// images from which the single-launch fused kernel (one workgroup per image) is used; ANYLOC_VLAD_FUSED_MIN overrides
+inline int64_t fused_min_images() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("ANYLOC_VLAD_FUSED_MIN");
+    v = e ? atoll(e) : 160;
+  }
+  return v;
+}
+
 // ANYLOC_VLAD_TWO_PASS=1 selects the two-pass path even where the fused kernel applies (A/B tests)
 inline bool two_pass_forced() {
   static int v = -1;
@@ -426,7 +436,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   // One workgroup per image: below ~160 images the fused kernel cannot fill the 256 CUs and the
   // two-pass path (grid = images x column slices) is faster (61 images: 0.25 vs 0.48 ms);
   // ANYLOC_VLAD_FUSED=1 forces the fused kernel regardless.
-  if (fused_supported(D, K) && !two_pass_forced() && (n_img >= 160 || fused_forced())) {
+  if (fused_supported(D, K) && !two_pass_forced() && (n_img >= fused_min_images() || fused_forced())) {
     // single-pass fused kernel (vlad_fused.hip): tokens are read from HBM once
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);

@@ -44,8 +44,9 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
   constexpr int D = NV * 128;
   constexpr int LD = D + 4;                  // padded LDS row: conflict-free ds_read_b128 of A fragments
   constexpr int NF = (NV + 1) / 2;           // staged float4 per thread per tile (4*D/1024 = NV/2)
-  constexpr int SW = 8;                      // scoring waves 0-7: each contracts a D/8 slice
-  constexpr int NG = NV;                     // 16-wide k-groups per scoring wave
+  constexpr int SW = 8;                      // scoring waves 0-7: each contracts a D/8 slice (all 16 waves on D/16 slices
+                                             // measured no faster: the tile loop is bound by its chain of phases, not by MFMA)
+  constexpr int NG = NV * 8 / SW;            // 16-wide k-groups per scoring wave
   // vmcnt retires in order PER WAVE: a wave that has the HBM loads of the next tile in flight
   // stalls on them at its next L2 load.  So the scoring waves (0-7) issue their share of the
   // next tile only AFTER their scoring loop, the other waves (8-15) at the top of the iteration;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // thread owns float4 slots f = tid + 1024*i of the [16][D/4] tile; slot -> (row, column) is
   // recomputed where needed (constant divisor) to save registers
-  const bool scorer = wave < 8;
+  const bool scorer = wave < SW;
   auto fetch = [&](int t) {
     const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
 #pragma unroll
