@@ -161,6 +161,7 @@ struct H3Problem {
   const float* gamma;                       // EPI_LS_RESID
   const float* resid;                       // EPI_LS_RESID, leading dim ldc
   int epi_lds;                              // EPI_LS_RESID: transposed 16-byte epilogue through LDS (set by gemm_h3)
+  int group_m;                              // tile-rows per XCD scheduling group (set by gemm_h3)
   // EPI_QKV_PLANES: N = 3 * heads * 64; see QkvPlanes below
   unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
   // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])

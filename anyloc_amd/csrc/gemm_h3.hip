@@ -25,12 +25,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void htile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void htile_coords(int bid, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
   const int nb = tiles_m * tiles_n;
   const int q = nb >> 3, r = nb & 7;
   const int xcd = bid & 7, loc = bid >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  constexpr int GM = 8;
   const int group_size = GM * tiles_n;
   const int g = logical / group_size;
   const int first_m = g * GM;
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int tm, tn;
-  htile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  htile_coords(blockIdx.x, tiles_m, tiles_n, p.group_m, tm, tn);
   const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
 
   const unsigned a_slab = (unsigned)(2 * p.RA * 32), w_slab = (unsigned)(2 * p.RW * 32);
@@ -733,13 +732,22 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
   return launch_status("gemm_h3_kernel");
 }
 
-int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream) {
+int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
+  H3Problem p = p_in;
   ANYLOC_CHECK_ARG(p.A2 && p.a_inv && p.W2 && p.w_inv && (p.C || epilogue >= EPI_QKV_PLANES), "gemm_h3: null operand");
   ANYLOC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K16 > 0 && p.RA >= p.M && p.RW >= p.N, "gemm_h3: bad shape");
   ANYLOC_CHECK_ARG((size_t)p.K16 * 2 * (size_t)p.RA * 32 < (1ull << 31) && (size_t)p.K16 * 2 * (size_t)p.RW * 32 < (1ull << 31),
                    "gemm_h3: operand image exceeds the 2 GiB buffer-addressing range");
   const int64_t K = 16ll * p.K16;
   ProfScope prof(p.tag ? p.tag : "gemm_h3", stream, 2.0 * p.M * p.N * K, 4.0 * (p.M + p.N) * K + 4.0 * p.M * p.N);
+  // tile-rows per scheduling group (co-resident workgroups of an XCD share A / W panels through its L2); ANYLOC_H3_GM
+  // overrides the default of 8 (micro-benchmarks)
+  static int gm = -1;
+  if (gm < 0) {
+    const char* e = getenv("ANYLOC_H3_GM");
+    gm = e ? std::max(1, atoi(e)) : 8;
+  }
+  p.group_m = gm;
   switch (epilogue) {
     case EPI_STORE: return dispatch_h3<EPI_STORE>(p, stream);
     case EPI_GELU: return dispatch_h3<EPI_GELU>(p, stream);

@@ -96,6 +96,15 @@ int64_t x6_min_rows() {
   const char* e = getenv("ANYLOC_X6_MIN_ROWS");
   return e ? atoll(e) : 1600;
 }
+// the two-term fp16 forward has no such threshold any more: with q | k | v, the attention output and the FFN activation
+// kept in fp16 planes it beats the fp32-MFMA kernels at every batch (B=1: 9.6 vs 16.5 ms, B=2: 11.3 vs 21.4 ms per batch,
+// profiles/r02_extractor_vs_batch.log); ANYLOC_H3_MIN_ROWS (or the older ANYLOC_X6_MIN_ROWS) restores one
+int64_t h3_min_rows() {
+  const char* e = getenv("ANYLOC_H3_MIN_ROWS");
+  if (e) return atoll(e);
+  e = getenv("ANYLOC_X6_MIN_ROWS");
+  return e ? atoll(e) : 0;
+}
 
 // y = act(A W^T + b) on the six-product bf16 GEMM.  A is given as fp32 (split into planes here) or, when A == nullptr,
 // a3 already holds its plane image (written by the producer).  c3 != nullptr: the activation is written as the plane
@@ -280,7 +289,7 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
   // honoured from x6_min_rows() rows up (ANYLOC_X6_MIN_ROWS overrides)
   ANYLOC_CHECK_ARG(!(flags & ANYLOC_VIT_SPLIT_FP16) || !h->h2.empty(),
                    "vit_forward: ANYLOC_VIT_SPLIT_FP16 without anyloc_vit_attach_h2");
-  const bool h3m = (flags & ANYLOC_VIT_SPLIT_FP16) && M >= x6_min_rows();
+  const bool h3m = (flags & ANYLOC_VIT_SPLIT_FP16) && M >= h3_min_rows();
   const bool x6 = !h3m && (flags & ANYLOC_VIT_SPLIT_BF16) && M >= x6_min_rows();
   const bool fuse_x6 = x6 && x6_fused();
   const int h3f = h3m ? h3_fused() : 0;
