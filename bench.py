@@ -433,14 +433,17 @@ def cpu_baseline_and_parity(sd, qu_img, vlad, db, ext, budget_s, warm, B):
     # on ONE transformer block first (a few seconds), then time whole images with it
     probe = torch.randn(1, 530, 1536)
     best_t, threads = None, cores
-    for nt in sorted({min(cores, n) for n in (16, 32, 64, 128, cores)}):
+    for nt in sorted({min(cores, n) for n in (16, 32, 64)}):
         torch.set_num_threads(nt)
         with torch.no_grad():
-            model.blocks[0](probe)
-            t0 = time.perf_counter()
-            model.blocks[0](probe)
-            dt = time.perf_counter() - t0
-        if best_t is None or dt < best_t:
+            model.blocks[0](probe)                    # warm-up (thread pool, allocator)
+            dt = None
+            for _ in range(3):                        # best of three: the host is shared, single runs are noisy
+                t0 = time.perf_counter()
+                model.blocks[0](probe)
+                el = time.perf_counter() - t0
+                dt = el if dt is None else min(dt, el)
+        if best_t is None or dt < 0.95 * best_t:      # prefer fewer threads unless clearly faster
             best_t, threads = dt, nt
     torch.set_num_threads(threads)
     cores = threads
