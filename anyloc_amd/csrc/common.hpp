@@ -223,6 +223,7 @@ struct FusedArgs {
   unsigned* cnt_part;      // k-means: [units, K] label counts; VLAD: null
   int64_t* lab64;          // optional [total] labels
   int norm_descs, intra;
+  unsigned long long* stamps;   // tools only (ANYLOC_KM_STAMPS = device address): per-tile phase timestamps of unit 0
 };
 bool fused_supported(int64_t D, int64_t K);
 int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream);

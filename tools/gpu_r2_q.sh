@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_vlad_topk.py tests/test_gpu_fullsize_properties.py -m gpu -q -x -k "kmeans" 2>&1 | tail -1
+for n in 4 6; do echo "NGR=$n"; ANYLOC_KM_NGR=$n timeout 300 python tools/stamp_kmeans.py 2>&1 | tail -7; ANYLOC_KM_NGR=$n timeout 300 python tools/time_kmeans.py 2>&1 | grep "^{"; done
