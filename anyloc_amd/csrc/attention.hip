@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void qkv_planes_kernel(const float* __restrict
   __syncthreads();
   amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
-  const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
+  const int e = ex == 0 ? 100 : max(-100, min(100, 14 - (ex - 127)));     // as h2_row_scale (gemm_h3.hip)
   const float scale = __uint_as_float((unsigned)(127 + e) << 23);
   const int64_t tile = ((int64_t)part * heads + h) * G + g;
   if (tid == 0) inv[tile] = __uint_as_float((unsigned)(127 - e) << 23);

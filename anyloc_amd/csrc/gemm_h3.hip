@@ -57,10 +57,12 @@ struct H3Cfg {
 };
 
 
-// scale / inverse scale of a row (or tile) from its largest magnitude: amax * 2^e in [2^14, 2^15)
+// scale / inverse scale of a row (or tile) from its largest magnitude: amax * 2^e in [2^14, 2^15).  An all-zero (or
+// denormal) row gets the LARGEST scale, 2^100: its planes are zero either way, and its 2^-100 never wins where the
+// scales of several tiles are compared (attention_h3 takes the maximum over an image's V tiles as the output's bound)
 __device__ __forceinline__ float h2_row_scale(float amax, float& inv) {
   const int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
-  const int e = ex == 0 ? 0 : max(-100, min(100, 14 - (ex - 127)));
+  const int e = ex == 0 ? 100 : max(-100, min(100, 14 - (ex - 127)));
   inv = __uint_as_float((unsigned)(127 - e) << 23);
   return __uint_as_float((unsigned)(127 + e) << 23);
 }

@@ -104,6 +104,8 @@ def test_attention_h3(dev, B, T, heads):
     qkv[0, T - 2, D:2 * D] *= 6.0
     qkv[:, ::7] *= 0.05                                   # small-magnitude tokens next to ordinary ones
     qkv[:, 5, 2 * D:] *= 40.0                             # one value row far above the others (sets the image scale)
+    if T > 64:
+        qkv[0, 32:64, 2 * D:] = 0.0                       # an all-zero V tile (global rows 32..63): must not set the scale
     img, inv = ops.attention_h3(qkv.to(dev), heads)
     out = ops.h2_image_to_f32(img, inv, B * T, D).reshape(B, T, D).cpu()
     q, k, v = qkv.double().reshape(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
