@@ -72,9 +72,9 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
                        ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
                       if split else "fp32 MFMA peak"),
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "clock_note": ("profiles/r01_pmc_x6.md: under these GEMMs the chip runs at its power limit (1.63 GHz with the matrix "
-                       "cores busy 70.9 % of SIMD cycles for h3; 1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz "
-                       "figure") if split else None,
+        "clock_note": ("profiles/r02_pmc_fused_sq_raw.md + r02_pmc_fused_write_raw.md (h3) / r01_pmc_x6.md (x6): under these GEMMs "
+                       "the chip runs at its power limit -- 1.57 GHz with the matrix cores busy 76.6 % of all SIMD cycles for "
+                       "the h3 w12 kernel (1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz figure") if split else None,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"],
         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
         "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
