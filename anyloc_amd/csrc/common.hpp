@@ -223,6 +223,9 @@ struct FusedArgs {
   unsigned* cnt_part;      // k-means: [units, K] label counts; VLAD: null
   int64_t* lab64;          // optional [total] labels
   int norm_descs, intra;
+  int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
+  float* part_buf;         // [units, parts, K, D] partial sums
+  unsigned* part_tickets;  // [units] arrival counters (zeroed by the launcher)
   unsigned long long* stamps;   // tools only (ANYLOC_KM_STAMPS = device address): per-tile phase timestamps of unit 0
 };
 bool fused_supported(int64_t D, int64_t K);

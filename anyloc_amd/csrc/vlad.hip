@@ -343,14 +343,32 @@ inline bool fused_forced() {
   return v == 1;
 }
 
-// images from which the single-launch fused kernel (one workgroup per image) is used; ANYLOC_VLAD_FUSED_MIN overrides
+// images from which the single-launch fused kernel is used; ANYLOC_VLAD_FUSED_MIN overrides
 inline int64_t fused_min_images() {
   static int64_t v = -1;
   if (v < 0) {
     const char* e = getenv("ANYLOC_VLAD_FUSED_MIN");
-    v = e ? atoll(e) : 160;
+    v = e ? atoll(e) : 1;
   }
   return v;
+}
+
+// Workgroups per image of the fused kernel: one workgroup per image cannot fill 256 CUs below ~200 images, so a small
+// batch splits every image's token tiles over up to 8 workgroups (the last to finish reduces, vlad_fused.hip); every
+// part keeps >= 2 tiles of 16 tokens on average.  ANYLOC_VLAD_PARTS forces a count (A/B, tests).
+inline int fused_parts(int64_t n_img, int64_t total) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("ANYLOC_VLAD_PARTS");
+    forced = e ? atoi(e) : 0;
+  }
+  if (n_img <= 0) return 1;
+  if (forced > 0) return forced > 64 ? 64 : forced;
+  int64_t p = 256 / n_img;
+  const int64_t tiles = (total / n_img + 15) / 16;
+  if (p > tiles / 2) p = tiles / 2;
+  if (p > 8) p = 8;
+  return p < 1 ? 1 : (int)p;
 }
 
 // ANYLOC_VLAD_TWO_PASS=1 selects the two-pass path even where the fused kernel applies (A/B tests)
@@ -366,9 +384,11 @@ inline bool two_pass_forced() {
 struct VladWs {
   float *chat, *cb, *scores, *rowsq, *nrm;
   int* lab32;
+  float* part_buf;
+  unsigned* tickets;
   size_t bytes;
 };
-VladWs carve(void* ws, size_t cap, int64_t n, int64_t D, int64_t K) {
+VladWs carve(void* ws, size_t cap, int64_t n, int64_t D, int64_t K, int64_t n_img = 0, int parts = 1) {
   Arena a(ws, cap);
   VladWs w;
   const int64_t kp = kpad_of(K);
@@ -378,6 +398,12 @@ VladWs carve(void* ws, size_t cap, int64_t n, int64_t D, int64_t K) {
   w.rowsq = a.take<float>(n > 0 ? n : 1);
   w.nrm = a.take<float>(n > 0 ? n : 1);
   w.lab32 = a.take<int>(n > 0 ? n : 1);
+  w.part_buf = nullptr;
+  w.tickets = nullptr;
+  if (parts > 1) {
+    w.part_buf = a.take<float>(n_img * parts * K * D);
+    w.tickets = a.take<unsigned>(n_img);
+  }
   w.bytes = a.off;
   return w;
 }
@@ -403,8 +429,8 @@ using namespace anyloc;
 extern "C" {
 
 size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K) {
-  (void)n_img;
-  return carve(nullptr, 0, total_tokens, D, K).bytes + 256;
+  const int parts = (fused_supported(D, K) && n_img > 0) ? fused_parts(n_img, total_tokens) : 1;
+  return carve(nullptr, 0, total_tokens, D, K, n_img, parts).bytes + 256;
 }
 
 static int vlad_common_checks(const float* tokens, const int64_t* offsets, int64_t n_img, int64_t total, int64_t D,
@@ -424,7 +450,9 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ANYLOC_TRY(vlad_common_checks(tokens, offsets, n_img, total_tokens, D, centers, K, out));
   if (n_img == 0) return ANYLOC_OK;
-  VladWs w = carve(workspace, workspace_bytes, total_tokens, D, K);
+  const bool fused = fused_supported(D, K) && !two_pass_forced() && (n_img >= fused_min_images() || fused_forced());
+  const int parts = fused ? fused_parts(n_img, total_tokens) : 1;
+  VladWs w = carve(workspace, workspace_bytes, total_tokens, D, K, n_img, parts);
   if (!workspace || w.bytes > workspace_bytes) {
     set_error("vlad_hard: workspace %zu < %zu", workspace_bytes, w.bytes);
     return ANYLOC_ERR_WORKSPACE;
@@ -433,10 +461,8 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   // labels = kmeans.predict(tokens) in the metric the vocabulary was built with (reference utilities.py:849 with
   // VLAD(dist_mode=...)): fpk cosine score, or fpk euclidean similarity 2ab - a^2 - b^2 (arg-max = nearest centre)
   const int metric = (flags & ANYLOC_VLAD_EUCLIDEAN) ? 1 : 0;
-  // One workgroup per image: below ~160 images the fused kernel cannot fill the 256 CUs and the
-  // two-pass path (grid = images x column slices) is faster (61 images: 0.25 vs 0.48 ms);
-  // ANYLOC_VLAD_FUSED=1 forces the fused kernel regardless.
-  if (fused_supported(D, K) && !two_pass_forced() && (n_img >= fused_min_images() || fused_forced())) {
+  // The fused kernel wherever it applies (K <= 32, the ViT widths); ANYLOC_VLAD_TWO_PASS=1 selects the general path.
+  if (fused) {
     // single-pass fused kernel (vlad_fused.hip): tokens are read from HBM once
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
@@ -450,6 +476,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     fa.out = out; fa.lab64 = labels;
     fa.norm_descs = (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0;
     fa.intra = (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0;
+    fa.parts = parts; fa.part_buf = w.part_buf; fa.part_tickets = w.tickets;
     return vlad_fused(fa, n_img, false, stream);
   }
   if (total_tokens > 0) {

@@ -80,14 +80,26 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
   float* red = reinterpret_cast<float*>(lab + TT);   // [32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t unit = blockIdx.x;
+  int64_t unit = blockIdx.x;
   int64_t n0, n1;
+  int part_id = 0;
   if (KMEANS) {
     n0 = unit * a.chunk_rows;
     n1 = min(n0 + a.chunk_rows, a.total);
   } else {
+    // a.parts > 1 (few images): a.parts workgroups share an image, each walking a contiguous run of its token tiles;
+    // the last one to finish adds the partial sums in part order and normalises (see the epilogue)
+    if (a.parts > 1) {
+      part_id = (int)(unit % a.parts);
+      unit /= a.parts;
+    }
     n0 = a.offsets[unit];
     n1 = a.offsets[unit + 1];
+    if (a.parts > 1) {
+      const int64_t per = (((n1 - n0 + TT - 1) / TT) + a.parts - 1) / a.parts * TT;   // rows per part, whole tiles
+      n0 = min(n0 + part_id * per, n1);
+      n1 = min(n0 + per, n1);
+    }
   }
   const int64_t nrows = n1 - n0;
   const int ntiles = (int)((nrows + TT - 1) / TT);
@@ -263,6 +275,42 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
       if (oj == 0) a.cnt_part[unit * a.K + ok_] = my_count;
     }
     return;
+  }
+  if (a.parts > 1) {
+    // Partial sums of this part -> workspace; the workgroup that takes the last ticket of its image (a relaxed atomic
+    // between an agent-scope release and acquire: the partials of every earlier part are visible to it, whichever XCD
+    // wrote them) reduces them in PART ORDER, so the result does not depend on which workgroup arrives last.  Nobody
+    // waits on anybody: no spinning, no co-residency requirement.
+    const int64_t kd = (int64_t)a.K * D;
+    if (k_live) {
+      float* pb = a.part_buf + (unit * a.parts + part_id) * kd + (int64_t)ok_ * D + 4 * oj;
+#pragma unroll
+      for (int m = 0; m < NV; ++m) *reinterpret_cast<f32x4*>(pb + 128 * m) = acc[m];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores have left
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(a.part_tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(a.parts - 1);
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      lab[0] = last;
+    }
+    __syncthreads();
+    if (!lab[0]) return;
+    if (k_live) {
+      const float* pb = a.part_buf + unit * a.parts * kd + (int64_t)ok_ * D + 4 * oj;
+#pragma unroll
+      for (int m = 0; m < NV; ++m) acc[m] = zero4;
+      for (int q = 0; q < a.parts; ++q) {
+#pragma unroll
+        for (int m = 0; m < NV; ++m) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(pb + q * kd + 128 * m);
+          acc[m][0] += v[0]; acc[m][1] += v[1]; acc[m][2] += v[2]; acc[m][3] += v[3];
+        }
+      }
+    }
   }
   // VLAD: intra-norm of each cluster block (its 32 owners = half a wave), then the global norm
   float ss = 0.f;
@@ -532,7 +580,13 @@ int launch_fused(const FusedArgs& a, int64_t units, hipStream_t stream) {
   }
   const double bytes = 4.0 * ((double)a.total * D + 2.0 * (double)units * a.K * D);
   ProfScope prof(KMEANS ? "kmeans_fused" : "vlad_fused", stream, 2.0 * a.total * D * 32, bytes);
-  hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(NTH), lds, stream, a);
+  unsigned grid = (unsigned)units;
+  if (!KMEANS && a.parts > 1) {
+    ANYLOC_CHECK_ARG(a.part_buf && a.part_tickets, "vlad_fused: parts without a partials buffer");
+    ANYLOC_HIP(hipMemsetAsync(a.part_tickets, 0, sizeof(unsigned) * units, stream));
+    grid = (unsigned)(units * a.parts);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, stream, a);
   return launch_status("vlad_fused_kernel");
 }
 

@@ -81,6 +81,21 @@ def test_vlad_hard_vs_oracle_flags_and_ragged(K, D, N):
         assert l2rel(out[i], vlad_ref.vlad_hard(parts[i], centers)[0]) < VLAD_RTOL
 
 
+@pytest.mark.parametrize("env", [{"ANYLOC_VLAD_PARTS": "1"}, {"ANYLOC_VLAD_PARTS": "3"}, {"ANYLOC_VLAD_PARTS": "8"},
+                                 {"ANYLOC_VLAD_PARTS": "40"}, {}, {"ANYLOC_VLAD_TWO_PASS": "1"}])
+def test_vlad_fused_parts(env):
+    """The fused VLAD kernel with 1 / 3 / 8 / 40 (more parts than tiles) workgroups per image, its own choice, and the
+    two-pass path: each against the oracle, bitwise reproducible run to run (tests/_vlad_parts_job.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_vlad_parts_job.py")], env=e, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok worst=" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("K,D,N", [(32, 1536, 529), (16, 384, 300), (40, 512, 257)])
 def test_vlad_hard_euclidean_assignment(K, D, N):
     """VLAD(dist_mode='euclidean'): labels = kmeans.predict(tokens) with fpk's euclidean similarity on the tokens as

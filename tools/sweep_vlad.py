@@ -1,5 +1,5 @@
 """VLAD (K=32, 529 x 1536 tokens per image) and one k-means step: fused single-launch kernel vs the two-pass path.
-usage: python tools/sweep_vlad.py [kmeans_rows]      env ANYLOC_VLAD_FUSED=1 / ANYLOC_VLAD_TWO_PASS=1 select the path"""
+usage: python tools/sweep_vlad.py [kmeans_rows]      env ANYLOC_VLAD_TWO_PASS=1 / ANYLOC_VLAD_PARTS=n select the path"""
 import json
 import os
 import sys
@@ -24,8 +24,8 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n
 
 
-mode = "fused" if os.environ.get("ANYLOC_VLAD_FUSED") == "1" else ("two_pass" if os.environ.get("ANYLOC_VLAD_TWO_PASS") == "1" else "auto")
-for n_img in (16, 61, 122, 256, 1024):
+mode = "two_pass" if os.environ.get("ANYLOC_VLAD_TWO_PASS") == "1" else "fused parts=" + os.environ.get("ANYLOC_VLAD_PARTS", "auto")
+for n_img in (1, 4, 16, 61, 122, 256, 1024):
     x = synth.clustered_tokens(n_img, N, D, n_modes=K, seed=3, device=dev)
     ms = timeit(lambda: ops.vlad(x, centers))
     gb = n_img * (N * D + 2 * K * D) * 4 / 1e9
