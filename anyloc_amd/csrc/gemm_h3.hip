@@ -719,6 +719,18 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
   } while (0)
   const bool small = ((p.M + 127) / 128) * ((p.N + 255) / 256) < 512;
   if (small && cfg == 0) {
+    // one or two images (the reference's scripts call the extractor per image): with 128x128 tiles proj / fc2 of ViT-g
+    // are 60 workgroups on 256 CUs -- below ANYLOC_H3_TINY_MAX (default 256) such tiles the GEMM runs 64x64 tiles on
+    // two-wave workgroups instead
+    static int64_t tiny_max = -1;
+    if (tiny_max < 0) {
+      const char* e = getenv("ANYLOC_H3_TINY_MAX");
+      tiny_max = e ? atoll(e) : 256;
+    }
+    if (((p.M + 127) / 128) * ((p.N + 127) / 128) < tiny_max) {
+      ANYLOC_LAUNCH_H3(1, 2, 2, 1, 3, 2);                   // 64x64, 2 waves
+      return launch_status("gemm_h3_kernel");
+    }
     ANYLOC_LAUNCH_H3(2, 2, 2, 2, 3, 2);                     // few tiles: 128x128
     return launch_status("gemm_h3_kernel");
   }

@@ -347,8 +347,8 @@ def main():
         "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"x6": "f32 (GEMM operands as exact 3-way bf16 splits, 6 bf16 MFMA products, fp32 accumulate)",
-                  "h3": "f32 (GEMM operands as row-scaled 2-term fp16 splits, 3 fp16 MFMA products, fp32 accumulate; "
-                        "attention on 3-way bf16 splits)",
+                  "h3": "f32 (GEMM and attention operands as power-of-two-scaled 2-term fp16 splits = 22 bits, "
+                        "3 fp16 MFMA products, fp32 accumulate; softmax, LayerNorm, residuals in fp32)",
                   "f32": "f32"}[args.gemm], "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: DINOv2 ViT-G/14 layer31 'value' K=32 VLAD, "
                                "322x322, top-20 vs 10k-row database per GPU", "batch_per_gpu": B, "gemm": args.gemm,
