@@ -28,7 +28,8 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "anyloc_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")]
+    headers.append(os.path.join(HERE, "..", "include", "anyloc_hip.h"))
 
     def compile_one(src):
         s = os.path.join(CSRC, src)

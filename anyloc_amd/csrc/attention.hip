@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "tile_order.hpp"
 
 namespace anyloc {
 
@@ -457,9 +458,6 @@ __device__ __forceinline__ void ah_pack2(float a, float b, unsigned& hi, unsigne
 }
 __device__ __forceinline__ float ah_pow2_recip(float inv) { return __uint_as_float((254u << 23) - __float_as_uint(inv)); }
 
-__device__ __forceinline__ void ah_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
-}
 
 constexpr int AH_STAGE = 16384;       // K hi | K lo | V hi | V lo, 4 KiB each
 
@@ -529,8 +527,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
       const int piece = i * NW + wave;                     // 0..7: K planes, 8..15: V planes
       unsigned char* st = ah_smem + stage * AH_STAGE + piece * 1024;
       const unsigned voff = (unsigned)((piece & 7) * 1024 + lane * 16);
-      if (i * NW < 8) ah_dma16(k_rsrc, st, voff, soff);
-      else ah_dma16(v_rsrc, st, voff, soff);
+      if (i * NW < 8) dma16_to_lds(k_rsrc, st, voff, soff);
+      else dma16_to_lds(v_rsrc, st, voff, soff);
     }
   };
 
@@ -734,10 +732,10 @@ __global__ __launch_bounds__(256, 2) void attention_h3p_kernel(const unsigned ch
   auto issue = [&](int t, int stage) {
     const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
     unsigned char* st = ah_smem + stage * AH_STAGE + wave * 1024;
-    ah_dma16(k_rsrc, st, voff, soff);
-    ah_dma16(k_rsrc, st + 4096, voff + 4096, soff);
-    ah_dma16(v_rsrc, st + 8192, voff, soff);
-    ah_dma16(v_rsrc, st + 12288, voff + 4096, soff);
+    dma16_to_lds(k_rsrc, st, voff, soff);
+    dma16_to_lds(k_rsrc, st + 4096, voff + 4096, soff);
+    dma16_to_lds(v_rsrc, st + 8192, voff, soff);
+    dma16_to_lds(v_rsrc, st + 12288, voff + 4096, soff);
   };
   float fk_lane = 1.0f, fv_lane = 1.0f;
   if (lane < ng) {

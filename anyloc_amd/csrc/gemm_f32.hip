@@ -34,34 +34,20 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "tile_order.hpp"
 
 namespace anyloc {
 
 namespace {
 
-__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int nb = tiles_m * tiles_n;
-  const int q = nb >> 3, r = nb & 7;
-  const int xcd = bid & 7, loc = bid >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  constexpr int GM = 8;
-  const int group_size = GM * tiles_n;
-  const int g = logical / group_size;
-  const int first_m = g * GM;
-  const int gm = min(tiles_m - first_m, GM);
-  const int within = logical - g * group_size;
-  tm = first_m + within % gm;
-  tn = within / gm;
-}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
-// 16 bytes per lane straight from global memory into LDS (wave-uniform LDS base + lane * 16)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+  dma16_to_lds(rsrc, reinterpret_cast<unsigned char*>(lds_dst), voff, soff);
 }
 
 __device__ __forceinline__ float gelu_erf(float v) {
@@ -106,7 +92,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_kernel(GemmProblem 
     if (ROWSQ) p.rowsq += sl * p.M;
   }
   int tile_m, tile_n;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
+  xcd_grouped_tile(blockIdx.x, tiles_m, tiles_n, 8, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
 
   // ---- staging coordinates: LPR lanes cover one BK*4-byte row segment ----

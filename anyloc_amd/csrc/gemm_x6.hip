@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "tile_order.hpp"
 
 namespace anyloc {
 
@@ -28,24 +29,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void xtile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int nb = tiles_m * tiles_n;
-  const int q = nb >> 3, r = nb & 7;
-  const int xcd = bid & 7, loc = bid >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  constexpr int GM = 8;
-  const int group_size = GM * tiles_n;
-  const int g = logical / group_size;
-  const int first_m = g * GM;
-  const int gm = min(tiles_m - first_m, GM);
-  const int within = logical - g * group_size;
-  tm = first_m + within % gm;
-  tn = within / gm;
-}
 
-__device__ __forceinline__ void dma16b(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
-}
 
 
 // MI x NI 32x32 MFMA blocks per wave, WM x WN waves: block tile (32 MI WM) x (32 NI WN); STAGES-deep LDS ring
@@ -83,7 +67,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int tm, tn;
-  xtile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  xcd_grouped_tile(blockIdx.x, tiles_m, tiles_n, 8, tm, tn);
   const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
 
   const unsigned a_slab = (unsigned)(3 * p.RA * 32), w_slab = (unsigned)(3 * p.RW * 32);
@@ -105,12 +89,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_x6_kernel(X6Problem p,
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int c = 0; c < Cfg::A_DMA; ++c)
-        dma16b(a_rsrc, st + pl * Cfg::A_PLANE + c * (1024 * Cfg::NW), a_voff[pl] + c * (1024 * Cfg::NW), ao);
+        dma16_to_lds(a_rsrc, st + pl * Cfg::A_PLANE + c * (1024 * Cfg::NW), a_voff[pl] + c * (1024 * Cfg::NW), ao);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int c = 0; c < Cfg::W_DMA; ++c)
-        dma16b(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * (1024 * Cfg::NW), w_voff[pl] + c * (1024 * Cfg::NW), wo);
+        dma16_to_lds(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * (1024 * Cfg::NW), w_voff[pl] + c * (1024 * Cfg::NW), wo);
   };
 
   // fragment address: lane (i = lane & 31, h = lane >> 5) reads the 16 bytes holding k = 8h .. 8h+7 of row i
