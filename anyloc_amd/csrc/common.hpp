@@ -223,6 +223,7 @@ struct FusedArgs {
   unsigned* cnt_part;      // k-means: [units, K] label counts; VLAD: null
   int64_t* lab64;          // optional [total] labels
   int norm_descs, intra;
+  int metric;              // 0 cosine (||chat_k|| = 1), 1 euclidean (chat = 2 c, cbias = -||c||^2): scales fused3's error bound
   int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
   float* part_buf;         // [units, parts, K, D] partial sums
   unsigned* part_tickets;  // [units] arrival counters (zeroed by the launcher)

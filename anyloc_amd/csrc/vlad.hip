@@ -472,7 +472,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     FusedArgs fa{};
     fa.x = tokens; fa.offsets = offsets; fa.total = total_tokens;
     fa.D = (int)D; fa.K = (int)K;
-    fa.chat = w.chat; fa.cbias = w.cb; fa.centers = centers;
+    fa.chat = w.chat; fa.cbias = w.cb; fa.centers = centers; fa.metric = metric;
     fa.out = out; fa.lab64 = labels;
     fa.norm_descs = (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0;
     fa.intra = (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0;
@@ -691,7 +691,7 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
     FusedArgs fa{};
     fa.x = x; fa.chunk_rows = rows; fa.total = n;
     fa.D = (int)D; fa.K = (int)K;
-    fa.chat = w.chat; fa.cbias = w.cb;
+    fa.chat = w.chat; fa.cbias = w.cb; fa.metric = mode;
     fa.out = part; fa.cnt_part = cnt_part; fa.lab64 = labels;
     ANYLOC_TRY(vlad_fused(fa, chunks, true, stream));
     {

@@ -20,6 +20,7 @@
 // (one cluster = half a wave), global norm by a block reduction, one coalesced store.
 // HBM bound: algorithmic bytes per image = (N*D + 2*K*D) * 4; LDS: 16*(D+4)*4 + 16 KiB + small.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -549,6 +550,488 @@ __global__ __launch_bounds__(512) void kmeans_fused2_kernel(FusedArgs a) {
   }
 }
 
+
+// ---- third structure: fp16 screening scores from register-resident centres + exact resolution of close calls ----
+// What bounds the two kernels above is the centre stream: 196 KB of normalised centres from L2 per 16-token tile and CU
+// (scoring 12 000 of 22 000 cycles per tile).  Here every wave keeps its D/8 slice of all 32 centres in REGISTERS as one
+// fp16 plane (48 VGPRs at D = 1536) and scores the tile on v_mfma_f32_16x16x32_f16 with the tokens split into two fp16
+// terms on the fly (x = hi + lo to ~2^-19): a screening score with a PROVEN error bound
+//     |s~_k - s_k| <= e = max_k||chat_k|| (||x|| 5.4e-4 + 2e-6)
+// (2^-11 from rounding the centre, ~2^-19 from the token, fp32 accumulation, fp16 subnormal quanta).  Every centre with
+// s~_k >= max s~ - 2e is a candidate -- the true arg-max is always among them.  One candidate (the usual case: top-2
+// cosine gaps of real tokens are ~10^-2, 2e is ~10^-3): done.  Several: their scores are recomputed exactly in fp32 by one
+// wave per token (x from the LDS tile, the candidate's fp32 centre from L2) and the first maximum wins, as in the exact
+// kernels.  Rows with a non-finite score or a norm beyond the fp16 range take the exact path with all centres.
+// Labels therefore equal the fp32 arg-max except at fp32-rounding ties, like the kernels above.
+// 512 threads; thread (cluster tid/16, columns 4 (tid%16) + 64 m) owns 2 NV float4 accumulators (both modes).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+__device__ __forceinline__ h16x8 pack_h16x8(const f32x4 a, const f32x4 b) {
+  u32x4s r;
+  r[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a[0], a[1]));
+  r[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a[2], a[3]));
+  r[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b[0], b[1]));
+  r[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b[2], b[3]));
+  return __builtin_bit_cast(h16x8, r);
+}
+
+// compile-time loop: the accumulator array below must only ever see constant indices (or it is demoted to scratch)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// SW = waves per workgroup: 8 (two per SIMD, 256 registers each) or 4 (one per SIMD: the wave may use the whole 512-entry
+// register file of its SIMD lane, 256 VGPRs + 256 AGPRs).  Per wave at D = 1536: 96 / 192 accumulators + 48 / 96 registers
+// of fp16 centres + 48 / 96 registers of the next tile in flight.  Nothing may spill: a scratch reload waits -- the
+// vector-memory counter retires in order -- for the HBM loads of the next tile.
+constexpr int f3_cw(int slice) {
+  int cw = (slice + 63) / 64;
+  while (slice % cw) ++cw;
+  return cw;
+}
+constexpr int f3_gcd(int x, int y) { return y == 0 ? x : f3_gcd(y, x % y); }
+
+template <int NV, int SW, bool KMEANS>
+__global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
+  constexpr int D = NV * 128;
+  constexpr int LD = D + 4;
+  constexpr int NT3 = 64 * SW;
+  constexpr int NF = 16 * (D / 4) / NT3;      // staged float4 per thread per tile
+  constexpr int SLICE = D / SW;               // columns of a wave: its scoring slice AND the columns it accumulates
+  constexpr int NKB = SLICE / 32;             // 32-wide k-blocks per wave slice
+  static_assert(SLICE % 32 == 0 && 16 * (D / 4) % NT3 == 0, "a wave's slice must be whole 32-wide k-blocks");
+  constexpr int NX = (D + 255) / 256;         // float4 per lane of one row (exact resolution)
+  // accumulators: wave w owns columns [w SLICE, (w+1) SLICE) of ALL 32 clusters, CW consecutive columns per lane ->
+  // 32 CW registers per lane, held as CW vectors of 32 (one element per cluster).  Every wave visits every token of the
+  // tile; the token's label is wave-uniform and indexes the vectors DYNAMICALLY IN REGISTERS (s_set_gpr_idx / v_movrel:
+  // a 32-way branch instead made the allocator keep two copies of every accumulator).  The gather is balanced whatever
+  // the label mix -- with one owner wave per cluster the tile waited for the wave whose clusters got the most tokens
+  // (measured: gather 4 400 cycles + 3 700 of imbalance per tile).
+  constexpr int CW = f3_cw(SLICE);
+  constexpr int GL = SLICE / CW;              // lanes of a wave that own columns (64 or 48)
+  static_assert(GL * CW == SLICE && GL <= 64, "column ownership must tile the slice");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;                          // [TT][LD]
+  float* part = tile + TT * LD;               // [SW][TT][32]
+  float* rsqp = part + SW * TT * 32;          // [SW][TT]
+  float* nrm = rsqp + SW * TT;                // [TT]
+  int* lab = reinterpret_cast<int*>(nrm + TT);            // [TT]
+  unsigned* amb = reinterpret_cast<unsigned*>(lab + TT);  // [TT] candidate masks of the rows to resolve exactly (0: none)
+  float* red = reinterpret_cast<float*>(amb + TT);        // [SW][32] epilogue reductions
+  int* npairs = reinterpret_cast<int*>(red + SW * 32);    // [1] (row, centre) pairs queued for exact scoring in this tile
+  int* pairs = npairs + 4;                                // [16 * 32] queue of (row << 5 | centre)
+  float* exs = part;                          // after barrier B the score partials are dead: exact-score table [16][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t unit = blockIdx.x;
+  int64_t n0, n1;
+  int part_id = 0;
+  if (KMEANS) {
+    n0 = unit * a.chunk_rows;
+    n1 = min(n0 + a.chunk_rows, a.total);
+  } else {
+    if (a.parts > 1) {
+      part_id = (int)(unit % a.parts);
+      unit /= a.parts;
+    }
+    n0 = a.offsets[unit];
+    n1 = a.offsets[unit + 1];
+    if (a.parts > 1) {
+      const int64_t per = (((n1 - n0 + TT - 1) / TT) + a.parts - 1) / a.parts * TT;
+      n0 = min(n0 + part_id * per, n1);
+      n1 = min(n0 + per, n1);
+    }
+  }
+  const int64_t nrows = n1 - n0;
+  const int ntiles = (int)((nrows + TT - 1) / TT);
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(a.x + n0 * D)), 0,
+      __builtin_amdgcn_readfirstlane((int)min<int64_t>(nrows * D * 4, 0x7fffffff)), 0x00020000);
+  f32x4 stg[NF];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // slot f = tid + NT3 i of the [16][D/4] tile is (row, float4 column) = (f / (D/4), f % (D/4)); NT3 i / (D/4) = 2 SW i / NV
+  // repeats with period P = NV / gcd(2 SW, NV), so only P (row, column) pairs are computed and the others are RSTEP rows
+  // further down: constant offsets instead of NF precomputed addresses per thread
+  constexpr int P = NV / f3_gcd(2 * SW, NV);
+  constexpr int RSTEP = 2 * SW * P / NV;
+  static_assert(NF % P == 0, "staging pattern");
+  auto fetch = [&](int t) {
+    const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      const int f = tid + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
+      const unsigned vo = (unsigned)((row * D + 4 * c4) * 4);
+#pragma unroll
+      for (int j = 0; j < NF / P; ++j) stg[j * P + r] = bload16(x_rsrc, vo, so + (unsigned)(j * RSTEP * D * 4));
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      const int f = tid + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
+      float* dst = tile + row * LD + 4 * c4;
+#pragma unroll
+      for (int j = 0; j < NF / P; ++j) *reinterpret_cast<f32x4*>(dst + j * RSTEP * LD) = stg[j * P + r];
+    }
+  };
+
+  f32x32 acc[CW];
+  static_for<CW>([&](auto j) {
+    static_for<32>([&](auto k) { acc[j][(int)k] = 0.f; });
+  });
+  unsigned my_count = 0;                       // wave 0, lane k: tokens labelled k
+  const int gcol = wave * SLICE + CW * (lane < GL ? lane : 0);
+  const __amdgpu_buffer_rsrc_t cen_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(KMEANS ? a.chat : a.centers)), 0, (KMEANS ? 32 : a.K) * D * 4, 0x00020000);
+
+  // scoring coordinates: 16x16x32 fragments -- token / centre = lane & 15, 8 consecutive k at 8 (lane >> 4) of the k-block
+  const int fr = lane & 15, fq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t c_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float*>(a.chat)), 0, 32 * D * 4, 0x00020000);
+  const float* a_frag = tile + fr * LD + wave * SLICE + 8 * fq;
+  h16x8 bh[2][NKB];                            // this wave's slice of the 32 centres, fp16, for the whole kernel
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const unsigned off = (unsigned)(((16 * h + fr) * D + wave * SLICE + 32 * kb + 8 * fq) * 4);
+      bh[h][kb] = pack_h16x8(bload16(c_rsrc, off, 0), bload16(c_rsrc, off, 16));
+    }
+  const float my_bias = a.cbias[tid & 31];
+  // ||chat_k||: 1 (cosine) or 2 ||c_k|| = 2 sqrt(-bias_k) (euclidean); its maximum scales the error bound
+  float cnmax = a.metric ? 2.0f * sqrtf(fmaxf(-my_bias, 0.0f)) : 1.0f;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) cnmax = fmaxf(cnmax, __shfl_xor(cnmax, o, 64));
+
+  if (ntiles > 0) {
+    fetch(0);
+    stash();
+  }
+  __syncthreads();
+
+  const bool stamp = a.stamps && blockIdx.x == 0 && tid == 0;
+  const bool wstamp = a.stamps && blockIdx.x == 0 && lane == 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int valid = (int)min<int64_t>(TT, nrows - (int64_t)t * TT);
+    if (stamp) a.stamps[t * 24 + 0] = __builtin_readcyclecounter();
+    if (tid == 0) *npairs = 0;                 // (read after barrier B; barrier A orders this store before the atomics)
+    // HBM loads of the next tile first: scoring and assign touch no vector memory, so by the time the exact resolution
+    // or the VLAD gather wait for their own (L2) loads -- the counter retires in order -- these have landed
+    if (t + 1 < ntiles) fetch(t + 1);
+    {
+      // ---- screening scores of this wave's slice (and the row sums of squares from the same fragments) ----
+      f32x4 s0 = zero4, s1 = zero4;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb + 4);
+        rs += (x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3]);
+        rs += (x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]);
+        const h16x8 hi = pack_h16x8(x0, x1);
+        f32x4 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          r0[e] = x0[e] - (float)hi[e];
+          r1[e] = x1[e] - (float)hi[4 + e];
+        }
+        const h16x8 lo = pack_h16x8(r0, r1);
+        // two accumulator chains per wave (x 2 waves per SIMD); more would cost registers this kernel does not have
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh[0][kb], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh[1][kb], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh[0][kb], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh[1][kb], s1, 0, 0, 0);
+        if (kb % 2 == 1) __builtin_amdgcn_sched_barrier(0);          // two k-blocks' fragments in flight at most
+      }
+      // C/D layout: centre = lane & 15, token = 4 (lane >> 4) + reg
+      float* p = part + wave * (TT * 32) + (4 * fq) * 32 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r * 32] = s0[r];
+        p[r * 32 + 16] = s1[r];
+      }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      if (fq == 0) rsqp[wave * TT + fr] = rs;
+      if (wstamp) a.stamps[t * 24 + 4 + wave] = __builtin_readcyclecounter();
+    }
+    lds_barrier();
+    if (stamp) a.stamps[t * 24 + 1] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int it = 0; it < 8 / SW; ++it) {
+      // ---- assign: fixed-order sum of the SW partials; arg-max; candidates within the error bound ----
+      // (addresses are rebuilt from an opaque copy of the thread id every tile: hoisted out of the tile loop they are
+      // registers this kernel does not have, and a spilled one is reloaded behind the HBM loads in flight)
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int row = (tl >> 5) + 2 * SW * it, k = tl & 31;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < SW; ++w2) {
+        s += part[w2 * (TT * 32) + row * 32 + k];
+        q += rsqp[w2 * TT + row];
+      }
+      s += my_bias;
+      const float xn = sqrtf(q);
+      const bool kin = k < a.K;
+      float best = kin ? s : -INFINITY;
+      int bi = (kin && best == best) ? k : 0x7fffffff;
+      if (!(best == best)) best = -INFINITY;
+      // first arg-max over the 32 lanes of the row: four DPP rotations inside each 16-lane row (every lane ends up with
+      // its row's winner), then one cross-row exchange
+      auto take = [&](float ov, int oi) {
+        const bool tk = (ov > best) | ((ov == best) & (oi < bi));
+        best = tk ? ov : best;
+        bi = tk ? oi : bi;
+      };
+      take(dpp_f32<0x128>(best), dpp_i32<0x128>(bi));     // row_ror:8
+      take(dpp_f32<0x124>(best), dpp_i32<0x124>(bi));     // row_ror:4
+      take(dpp_f32<0x122>(best), dpp_i32<0x122>(bi));     // row_ror:2
+      take(dpp_f32<0x121>(best), dpp_i32<0x121>(bi));     // row_ror:1
+      take(__shfl_xor(best, 16, 64), __shfl_xor(bi, 16, 64));
+      const float tau = 2.0f * cnmax * (xn * 5.4e-4f + 2e-6f);
+      const bool odd = kin && !(fabsf(s) < INFINITY);               // NaN / inf score
+      const unsigned long long oddm = __ballot(odd || !(xn < 6.0e4f));
+      const unsigned sh = 32u * (unsigned)(lane >> 5);
+      const bool wild = ((unsigned)(oddm >> sh)) != 0u;              // this row cannot be screened in fp16
+      const unsigned long long cm = __ballot(kin && (wild || s >= best - tau));
+      const unsigned mask = (unsigned)(cm >> sh);
+      const bool live = row < valid;
+      const bool close = live && __builtin_popcount(mask) > 1;
+      if (close && ((mask >> k) & 1u)) pairs[atomicAdd(npairs, 1)] = (row << 5) | k;   // LDS atomic; order is irrelevant
+      if (k == 0) {
+        if (bi == 0x7fffffff) bi = 0;
+        amb[row] = close ? mask : 0u;
+        lab[row] = live ? bi : -1;
+        if (!KMEANS) nrm[row] = a.norm_descs ? fmaxf(xn, 1e-12f) : 1.0f;
+        if (live && !close && a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
+      }
+    }
+    lds_barrier();
+    if (stamp) a.stamps[t * 24 + 2] = __builtin_readcyclecounter();
+    // ---- exact resolution: the queued (row, centre) pairs are dealt round-robin to the waves (a close row has 2-3
+    //      candidates; dealing whole rows left most waves idle behind the one that had a row), each scored exactly in
+    //      fp32 by a whole wave; then the rows' arg-max over their candidates' exact scores ----
+    const int np = __builtin_amdgcn_readfirstlane(*npairs);
+    if (np > 0) {
+      int ll = lane;
+      asm volatile("" : "+v"(ll));
+      for (int pi = wave; pi < np; pi += SW) {
+        const int pr = __builtin_amdgcn_readfirstlane(pairs[pi]);
+        const int rr = pr >> 5, k = pr & 31;
+        const float* xrow = tile + rr * LD + 4 * ll;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          if (4 * ll + 256 * i < D) {
+            const f32x4 c = bload16(c_rsrc, (unsigned)(16 * ll), (unsigned)((k * D + 256 * i) * 4));
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xrow + 256 * i);
+            d = fmaf(x[0], c[0], d); d = fmaf(x[1], c[1], d);
+            d = fmaf(x[2], c[2], d); d = fmaf(x[3], c[3], d);
+          }
+        }
+        d = wave_sum(d) + a.cbias[k];
+        if (lane == 0) exs[pr] = d;
+      }
+      lds_barrier();
+#pragma unroll
+      for (int it = 0; it < 8 / SW; ++it) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const int row = (tl >> 5) + 2 * SW * it, k = tl & 31;
+        const unsigned m = amb[row];
+        const bool cand = (m >> k) & 1u;
+        const float d = cand ? exs[row * 32 + k] : 0.f;
+        float best = (cand && d == d) ? d : -INFINITY;
+        int bi = (cand && d == d) ? k : 0x7fffffff;
+        auto take = [&](float ov, int oi) {
+          const bool tk = (ov > best) | ((ov == best) & (oi < bi));
+          best = tk ? ov : best;
+          bi = tk ? oi : bi;
+        };
+        take(dpp_f32<0x128>(best), dpp_i32<0x128>(bi));
+        take(dpp_f32<0x124>(best), dpp_i32<0x124>(bi));
+        take(dpp_f32<0x122>(best), dpp_i32<0x122>(bi));
+        take(dpp_f32<0x121>(best), dpp_i32<0x121>(bi));
+        take(__shfl_xor(best, 16, 64), __shfl_xor(bi, 16, 64));
+        if (k == 0 && m != 0u) {
+          if (bi == 0x7fffffff) bi = 0;
+          lab[row] = bi;
+          if (a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
+        }
+      }
+    }
+    lds_barrier();
+    if (stamp) a.stamps[t * 24 + 21] = __builtin_readcyclecounter();
+    {
+      // ---- gather: every wave adds every token (in order) to its columns of the token's cluster ----
+      const float* tp = tile + gcol;
+      auto add_token = [&](int k, const float* v) {
+        if (k >= 0) static_for<CW>([&](auto j) { acc[j][(int)k] += v[j]; });
+      };
+      // four tokens per round: one LDS round trip for their labels and columns, then the register-indexed adds
+#pragma unroll 1
+      for (int n4 = 0; n4 < TT; n4 += 4) {
+        const i32x4_t lq = *reinterpret_cast<const i32x4_t*>(lab + n4);
+        float v[4][CW];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < CW; ++j) v[e][j] = tp[(n4 + e) * LD + j];
+        int kk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
+        if (KMEANS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            add_token(kk[e], v[e]);
+            if (wave == 0) my_count += (lane == kk[e]) ? 1u : 0u;
+          }
+        } else {
+          // x / ||x|| - c_k: the centre's CW columns come from L2
+          float c[4][CW];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned so = (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4);
+#pragma unroll
+            for (int j = 0; j < CW; ++j)
+              c[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cen_rsrc, (unsigned)((gcol + j) * 4), so, 0));
+          }
+          const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + n4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float inv = 1.0f / nq[e];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) v[e][j] = v[e][j] * inv - c[e][j];
+            add_token(kk[e], v[e]);
+          }
+        }
+      }
+    }
+    if (wstamp) a.stamps[t * 24 + 12 + wave] = __builtin_readcyclecounter();
+    lds_barrier();
+    if (stamp) a.stamps[t * 24 + 3] = __builtin_readcyclecounter();
+    if (t + 1 < ntiles) stash();
+    lds_barrier();
+    if (stamp) a.stamps[t * 24 + 20] = __builtin_readcyclecounter();
+  }
+
+  const bool g_live = lane < GL;
+  if (KMEANS) {
+    float* o = a.out + unit * a.K * (int64_t)D + gcol;
+    static_for<32>([&](auto k) {
+      if (k < a.K && g_live) static_for<CW>([&](auto j) { o[(int64_t)k * D + j] = acc[j][(int)k]; });
+    });
+    if (wave == 0 && lane < a.K) a.cnt_part[unit * a.K + lane] = my_count;
+    return;
+  }
+  if (a.parts > 1) {
+    // (the hand-off of vlad_fused_kernel: partial sums -> workspace, last ticket reduces in part order)
+    const int64_t kd = (int64_t)a.K * D;
+    {
+      float* pb = a.part_buf + (unit * a.parts + part_id) * kd + gcol;
+      static_for<32>([&](auto k) {
+        if (k < a.K && g_live) static_for<CW>([&](auto j) { pb[(int64_t)k * D + j] = acc[j][(int)k]; });
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(a.part_tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(a.parts - 1);
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      lab[0] = last;
+    }
+    __syncthreads();
+    if (!lab[0]) return;
+    static_for<CW>([&](auto j) {
+      static_for<32>([&](auto k) { acc[j][(int)k] = 0.f; });
+    });
+    const float* pb = a.part_buf + unit * a.parts * kd + gcol;
+    for (int q = 0; q < a.parts; ++q) {
+      static_for<32>([&](auto k) {
+        if (k < a.K && g_live) static_for<CW>([&](auto j) { acc[j][(int)k] += pb[q * kd + (int64_t)k * D + j]; });
+      });
+    }
+  }
+  // intra-norm of each cluster block (its columns are spread over the SW waves), then the global norm
+  if (a.intra) {
+    static_for<32>([&](auto k) {
+      float ss = 0.f;
+      static_for<CW>([&](auto j) { ss += acc[j][(int)k] * acc[j][(int)k]; });
+      ss = wave_sum(g_live ? ss : 0.f);
+      if (lane == 0) red[wave * 32 + k] = ss;
+    });
+    __syncthreads();
+    static_for<32>([&](auto k) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < SW; ++w2) tot += red[w2 * 32 + k];
+      const float kn = fmaxf(sqrtf(tot), 1e-12f);
+      static_for<CW>([&](auto j) { acc[j][(int)k] /= kn; });
+    });
+    __syncthreads();
+  }
+  float ss = 0.f;
+  static_for<32>([&](auto k) {
+    if (k < a.K) static_for<CW>([&](auto j) { ss += acc[j][(int)k] * acc[j][(int)k]; });
+  });
+  ss = wave_sum(g_live ? ss : 0.f);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < SW; ++w2) tot += red[w2];
+  const float gn = fmaxf(sqrtf(tot), 1e-12f);
+  float* o = a.out + unit * a.K * (int64_t)D + gcol;
+  static_for<32>([&](auto k) {
+    if (k < a.K && g_live) static_for<CW>([&](auto j) { o[(int64_t)k * D + j] = acc[j][(int)k] / gn; });
+  });
+}
+
+template <int NV, int SW, bool KMEANS>
+int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
+  constexpr int D = NV * 128;
+  const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32);
+  auto kern = fused3_kernel<NV, SW, KMEANS>;
+  static bool attr = false;
+  if (!attr) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  ProfScope prof(KMEANS ? "kmeans_fused" : "vlad_fused", stream, 2.0 * a.total * D * 32,
+                 4.0 * ((double)a.total * D + 2.0 * (double)units * a.K * D));
+  unsigned grid = (unsigned)units;
+  if (!KMEANS && a.parts > 1) {
+    ANYLOC_CHECK_ARG(a.part_buf && a.part_tickets, "vlad_fused: parts without a partials buffer");
+    ANYLOC_HIP(hipMemsetAsync(a.part_tickets, 0, sizeof(unsigned) * units, stream));
+    grid = (unsigned)(units * a.parts);
+  }
+  FusedArgs b = a;
+  if (const char* e = getenv("ANYLOC_KM_STAMPS")) b.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * SW), lds, stream, b);
+  return launch_status("fused3_kernel");
+}
+
 template <int NV, int NGRQ>
 int launch_kmeans2(const FusedArgs& a, int64_t units, hipStream_t stream) {
   constexpr int D = NV * 128;
@@ -599,15 +1082,28 @@ bool fused_supported(int64_t D, int64_t K) {
 int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream) {
   if (units <= 0) return ANYLOC_OK;
   ANYLOC_CHECK_ARG(units < (1ll << 31), "vlad_fused: too many units");
-  // ANYLOC_KMEANS_FUSED_V (A/B): 2 (default) = the 512-thread kernel with register-resident centres, 1 = the first structure
-  static int kv = -1;
+  // ANYLOC_KMEANS_FUSED_V / ANYLOC_VLAD_FUSED_V (A/B switches): 0 (default) = fused3_kernel -- 8 waves where D / 128 is
+  // even, 4 waves otherwise; VLAD with more than two workgroups per image stays on vlad_fused_kernel (its hand-off epilogue
+  // is cheaper); 1 = vlad_fused_kernel (both modes), 2 = kmeans_fused2_kernel, 3 = fused3 with 4 waves, 4 = fused3 with 8
+  static int kv = -1, vv = -1;
   if (kv < 0) {
     const char* e = getenv("ANYLOC_KMEANS_FUSED_V");
-    kv = e ? atoi(e) : 2;
+    kv = e ? atoi(e) : 0;
+    e = getenv("ANYLOC_VLAD_FUSED_V");
+    vv = e ? atoi(e) : 0;
   }
-#define ANYLOC_FUSED_CASE(NV)                                                      \
-  case NV * 128:                                                                   \
-    if (kmeans && kv == 2) return launch_kmeans2<NV, 4>(a, units, stream);         \
+  const int ver = kmeans ? kv : vv;
+  const bool f3 = ver == 0 ? (kmeans || a.parts <= 2) : ver >= 3;
+#define ANYLOC_FUSED_CASE(NV)                                                                         \
+  case NV * 128:                                                                                      \
+    if (f3) {                                                                                         \
+      if constexpr (NV % 2 == 0) {                                                                    \
+        if (ver != 3)                                                                                 \
+          return kmeans ? launch_fused3<NV, 8, true>(a, units, stream) : launch_fused3<NV, 8, false>(a, units, stream); \
+      }                                                                                               \
+      return kmeans ? launch_fused3<NV, 4, true>(a, units, stream) : launch_fused3<NV, 4, false>(a, units, stream);     \
+    }                                                                                                 \
+    if (kmeans && ver == 2) return launch_kmeans2<NV, 4>(a, units, stream);                           \
     return kmeans ? launch_fused<NV, true>(a, units, stream) : launch_fused<NV, false>(a, units, stream);
   switch (a.D) {
     ANYLOC_FUSED_CASE(3)

@@ -1,7 +1,9 @@
 """Run by tests/test_gpu_vlad_topk.py::test_vlad_fused_parts in a subprocess (the path switches are read once per
-process): hard VLAD through the fused kernel with the environment's ANYLOC_VLAD_PARTS / ANYLOC_VLAD_TWO_PASS against the
-CPU oracle, the same workspace reused across calls with different inputs (the reducing workgroup of one call has the
-previous call's partial sums in its L1: the agent-scope acquire has to drop them)."""
+process): hard VLAD through the fused kernel with the environment's ANYLOC_VLAD_PARTS / ANYLOC_VLAD_TWO_PASS /
+ANYLOC_VLAD_FUSED_V against the CPU oracle, the same workspace reused across calls with different inputs (the reducing
+workgroup of one call has the previous call's partial sums in its L1: the agent-scope acquire has to drop them); and one
+k-means step (ANYLOC_KMEANS_FUSED_V) on inputs chosen to hit the close-call logic of the fp16-screening kernel:
+isotropic rows (top-2 gaps of ~1e-3), duplicated centres (exact ties), zero / tiny / huge rows."""
 import sys
 
 import torch
@@ -44,7 +46,45 @@ def main():
                 first = (imgs, out.clone())
         again = ops.vlad([t.to(DEV) for t in first[0]], centers.to(DEV))
         assert torch.equal(again, first[1]), "not reproducible run to run"
+    kmeans_close_calls()
     print(f"ok worst={worst:.2e}")
+
+
+def kmeans_close_calls():
+    for D, K, n in ((1536, 32, 4111), (768, 20, 1500), (384, 16, 2050), (1024, 32, 999)):
+        g = torch.Generator().manual_seed(D + K)
+        x = torch.randn(n, D, generator=g) * (0.2 + 3.0 * torch.rand(n, 1, generator=g))
+        c = torch.randn(K, D, generator=g)
+        c[K - 1] = c[1]                                   # an exact tie: the lower index has to win
+        x[5] = 0.0                                        # every score equal
+        x[6] *= 1e-7                                      # below the fp16 range of the screening pass
+        x[7] *= 3e4                                       # beyond it
+        x[8] = c[3] + 1e-4 * torch.randn(D, generator=g)  # a clear winner
+        for mode in ("cosine", "euclidean"):
+            sums, counts, lab = ops.kmeans_step(x.to(DEV), c.to(DEV), mode, True)
+            lab = lab.cpu()
+            xd, cd = x.double(), c.double()
+            if mode == "cosine":
+                sc = torch.nn.functional.normalize(xd) @ torch.nn.functional.normalize(cd).T
+                scale = torch.ones(n, dtype=torch.float64)
+            else:
+                sc = 2 * xd @ cd.T - (cd * cd).sum(1)[None]
+                scale = xd.norm(dim=1) * cd.norm(dim=1).max() + (cd * cd).sum(1).max()
+            sc[:, K - 1] = sc[:, 1]                      # (the GEMM may round the two identical columns differently)
+            ref = sc.max(dim=1)[1]
+            bad = (lab != ref).nonzero().flatten()
+            for i in bad.tolist():
+                gap = float(sc[i, ref[i]] - sc[i, lab[i]])
+                assert gap <= 2e-6 * float(scale[i]) + 1e-300, (D, K, mode, i, gap, float(scale[i]))
+                assert not (gap == 0.0 and int(lab[i]) > int(ref[i])), (D, K, mode, i, "tie must go to the lower index")
+            assert int(lab[5]) == 0 or mode == "euclidean"
+            assert int(lab[8]) == 3
+            assert len(bad) <= 8, (D, K, mode, len(bad))
+            onehot = (lab[None] == torch.arange(K)[:, None]).double()
+            assert torch.equal(counts.cpu(), onehot.sum(-1).float())
+            ref_sums = onehot @ xd
+            err = float((sums.cpu().double() - ref_sums).norm() / ref_sums.norm())
+            assert err < 1e-6, (D, K, mode, err)
 
 
 if __name__ == "__main__":

@@ -82,10 +82,16 @@ def test_vlad_hard_vs_oracle_flags_and_ragged(K, D, N):
 
 
 @pytest.mark.parametrize("env", [{"ANYLOC_VLAD_PARTS": "1"}, {"ANYLOC_VLAD_PARTS": "3"}, {"ANYLOC_VLAD_PARTS": "8"},
-                                 {"ANYLOC_VLAD_PARTS": "40"}, {}, {"ANYLOC_VLAD_TWO_PASS": "1"}])
+                                 {"ANYLOC_VLAD_PARTS": "40"}, {}, {"ANYLOC_VLAD_TWO_PASS": "1"},
+                                 {"ANYLOC_VLAD_FUSED_V": "1", "ANYLOC_KMEANS_FUSED_V": "1"},
+                                 {"ANYLOC_VLAD_FUSED_V": "3", "ANYLOC_KMEANS_FUSED_V": "3", "ANYLOC_VLAD_PARTS": "2"},
+                                 {"ANYLOC_VLAD_FUSED_V": "4", "ANYLOC_KMEANS_FUSED_V": "4", "ANYLOC_VLAD_PARTS": "5"},
+                                 {"ANYLOC_KMEANS_FUSED_V": "2"}])
 def test_vlad_fused_parts(env):
-    """The fused VLAD kernel with 1 / 3 / 8 / 40 (more parts than tiles) workgroups per image, its own choice, and the
-    two-pass path: each against the oracle, bitwise reproducible run to run (tests/_vlad_parts_job.py)."""
+    """The fused VLAD kernels with 1 / 3 / 8 / 40 (more parts than tiles) workgroups per image, their own choice, every
+    kernel version (ANYLOC_*_FUSED_V: the exact-score kernels 1 / 2, the fp16-screening kernel with 4 and 8 waves) and
+    the two-pass path: each against the oracle, bitwise reproducible run to run; plus one k-means step on close-call
+    inputs (tests/_vlad_parts_job.py)."""
     import os
     import subprocess
     import sys
