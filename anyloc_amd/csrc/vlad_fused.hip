@@ -682,6 +682,18 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       for (int j = 0; j < NF / P; ++j) stg[j * P + r] = bload16(x_rsrc, vo, so + (unsigned)(j * RSTEP * D * 4));
     }
   };
+  // two staged float4 per k-block of the scoring loop (NF = 2 NKB): the loads of the next tile are spread through the
+  // scoring phase, so the wave's VALU / MFMA work runs while the texture path accepts them (98 KB per tile and CU at
+  // 64 B/clk is ~1 500 cycles; issued in one burst, every wave sat in that queue before it scored)
+  static_assert(NF == 2 * NKB, "two staged float4 per k-block");
+  auto fetch_pair = [&](int t, auto kbc) {
+    const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
+    static_for<2>([&](auto h) {
+      constexpr int i = 2 * decltype(kbc)::value + decltype(h)::value, r = i % P, j = i / P;
+      const int f = tid + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
+      stg[j * P + r] = bload16(x_rsrc, (unsigned)((row * D + 4 * c4) * 4), so + (unsigned)(j * RSTEP * D * 4));
+    });
+  };
   auto stash = [&]() {
 #pragma unroll
     for (int r = 0; r < P; ++r) {
@@ -732,15 +744,16 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     const int valid = (int)min<int64_t>(TT, nrows - (int64_t)t * TT);
     if (stamp) a.stamps[t * 24 + 0] = __builtin_readcyclecounter();
     if (tid == 0) *npairs = 0;                 // (read after barrier B; barrier A orders this store before the atomics)
-    // HBM loads of the next tile first: scoring and assign touch no vector memory, so by the time the exact resolution
-    // or the VLAD gather wait for their own (L2) loads -- the counter retires in order -- these have landed
-    if (t + 1 < ntiles) fetch(t + 1);
+    // The HBM loads of the next tile go out during scoring: scoring and assign wait for no vector memory, so by the time
+    // the exact resolution or the VLAD gather wait for their own (L2) loads -- the counter retires in order -- these
+    // have landed
     {
       // ---- screening scores of this wave's slice (and the row sums of squares from the same fragments) ----
       f32x4 s0 = zero4, s1 = zero4;
       float rs = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
+      static_for<NKB>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        fetch_pair(t + 1, kbc);          // (past the last tile: out of the descriptor's range, returns zeros, never stashed)
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb + 4);
         rs += (x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3]);
@@ -759,7 +772,7 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh[0][kb], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh[1][kb], s1, 0, 0, 0);
         if (kb % 2 == 1) __builtin_amdgcn_sched_barrier(0);          // two k-blocks' fragments in flight at most
-      }
+      });
       // C/D layout: centre = lane & 15, token = 4 (lane >> 4) + reg
       float* p = part + wave * (TT * 32) + (4 * fq) * 32 + fr;
 #pragma unroll
@@ -883,8 +896,31 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     {
       // ---- gather: every wave adds every token (in order) to its columns of the token's cluster ----
       const float* tp = tile + gcol;
+      // acc[j][k] += v[j] with the cluster index in an SGPR: ONE region of GPR-index mode (source 0 and destination
+      // indexed) around CW adds.  The compiler's own lowering of the dynamic subscript switches the mode on and off
+      // around a v_mov for every read and every write (7 instructions per element); the vectors are pinned to the top
+      // of the register file so the instructions can name their base registers.
       auto add_token = [&](int k, const float* v) {
-        if (k >= 0) static_for<CW>([&](auto j) { acc[j][(int)k] += v[j]; });
+        if (k < 0) return;
+        if constexpr (CW == 1) {
+          asm volatile("s_set_gpr_idx_on %2, 0x9\n\tv_add_f32 v224, v224, %1\n\ts_set_gpr_idx_off"
+                       : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
+        } else if constexpr (CW == 2) {
+          asm volatile("s_set_gpr_idx_on %4, 0x9\n\tv_add_f32 v192, v192, %2\n\tv_add_f32 v224, v224, %3\n\ts_set_gpr_idx_off"
+                       : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
+        } else if constexpr (CW == 3) {
+          asm volatile("s_set_gpr_idx_on %6, 0x9\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
+                       "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
+                       : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
+        } else if constexpr (CW == 4) {
+          asm volatile("s_set_gpr_idx_on %8, 0x9\n\tv_add_f32 v128, v128, %4\n\tv_add_f32 v160, v160, %5\n\t"
+                       "v_add_f32 v192, v192, %6\n\tv_add_f32 v224, v224, %7\n\ts_set_gpr_idx_off"
+                       : "+{v[128:159]}"(acc[0]), "+{v[160:191]}"(acc[1]), "+{v[192:223]}"(acc[2]), "+{v[224:255]}"(acc[3])
+                       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k));
+        } else {
+          static_for<CW>([&](auto j) { acc[j][(int)k] += v[j]; });
+        }
       };
       // four tokens per round: one LDS round trip for their labels and columns, then the register-indexed adds
 #pragma unroll 1
