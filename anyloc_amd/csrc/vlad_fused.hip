@@ -59,6 +59,11 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// min over int64 in SALU-friendly integer ops.  (`min<int64_t>(a, b)` resolved to a floating-point overload here: the
+// result came out of v_cvt_i32_f64 in a VGPR, the readfirstlane around it was folded away as "already uniform", and every
+// buffer load through the descriptor it went into got a waterfall loop.)
+__device__ __forceinline__ int64_t imin64(int64_t x, int64_t y) { return x < y ? x : y; }
+
 // NV = D / 128: float4 columns per owner thread (and 16-wide k-groups per scoring wave)
 template <int NV, bool KMEANS>
 __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
 
   // ---- staging: thread owns float4 slots f = tid + 1024*i of the [16][D/4] tile ----
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x + n0 * D), 0, (int)min<int64_t>(nrows * D * 4, 0x7fffffff), 0x00020000);
+      const_cast<float*>(a.x + n0 * D), 0, (int)imin64(nrows * D * 4, 0x7fffffff), 0x00020000);
   f32x4 stg[NF];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // thread owns float4 slots f = tid + 1024*i of the [16][D/4] tile; slot -> (row, column) is
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
 
   for (int t = 0; t < ntiles; ++t) {
     if (!scorer && t + 1 < ntiles) fetch(t + 1);
-    const int valid = (int)min<int64_t>(TT, nrows - (int64_t)t * TT);
+    const int valid = (int)imin64(TT, nrows - (int64_t)t * TT);
 
     if (wave < SW) {
       // ---- scores: S[16 tokens][32 centres] over this wave's D/SW slice; the same A fragments
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(512) void kmeans_fused2_kernel(FusedArgs a) {
   // the descriptor must be PROVABLY wave-uniform, or every buffer load is wrapped in a waterfall loop (15 instructions each)
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<float*>(a.x + n0 * D)), 0,
-      __builtin_amdgcn_readfirstlane((int)min<int64_t>(nrows * D * 4, 0x7fffffff)), 0x00020000);
+      __builtin_amdgcn_readfirstlane((int)imin64(nrows * D * 4, 0x7fffffff)), 0x00020000);
   f32x4 stg[NF];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int t) {
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(512) void kmeans_fused2_kernel(FusedArgs a) {
   const bool stamp = a.stamps && unit == 0 && tid == 0;
   const bool wstamp = a.stamps && unit == 0 && lane == 0;      // one lane per wave: per-wave phase ends
   for (int t = 0; t < ntiles; ++t) {
-    const int valid = (int)min<int64_t>(TT, nrows - (int64_t)t * TT);
+    const int valid = (int)imin64(TT, nrows - (int64_t)t * TT);
     if (stamp) a.stamps[t * 24 + 0] = __builtin_readcyclecounter();
     {
       // ---- scores: S[16 tokens][32 centres] over this wave's D/8 slice.  The B fragments (normalised centres, L2-resident)
@@ -661,9 +666,11 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   const int64_t nrows = n1 - n0;
   const int ntiles = (int)((nrows + TT - 1) / TT);
 
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(const_cast<float*>(a.x + n0 * D)), 0,
-      __builtin_amdgcn_readfirstlane((int)min<int64_t>(nrows * D * 4, 0x7fffffff)), 0x00020000);
+  // The descriptor of the unit's rows is rebuilt from two scalars at every use: built once here, the compiler kept half
+  // of it in VGPRs across the tile loop and wrapped every load of the next tile in a waterfall loop.
+  const unsigned long long x_base = reinterpret_cast<unsigned long long>(uniform_ptr(const_cast<float*>(a.x + n0 * D)));
+  const int x_bytes = __builtin_amdgcn_readfirstlane((int)imin64(nrows * D * 4, 0x7fffffff));
+#define x_rsrc __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(x_base), 0, x_bytes, 0x00020000)
   f32x4 stg[NF];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // slot f = tid + NT3 i of the [16][D/4] tile is (row, float4 column) = (f / (D/4), f % (D/4)); NT3 i / (D/4) = 2 SW i / NV
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   const bool stamp = a.stamps && blockIdx.x == 0 && tid == 0;
   const bool wstamp = a.stamps && blockIdx.x == 0 && lane == 0;
   for (int t = 0; t < ntiles; ++t) {
-    const int valid = (int)min<int64_t>(TT, nrows - (int64_t)t * TT);
+    const int valid = (int)imin64(TT, nrows - (int64_t)t * TT);
     if (stamp) a.stamps[t * 24 + 0] = __builtin_readcyclecounter();
     if (tid == 0) *npairs = 0;                 // (read after barrier B; barrier A orders this store before the atomics)
     // The HBM loads of the next tile go out during scoring: scoring and assign wait for no vector memory, so by the time
@@ -1043,6 +1050,8 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     if (k < a.K && g_live) static_for<CW>([&](auto j) { o[(int64_t)k * D + j] = acc[j][(int)k] / gn; });
   });
 }
+
+#undef x_rsrc
 
 template <int NV, int SW, bool KMEANS>
 int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
