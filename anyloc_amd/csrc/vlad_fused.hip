@@ -4,8 +4,13 @@
 // per-cluster sums / intra-norm / global norm of VLAD.generate :854-861,:889 (VLAD mode), and the
 // assign + update body of fast-pytorch-kmeans' fit loop reached from VLAD.fit :786 (k-means mode).
 //
-// One 1024-thread workgroup (16 waves, one per CU) owns a *unit*: an image (VLAD) or a chunk of
-// rows (k-means).  It walks the unit's tokens in tiles of 16:
+// Three structures live here (vlad_fused() picks; ANYLOC_VLAD_FUSED_V / ANYLOC_KMEANS_FUSED_V select one for A/B runs):
+//   vlad_fused_kernel     exact fp32-MFMA scores, centres streamed from L2, one owner thread per (cluster, column)
+//   kmeans_fused2_kernel  the same arithmetic, 512 threads, part of the centres register-resident (k-means only)
+//   fused3_kernel         fp16 screening scores from register-resident centres + exact fp32 resolution of close calls,
+//                         balanced register-indexed gather -- the default
+// The first structure, described: one 1024-thread workgroup (16 waves, one per CU) owns a *unit*: an image (VLAD) or a chunk
+// of rows (k-means).  It walks the unit's tokens in tiles of 16:
 //   stage   16 x D tile: coalesced buffer loads (rows past the unit read as 0) -> VGPR -> LDS,
 //           issued one tile ahead of its use
 //   score   waves 0-7: S[16 x 32] partials over their D/8 slice on v_mfma_f32_16x16x4_f32
@@ -570,6 +575,7 @@ __global__ __launch_bounds__(512) void kmeans_fused2_kernel(FusedArgs a) {
 // Labels therefore equal the fp32 arg-max except at fp32-rounding ties, like the kernels above.
 // 512 threads; thread (cluster tid/16, columns 4 (tid%16) + 64 m) owns 2 NV float4 accumulators (both modes).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 typedef float f32x32 __attribute__((ext_vector_type(32)));
@@ -731,7 +737,13 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       const unsigned off = (unsigned)(((16 * h + fr) * D + wave * SLICE + 32 * kb + 8 * fq) * 4);
-      bh[h][kb] = pack_h16x8(bload16(c_rsrc, off, 0), bload16(c_rsrc, off, 16));
+      // round to nearest (the error bound counts on half an fp16 ulp per centre element; the tokens' own split below may
+      // truncate, its second term picks up what the first one dropped)
+      const f32x4 c0 = bload16(c_rsrc, off, 0), c1 = bload16(c_rsrc, off, 16);
+      f32x8 cc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cc[e] = c0[e]; cc[4 + e] = c1[e]; }
+      bh[h][kb] = __builtin_convertvector(cc, h16x8);
     }
   const float my_bias = a.cbias[tid & 31];
   // ||chat_k||: 1 (cosine) or 2 ||c_k|| = 2 sqrt(-bias_k) (euclidean); its maximum scales the error bound
@@ -897,8 +909,8 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
           if (a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
         }
       }
+      lds_barrier();                           // (np is workgroup-uniform: with nothing queued, lab[] is final already)
     }
-    lds_barrier();
     if (stamp) a.stamps[t * 24 + 21] = __builtin_readcyclecounter();
     {
       // ---- gather: every wave adds every token (in order) to its columns of the token's cluster ----
@@ -944,7 +956,9 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         if (KMEANS) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            add_token(kk[e], v[e]);
+            // rows past the unit carry label -1 and are all zero (the loads were out of the descriptor's range): adding
+            // them to cluster 0 changes nothing and saves a branch per token
+            add_token(kk[e] < 0 ? 0 : kk[e], v[e]);
             if (wave == 0) my_count += (lane == kk[e]) ? 1u : 0u;
           }
         } else {
