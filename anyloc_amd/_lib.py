@@ -98,6 +98,7 @@ SIGNATURES = {
     "anyloc_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_f32p, C.c_int32,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint, c_f32p,
                                      C.c_void_p, c_sz, C.c_void_p]),
+    "anyloc_vit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "anyloc_profile_enable": (C.c_int, [C.c_int]),
     "anyloc_profile_reset": (C.c_int, []),
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),

@@ -47,6 +47,8 @@ struct ProfScope {
   ~ProfScope();
 };
 
+bool profiling_enabled();
+
 int launch_status(const char* what);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -33,6 +33,8 @@ int hip_fail(hipError_t e, const char* what) {
   return ANYLOC_ERR_HIP;
 }
 
+bool profiling_enabled() { return g_prof_on; }
+
 int launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, what);
@@ -47,7 +49,7 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes
   e.flops = flops;
   e.bytes = bytes;
   if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess) return;
-  hipEventRecord(e.start, s);
+  (void)hipEventRecord(e.start, s);
   g_prof.push_back(e);
   slot = (int)g_prof.size() - 1;
 }
@@ -55,7 +57,7 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes
 ProfScope::~ProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEventRecord(g_prof[slot].stop, stream);
+  (void)hipEventRecord(g_prof[slot].stop, stream);
 }
 
 }  // namespace anyloc
@@ -76,8 +78,8 @@ int anyloc_profile_enable(int enable) {
 int anyloc_profile_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& e : g_prof) {
-    hipEventDestroy(e.start);
-    hipEventDestroy(e.stop);
+    (void)hipEventDestroy(e.start);
+    (void)hipEventDestroy(e.stop);
   }
   g_prof.clear();
   return ANYLOC_OK;

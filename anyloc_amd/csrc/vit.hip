@@ -31,6 +31,23 @@ struct anyloc_vit {
   std::vector<anyloc_vit_block_weights> blocks;
   std::vector<anyloc_vit_block_x3> x3;      // optional: three-plane bf16 images of the four weight matrices
   std::vector<anyloc_vit_block_h2> h2;      // optional: two-plane fp16 images + row scales of the same matrices
+  // ANYLOC_VIT_GRAPH: instantiated launch sequences, keyed by everything a sequence depends on (shape, taps, flags,
+  // the four caller pointers, the environment switches read per forward); at most kMaxGraphs, least recently used out
+  struct Graph {
+    std::vector<int64_t> key;
+    hipGraphExec_t exec;
+    uint64_t stamp;
+  };
+  static constexpr size_t kMaxGraphs = 8;
+  std::vector<Graph> graphs;
+  std::vector<std::vector<int64_t>> seen;   // keys that ran eagerly once (the second call captures)
+  hipStream_t capture_stream = nullptr;     // capture needs a non-default stream; replay goes to the caller's stream
+  uint64_t clock = 0;
+  int64_t replays = 0;                      // hipGraphLaunch calls so far
+  ~anyloc_vit() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+    if (capture_stream) (void)hipStreamDestroy(capture_stream);
+  }
 };
 
 namespace anyloc {
@@ -258,23 +275,11 @@ size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch, int64_t 
   return carve(nullptr, 0, h->cfg, batch, img_h, img_w).bytes + 256;
 }
 
-int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t img_h, int64_t img_w,
-                       const float* pos, int32_t n_taps, const int32_t* tap_layers, const int32_t* tap_facets,
-                       unsigned flags, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  ANYLOC_CHECK_ARG(h && img && pos && out && tap_layers && tap_facets, "vit_forward: null pointer");
+// the launch sequence of one forward on `stream` (shape and taps already validated by anyloc_vit_forward)
+static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch, int64_t img_h, int64_t img_w,
+                                const float* pos, int32_t n_taps, const int32_t* tap_layers, const int32_t* tap_facets,
+                                unsigned flags, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   const anyloc_vit_config& c = h->cfg;
-  ANYLOC_CHECK_ARG(batch > 0 && batch < 65536, "vit_forward: batch %lld", (long long)batch);
-  ANYLOC_CHECK_ARG(img_h >= c.patch && img_w >= c.patch && img_h % c.patch == 0 && img_w % c.patch == 0,
-                   "vit_forward: image %lldx%lld is not a positive multiple of the patch size %d", (long long)img_h,
-                   (long long)img_w, c.patch);
-  ANYLOC_CHECK_ARG(n_taps >= 1 && n_taps <= 64, "vit_forward: n_taps %d", n_taps);
-  for (int t = 0; t < n_taps; ++t) {
-    ANYLOC_CHECK_ARG(tap_layers[t] >= 0 && tap_layers[t] < c.depth, "vit_forward: tap layer %d outside [0,%d)",
-                     tap_layers[t], c.depth);
-    ANYLOC_CHECK_ARG(tap_facets[t] >= 0 && tap_facets[t] <= 3, "vit_forward: facet %d", tap_facets[t]);
-    ANYLOC_CHECK_ARG(t == 0 || tap_layers[t] >= tap_layers[t - 1], "vit_forward: tap layers must ascend");
-  }
   const int D = c.dim, gh = (int)(img_h / c.patch), gw = (int)(img_w / c.patch), np = gh * gw, T = np + 1;
   const int64_t M = batch * T;
   VitWs w = carve(workspace, workspace_bytes, c, batch, img_h, img_w);
@@ -433,6 +438,91 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
   }
   if (flags & ANYLOC_VIT_NORM_CONCAT)
     ANYLOC_TRY(l2norm_rows(out, ldo, out, ldo, batch * rows_per_img, ldo, 1e-12f, stream));
+  return ANYLOC_OK;
+}
+
+int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t img_h, int64_t img_w,
+                       const float* pos, int32_t n_taps, const int32_t* tap_layers, const int32_t* tap_facets,
+                       unsigned flags, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(h && img && pos && out && tap_layers && tap_facets, "vit_forward: null pointer");
+  const anyloc_vit_config& c = h->cfg;
+  ANYLOC_CHECK_ARG(batch > 0 && batch < 65536, "vit_forward: batch %lld", (long long)batch);
+  ANYLOC_CHECK_ARG(img_h >= c.patch && img_w >= c.patch && img_h % c.patch == 0 && img_w % c.patch == 0,
+                   "vit_forward: image %lldx%lld is not a positive multiple of the patch size %d", (long long)img_h,
+                   (long long)img_w, c.patch);
+  ANYLOC_CHECK_ARG(n_taps >= 1 && n_taps <= 64, "vit_forward: n_taps %d", n_taps);
+  for (int t = 0; t < n_taps; ++t) {
+    ANYLOC_CHECK_ARG(tap_layers[t] >= 0 && tap_layers[t] < c.depth, "vit_forward: tap layer %d outside [0,%d)",
+                     tap_layers[t], c.depth);
+    ANYLOC_CHECK_ARG(tap_facets[t] >= 0 && tap_facets[t] <= 3, "vit_forward: facet %d", tap_facets[t]);
+    ANYLOC_CHECK_ARG(t == 0 || tap_layers[t] >= tap_layers[t - 1], "vit_forward: tap layers must ascend");
+  }
+  auto eager = [&]() {
+    return vit_forward_launches(h, img, batch, img_h, img_w, pos, n_taps, tap_layers, tap_facets, flags, out, workspace,
+                                workspace_bytes, stream);
+  };
+  // Small batches are bound by launch latency, not by throughput (ViT-g, one 322 x 322 image: ~220 dependent launches of
+  // 20-40 us): with ANYLOC_VIT_GRAPH the sequence is captured once per key into a HIP graph and replayed with a single
+  // hipGraphLaunch.  The first call of a key runs eagerly (it sets kernel attributes and loads the code objects, and
+  // one-off shapes never pay for an instantiation), the second captures.  Not while the per-kernel profiler is on (its
+  // events bracket individual launches).
+  if (!(flags & ANYLOC_VIT_GRAPH) || profiling_enabled()) return eager();
+  std::vector<int64_t> key = {batch, img_h, img_w, (int64_t)flags, (int64_t)n_taps, (int64_t)(uintptr_t)img,
+                              (int64_t)(uintptr_t)pos, (int64_t)(uintptr_t)out, (int64_t)(uintptr_t)workspace,
+                              (int64_t)workspace_bytes, (int64_t)h3_fused(), (int64_t)x6_fused(), h3_min_rows(), x6_min_rows()};
+  for (int t = 0; t < n_taps; ++t) key.push_back(((int64_t)tap_layers[t] << 8) | tap_facets[t]);
+  ++h->clock;
+  for (auto& g : h->graphs)
+    if (g.key == key) {
+      g.stamp = h->clock;
+      ANYLOC_HIP(hipGraphLaunch(g.exec, stream));
+      ++h->replays;
+      return ANYLOC_OK;
+    }
+  bool seen = false;
+  for (auto& k : h->seen) seen = seen || k == key;
+  if (!seen) {
+    if (h->seen.size() >= 64) h->seen.erase(h->seen.begin());
+    h->seen.push_back(key);
+    return eager();
+  }
+  if (!h->capture_stream) ANYLOC_HIP(hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
+  ANYLOC_HIP(hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal));
+  const int rc = vit_forward_launches(h, img, batch, img_h, img_w, pos, n_taps, tap_layers, tap_facets, flags, out, workspace,
+                                      workspace_bytes, h->capture_stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(h->capture_stream, &graph);
+  if (rc != ANYLOC_OK || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (rc != ANYLOC_OK) return rc;                        // the sequence itself is invalid: report that
+    return eager();                                        // capture refused: run as usual
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    return eager();
+  }
+  if (h->graphs.size() >= anyloc_vit::kMaxGraphs) {
+    size_t victim = 0;
+    for (size_t i = 1; i < h->graphs.size(); ++i)
+      if (h->graphs[i].stamp < h->graphs[victim].stamp) victim = i;
+    (void)hipGraphExecDestroy(h->graphs[victim].exec);
+    h->graphs.erase(h->graphs.begin() + victim);
+  }
+  h->graphs.push_back({key, exec, h->clock});
+  ANYLOC_HIP(hipGraphLaunch(exec, stream));
+  ++h->replays;
+  return ANYLOC_OK;
+}
+
+int anyloc_vit_graph_stats(const anyloc_vit_t* h, int64_t* graphs, int64_t* replays) {
+  ANYLOC_CHECK_ARG(h && graphs && replays, "vit_graph_stats: null pointer");
+  *graphs = (int64_t)h->graphs.size();
+  *replays = h->replays;
   return ANYLOC_OK;
 }
 

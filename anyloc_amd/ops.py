@@ -14,7 +14,7 @@ VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
 VLAD_EUCLIDEAN = 4
 FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
-VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1, 2, 4, 8, 16
+VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16, VIT_GRAPH = 1, 2, 4, 8, 16, 32
 
 
 def _f32c(t, device=None):

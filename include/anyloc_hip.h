@@ -320,6 +320,13 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*ho
 #define ANYLOC_VIT_NORM_TAPS 2u      /* L2-normalise each tap (utilities.py:282-283) */
 #define ANYLOC_VIT_NORM_CONCAT 4u    /* L2-normalise the concatenated taps again
                                         (scripts/dino_v2_vlad_viz.py:175-196) */
+#define ANYLOC_VIT_GRAPH 32u         /* replay the launch sequence as one HIP graph: the first call with a given
+                                        (shape, taps, flags, img / pos / out / workspace pointers) runs as usual, the
+                                        second captures it, later ones are a single hipGraphLaunch on `stream`.  For
+                                        launch-latency-bound calls (one or two images, as the reference's scripts call
+                                        the extractor, utilities.py:263-285); needs stable pointers to pay off and is
+                                        ignored while anyloc_profile_enable(1) is in effect.  Results are those of the
+                                        plain call (same kernels, same order). */
 
 size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch,
                                   int64_t img_h, int64_t img_w);
@@ -332,6 +339,9 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch,
                        int32_t n_taps, const int32_t* tap_layers,
                        const int32_t* tap_facets, unsigned flags, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ANYLOC_VIT_GRAPH bookkeeping: instantiated graphs held by the handle, graph launches so far. */
+int anyloc_vit_graph_stats(const anyloc_vit_t* h, int64_t* graphs, int64_t* replays);
 
 /* Name and average device time (ms, HIP events on the launch stream) of the
  * kernels issued by the most recent call with profiling enabled; used by

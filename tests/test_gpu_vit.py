@@ -151,3 +151,24 @@ def test_config1_pipeline_through_reference_surface(g1, c1, capsys):
     assert np.array_equal(i.numpy()[:, :5], g1["top_idx"][:, :5])
     np.testing.assert_allclose(d.numpy(), g1["top_dist"], atol=2e-5)
     capsys.readouterr()
+
+
+def test_hip_graph_replay_is_bit_equal(c1, monkeypatch):
+    """ANYLOC_VIT_GRAPH (csrc/vit.hip): the launch sequence of a small-batch forward, captured into a HIP graph on the
+    second call with a key and replayed afterwards, produces exactly the tokens of the plain launches -- on changing
+    inputs (the graph is bound to the extractor's own input / output pair), for two shapes held at the same time."""
+    import utilities
+    sd, imgs, _ = c1
+    ext = utilities.DinoV2ExtractFeatures("dinov2_vits14", 9, "value", device=DEV)
+    batches = [imgs[0:1], imgs[1:2], imgs[2:3], imgs[3:5], imgs[5:7], imgs[0:1]]
+    monkeypatch.setenv("ANYLOC_VIT_GRAPH_MAX_ROWS", "0")
+    want = [ext(b.to(DEV)).clone() for b in batches]
+    assert ext.dino_model.graph_stats() == (0, 0)
+    monkeypatch.setenv("ANYLOC_VIT_GRAPH_MAX_ROWS", "1000")
+    got = [ext(b.to(DEV)).clone() for b in batches]
+    graphs, replays = ext.dino_model.graph_stats()
+    assert graphs == 2 and replays == 4          # B=1: eager, capture+launch, replay, replay; B=2: eager, capture+launch
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    big = torch.cat([imgs[:6]]).to(DEV)          # above the threshold: plain launches, no new graph
+    assert ext(big).shape[0] == 6 and ext.dino_model.graph_stats() == (graphs, replays)
