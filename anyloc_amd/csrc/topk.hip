@@ -5,8 +5,9 @@
 //
 // The database is processed in column panels: an fp32 MFMA GEMM (gemm_f32.hip)
 // writes the [nq, panel] score block, then one block per query merges the
-// panel into that query's running top-k list (k selection passes over an
-// LDS-resident candidate set; ties -> lower database index, deterministic).
+// panel into that query's running top-k list (threshold filter against the
+// list's k-th entry + one-wave selection; ties -> lower database index,
+// deterministic).
 // Governing roofline: fp32 MFMA (2*nq flop per database float).
 #include <algorithm>
 
@@ -16,19 +17,15 @@ namespace anyloc {
 
 namespace {
 
-constexpr int CH = 4096;          // candidates staged in LDS per merge round
+constexpr int TILE = 2048;        // score columns per filtering step (at most TILE new candidates)
+constexpr int BOOT = 256;         // columns of the very first step (no threshold yet: every column is a candidate)
+constexpr int CAP = TILE + BOOT;  // candidates that beat the running k-th entry, buffered in LDS between selections
 constexpr int64_t PANEL = 32768;  // database rows per GEMM panel
 constexpr int KMAX = 1024;
 
-struct Cand {
-  float v;
-  long long i;   // global index (lower wins ties)
-  int pos;       // position in the LDS candidate array
-};
 __device__ __forceinline__ bool better(float v, long long i, float bv, long long bi) {
   return v > bv || (v == bv && i < bi);
 }
-
 __global__ __launch_bounds__(256) void rownorm_sq_kernel(const float* __restrict__ x, int64_t dim,
                                                          float* __restrict__ out) {
   __shared__ float red[4];
@@ -45,6 +42,61 @@ __global__ __launch_bounds__(256) void rownorm_sq_kernel(const float* __restrict
 // initialises it to (-inf, -1).  metric 1: candidate value = -(qn + dn - 2 ip).
 // dnorm != nullptr: the database rows were scored RAW and are normalised here, score / dnorm[col]
 // (dnorm = max(||row||, 1e-12): F.normalize of the row, reference utilities.py:436, without a normalised copy).
+//
+// Threshold filter + rank selection.  The k-th entry of the running list bounds everything that can still enter it, so
+// the block streams the score row in steps of TILE columns and keeps only the candidates that beat that entry (value,
+// then lower index) in an LDS buffer -- for a list that has seen n columns about k / n of a step.  When the buffer could
+// overflow on the next step, and at the end, the best k of list + buffer are found WITHOUT selection rounds: every entry
+// carries a 64-bit key whose unsigned order is the retrieval order,
+//     key = order-preserving bits of the value | tie field (list entries 0xFFFF, candidates 0x7FFF - column) | ~slot,
+// (list entries come from earlier columns than any buffered candidate, and the list is sorted: on equal values a list
+// entry precedes a candidate and a lower slot precedes a higher one -- exactly "ties -> lower database index"), each
+// thread counts the keys above those of its own entries while the whole block reads the key array as LDS broadcasts, and an
+// entry of rank r < k goes to position r of the new list.  Keys are unique (the slot), so ranks are; the buffer is filled
+// through an LDS counter in a varying order, which the ranks do not depend on: the result is deterministic.
+__device__ __forceinline__ unsigned ord_bits(float v) {
+  v += 0.0f;                                               // -0 -> +0: equal under the float comparison of the filter
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float ord_value(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+__device__ __forceinline__ unsigned long long merge_key(float v, unsigned tie, int slot) {
+  return ((unsigned long long)ord_bits(v) << 32) | ((unsigned long long)(tie & 0xffffu) << 16) | (unsigned long long)(0xffff - slot);
+}
+
+// rank of every entry among the `tot` keys (number of keys above it); entries of rank < k go to position rank of the new
+// list.  U of a thread's entries share one pass over the key array, which every lane reads at the same address (broadcast).
+template <int U>
+__device__ __forceinline__ void rank_entries(const unsigned long long* key, const long long* ei, float* nv, long long* ni,
+                                             int tot, int tot2, int k) {
+  const int tid = threadIdx.x;
+  for (int e0 = tid; e0 < tot; e0 += 256 * U) {
+    unsigned long long mine[U];
+    int rank[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u;
+      mine[u] = e < tot ? key[e] : ~0ull;                  // no entry: nothing ranks above it, and it is never written
+      rank[u] = 0;
+    }
+    for (int j = 0; j < tot2; j += 2) {
+      const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&key[j]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) rank[u] += (kk.x > mine[u]) + (kk.y > mine[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < tot && rank[u] < k) {
+        nv[rank[u]] = ord_value((unsigned)(mine[u] >> 32));
+        ni[rank[u]] = ei[e];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, int64_t ld, int64_t ncols,
                                                          int64_t col_base, int k, int metric,
                                                          const float* __restrict__ qn, const float* __restrict__ dn,
@@ -52,72 +104,90 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
                                                          float* __restrict__ run_v, long long* __restrict__ run_i,
                                                          int first) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* cv = reinterpret_cast<float*>(smem_raw);                       // [CH + k] candidate values
-  long long* ri = reinterpret_cast<long long*>(cv + CH + KMAX);         // [k] indices of the running entries
-  float* nv = reinterpret_cast<float*>(ri + KMAX);                      // [k] new list values
-  long long* ni = reinterpret_cast<long long*>(nv + KMAX);              // [k] new list indices
-  __shared__ Cand wbest[4];
+  // slots [0, k): running list, best first; slots [k, k + CAP): buffered candidates
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem_raw);          // [k2 + CAP], k2 = k rounded up to even
+  const int k2 = (k + 1) & ~1;
+  long long* ei = reinterpret_cast<long long*>(key + k2 + CAP);                        // [k2 + CAP] global indices
+  float* nv = reinterpret_cast<float*>(ei + k2 + CAP);                                 // [k] list under construction
+  long long* ni = reinterpret_cast<long long*>(nv + k2);
+  __shared__ int n_s;
+  __shared__ float thr_v;
+  __shared__ long long thr_i;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int64_t q = blockIdx.x;
   const float* srow = scores + q * ld;
   const float qq = metric ? qn[q] : 0.f;
 
   for (int i = tid; i < k; i += 256) {
-    if (first) { cv[CH + i] = -INFINITY; ri[i] = -1; }
-    else { cv[CH + i] = run_v[q * k + i]; ri[i] = run_i[q * k + i]; }
+    const float v = first ? -INFINITY : run_v[q * k + i];
+    key[i] = merge_key(v, 0xffffu, i);
+    ei[i] = first ? -1 : run_i[q * k + i];
   }
-  for (int64_t c0 = 0; c0 < ncols; c0 += CH) {
-    const int nc = (int)min<int64_t>(CH, ncols - c0);
-    for (int i = tid; i < CH; i += 256) {
-      float v = -INFINITY;
-      if (i < nc) {
-        v = srow[c0 + i];
-        if (dnorm) v = v / dnorm[c0 + i];
-        if (metric) v = -((qq + dn[c0 + i]) - 2.0f * v);
-      }
-      cv[i] = v;
+  if (tid == 0) {
+    n_s = 0;
+    thr_v = first ? -INFINITY : run_v[q * k + k - 1];
+    thr_i = first ? -1 : run_i[q * k + k - 1];
+  }
+  __syncthreads();
+
+  // best k of slots [0, k + n_s) -> list; called by the whole block after a barrier
+  auto select = [&]() {
+    const int tot = k + n_s;
+    const int tot2 = (tot + 1) & ~1;
+    if (tid == 0 && (tot & 1)) key[tot] = 0;               // pad to a whole 16-byte read: below every real key
+    __syncthreads();
+    if (tot <= 256) rank_entries<1>(key, ei, nv, ni, tot, tot2, k);
+    else if (tot <= 512) rank_entries<2>(key, ei, nv, ni, tot, tot2, k);
+    else rank_entries<4>(key, ei, nv, ni, tot, tot2, k);
+    __syncthreads();
+    for (int i = tid; i < k; i += 256) {
+      key[i] = merge_key(nv[i], 0xffffu, i);
+      ei[i] = ni[i];
+    }
+    if (tid == 0) {
+      thr_v = nv[k - 1];
+      thr_i = ni[k - 1];
+      n_s = 0;
     }
     __syncthreads();
-    const long long gbase = col_base + c0;
-    for (int sel = 0; sel < k; ++sel) {
-      float bv = -INFINITY;
-      long long bi = 0x7fffffffffffffffll;
-      int bp = -1;
-      for (int i = tid; i < CH + k; i += 256) {
-        if (i >= nc && i < CH) continue;
-        const float v = cv[i];
-        const long long gi = i < CH ? gbase + i : ri[i - CH];
-        if (bp < 0 || better(v, gi, bv, bi)) { bv = v; bi = gi; bp = i; }
-      }
+  };
+
+  int64_t c0 = 0;
+  while (c0 < ncols) {
+    const int step = (first && c0 == 0) ? BOOT : TILE;    // the first step only seeds the threshold
+    if (n_s + step > CAP) select();                       // n_s is uniform here: every path to this line ends in a barrier
+    const float tv = thr_v;
+    const long long ti = thr_i;
+    float v[TILE / 256];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const long long oi = __shfl_xor(bi, o, 64);
-        const int op = __shfl_xor(bp, o, 64);
-        if (op >= 0 && (bp < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+    for (int j = 0; j < TILE / 256; ++j) {                // all loads of the step first
+      const int64_t c = c0 + tid + 256 * j;
+      v[j] = -INFINITY;
+      if (256 * j < step && c < ncols) {
+        v[j] = srow[c];
+        if (dnorm) v[j] = v[j] / dnorm[c];
+        if (metric) v[j] = -((qq + dn[c]) - 2.0f * v[j]);
       }
-      if (lane == 0) { wbest[wave].v = bv; wbest[wave].i = bi; wbest[wave].pos = bp; }
-      __syncthreads();
-      if (tid == 0) {
-        Cand b = wbest[0];
-        for (int w2 = 1; w2 < 4; ++w2)
-          if (wbest[w2].pos >= 0 && (b.pos < 0 || better(wbest[w2].v, wbest[w2].i, b.v, b.i))) b = wbest[w2];
-        nv[sel] = b.v;
-        ni[sel] = b.i;
-        // retire the winner: value -inf; a retired running entry also gets the largest index so
-        // that untouched (-inf, -1) padding entries are preferred over it
-        cv[b.pos] = -INFINITY;
-        if (b.pos >= CH) ri[b.pos - CH] = 0x7fffffffffffffffll;
-      }
-      __syncthreads();
     }
-    for (int i = tid; i < k; i += 256) { cv[CH + i] = nv[i]; ri[i] = ni[i]; }
+#pragma unroll
+    for (int j = 0; j < TILE / 256; ++j) {
+      const int64_t c = c0 + tid + 256 * j;
+      const long long gi = col_base + c;
+      if (256 * j < step && c < ncols && better(v[j], gi, tv, ti)) {
+        const int slot = k + atomicAdd(&n_s, 1);
+        key[slot] = merge_key(v[j], 0x7fffu - (unsigned)c, slot);
+        ei[slot] = gi;
+      }
+    }
     __syncthreads();
+    if (first && c0 == 0) select();                       // the seed columns become the first list: a real threshold from here on
+    c0 += step;
   }
+  select();
   for (int i = tid; i < k; i += 256) {
-    run_v[q * k + i] = cv[CH + i];
-    run_i[q * k + i] = ri[i];
+    run_v[q * k + i] = ord_value((unsigned)(key[i] >> 32));
+    run_i[q * k + i] = ei[i];
   }
 }
 
@@ -234,12 +304,13 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
     set_error("topk: workspace %zu < %zu", workspace_bytes, w.bytes);
     return ANYLOC_ERR_WORKSPACE;
   }
-  const size_t lds = sizeof(float) * (CH + KMAX) + sizeof(long long) * KMAX + sizeof(float) * KMAX +
-                     sizeof(long long) * KMAX;
+  static_assert(PANEL <= 0x8000 && CAP + KMAX + 2 <= 0xffff, "merge keys hold the column in 15 bits and the slot in 16");
+  const size_t k2 = (size_t)((k + 1) & ~1ll);
+  const size_t lds = 16 * (k2 + CAP) + 12 * k2 + 16;      // 37 KiB at k = 20: four blocks per CU
   static bool attr = false;
   if (!attr) {
     ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (KMAX + CAP) + 12 * KMAX + 16));
     attr = true;
   }
   if (metric == 1) {

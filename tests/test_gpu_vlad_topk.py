@@ -284,6 +284,42 @@ def test_topk_normalize_db_vs_oracle(nq, ndb, dim, k, metric):
     assert float((i2.cpu()[:, :kk] != i[:, :kk]).float().mean()) < 0.02
 
 
+@pytest.mark.parametrize("order", ["ascending", "descending", "constant", "blocks"])
+@pytest.mark.parametrize("k", [1, 20, 300])
+def test_topk_merge_adversarial_orders(order, k):
+    """The merge kernel keeps only the columns that beat the running k-th entry (csrc/topk.hip): score rows that rise
+    monotonically (every tile beats the threshold: one selection per tile), fall, are all equal (every entry ties: lower
+    index first) or come in equal-valued blocks must give exactly the flat search's lists -- over several panels."""
+    from anyloc_amd import ops
+    ndb, dim = 70001, 8                                   # three 32768-row panels, the last one ragged
+    u = torch.zeros(dim)
+    u[0] = 1.0
+    j = torch.arange(ndb, dtype=torch.float32)
+    if order == "ascending":
+        s = (j + 1.0) / ndb
+    elif order == "descending":
+        s = (ndb - j) / ndb
+    elif order == "constant":
+        s = torch.full((ndb,), 0.5)
+    else:
+        s = torch.floor(j / 97.0) % 13 / 13.0 + 0.25      # blocks of 97 equal scores, 13 levels, repeating
+    db = s[:, None] * u[None, :]
+    qu = torch.stack([u, 2.0 * u, -u])                    # -u reverses the order
+    for metric in ("ip", "l2"):
+        d, i = ops.topk(qu.to(DEV), db.to(DEV), k, metric)
+        d_ref, i_ref = faiss_flat.flat_search(qu, db, k, metric)
+        d, i = d.cpu(), i.cpu()
+        np.testing.assert_allclose(d.numpy(), d_ref.numpy(), rtol=0, atol=1e-6)
+        if metric == "ip":                                # one exact product per score: the lists must be identical
+            assert torch.equal(i, i_ref), (order, k, metric)
+        else:                                             # |q|^2 + |d|^2 - 2 q.d rounds: only exact-distance ties may swap
+            mism = i != i_ref
+            assert not mism.any() or float((d_ref[mism] - d[mism]).abs().max()) < 1e-6
+            for r in range(i.shape[0]):                   # ... and the GPU's own list is ordered (distance, then index)
+                dd, ii = d[r], i[r]
+                assert bool(((dd[:-1] < dd[1:]) | ((dd[:-1] == dd[1:]) & (ii[:-1] < ii[1:]))).all())
+
+
 def test_get_top_k_recall_surface():
     import utilities
     g = torch.Generator().manual_seed(5)
