@@ -74,7 +74,10 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         "clock_note": ("profiles/r02_pmc_fused_sq_raw.md + r02_pmc_fused_write_raw.md (h3) / r01_pmc_x6.md (x6): under these GEMMs "
                        "the chip runs at its power limit -- 1.57 GHz with the matrix cores busy 76.6 % of all SIMD cycles for "
-                       "the h3 w12 kernel (1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz figure") if split else None,
+                       "the h3 w12 kernel (1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz figure.  Calibration "
+                       "(profiles/r02_calib_h3_hipblaslt_zero_data.log): the same h3 kernel runs 39 % faster on all-zero operands, "
+                       "and hipBLASLt's fp16 GEMM sustains 1.04-1.43 PFLOP/s on these shapes on random data (this kernel: 1.15-1.24 "
+                       "PFLOP/s of fp16 MFMA work = 3 x achieved)") if split else None,
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"],
         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
         "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
