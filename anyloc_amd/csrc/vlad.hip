@@ -200,7 +200,15 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= kd) return;
   float s = 0.f;
-  for (int64_t ch = 0; ch < n_chunks; ++ch) s += part[ch * kd + i];
+  int64_t ch = 0;
+  for (; ch + 16 <= n_chunks; ch += 16) {                   // 16 independent loads in flight, added in chunk order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(ch + u) * kd + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; ch < n_chunks; ++ch) s += part[ch * kd + i];
   sums[i] = s;
 }
 
@@ -652,8 +660,24 @@ int anyloc_vlad_assigned(const float* tokens, int64_t n_tok, int64_t D, const fl
 }
 
 // ------------------------------------------------------------------ k-means
+// rows per chunk of the k-means step: one workgroup and one partial [K, D] sum per chunk, the partial sums added in chunk
+// order by reduce_chunks_kernel.  At least 1024 rows per chunk and at most two chunks per CU (ANYLOC_KMEANS_MAX_CHUNKS
+// overrides): every chunk costs a prologue, 196 KB of partial sums written and re-read, and with one fused workgroup
+// filling a CU more chunks only add rounds -- 5 M x 1536 rows: 2048 chunks 6.67 ms, 1024 6.20, 512 5.87, 256 5.87 per
+// step on clustered rows (profiles/r02_kmeans_chunks.log); two per CU keeps some slack for CUs of unequal speed.
 static int64_t kmeans_chunk_rows(int64_t n) {
-  int64_t rows = (n + 2047) / 2048;       // at most 2048 chunks
+  static int64_t max_chunks = 0;
+  if (max_chunks == 0) {
+    const char* e = getenv("ANYLOC_KMEANS_MAX_CHUNKS");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    max_chunks = (e && atoll(e) > 0) ? atoll(e) : 2ll * cus;
+  }
+  int64_t rows = (n + max_chunks - 1) / max_chunks;
   return rows < 1024 ? 1024 : rows;
 }
 
