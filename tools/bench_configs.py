@@ -115,12 +115,19 @@ def config5():
     run()
     t, (dist, idx, d, q) = sync_time(run)
     rec = retrieval.recalls_from_indices([1, 5, 10], idx.cpu().numpy(), gt)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    run()
+    torch.cuda.synchronize()
+    prof = ops.profile_dump()
+    ops.profile_enable(False)
     T = 1370
     f_block = 2 * T * 1024 * 3072 + 4 * T * T * 1024 + 2 * T * 1024 * 1024 + 16 * T * 1024 * 1024
     f_img = 2 * 1369 * 588 * 1024 + 23 * f_block + 2 * T * 1024 * 1024 + 2 * T * 1024 * 3072   # L23 tap + qkv of block 20 reused
     return {"config": "configs[4] ViT-L/14 518x518, taps L20+L23 'value' concat (2048-d), K=64 VLAD (131072-d), 64 db + 16 qu",
             "images_per_s": round(80 / t, 2), "seconds": round(t, 3), "vlad_dim": int(d.shape[1]),
-            "approx_tflops": round(80 * f_img / t / 1e12, 1), "recall": rec}
+            "approx_tflops": round(80 * f_img / t / 1e12, 1), "recall": rec,
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
 
 
 if __name__ == "__main__":
