@@ -29,16 +29,19 @@ typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
 
 
 
-template <int MI, int NI, int WM, int WN, int STAGES>
+// KB = k-blocks (of 16) per ring stage: one barrier and one counted wait per KB k-blocks instead of per k-block
+template <int MI, int NI, int WM, int WN, int STAGES, int KB = 1>
 struct H3Cfg {
   static constexpr int NW = WM * WN;
   static constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
   static constexpr int A_PLANE = BM * 32, W_PLANE = BN * 32;
-  static constexpr int A_OP = 2 * A_PLANE, STAGE = A_OP + 2 * W_PLANE;
+  static constexpr int A_OP = 2 * A_PLANE, KSTAGE = A_OP + 2 * W_PLANE;   // one k-block: A planes, then W planes
+  static constexpr int STAGE = KB * KSTAGE;
   static constexpr int LDS = STAGES * STAGE;
   static constexpr int A_DMA = BM / (32 * NW), W_DMA = BN / (32 * NW);
-  static constexpr int NDMA = 2 * (A_DMA + W_DMA);
+  static constexpr int NDMA = KB * 2 * (A_DMA + W_DMA);
   static_assert(BM % (32 * NW) == 0 && BN % (32 * NW) == 0, "each wave stages whole 32-row pieces");
+  static_assert((STAGES - 2) * NDMA <= 63, "the counted vmcnt wait must be encodable");
 };
 
 
@@ -69,9 +72,9 @@ __device__ __forceinline__ void h2_pack2(float a, float b, unsigned& hi, unsigne
 __device__ __forceinline__ float h3_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float h3_silu(float v) { return v / (1.0f + expf(-v)); }
 
-template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI>
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p, int tiles_m, int tiles_n) {
-  using Cfg = H3Cfg<MI, NI, WM, WN, STAGES>;
+  using Cfg = H3Cfg<MI, NI, WM, WN, STAGES, KB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -90,19 +93,23 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
     a_voff[pl] = (unsigned)(((int64_t)pl * p.RA + m0 + 32 * wave) * 32 + lane * 16);
     w_voff[pl] = (unsigned)(((int64_t)pl * p.RW + n0 + 32 * wave) * 32 + lane * 16);
   }
-  auto issue = [&](int kt, int stage) {
-    unsigned char* st = smem + stage * Cfg::STAGE + wave * 1024;
-    const unsigned ao = (unsigned)kt * a_slab, wo = (unsigned)kt * w_slab;
+  // stage step `ks` = k-blocks ks * KB ... ks * KB + KB - 1 (past the last k-block: out of the descriptor's range, zero-fills)
+  auto issue = [&](int ks, int stage) {
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int kb = 0; kb < KB; ++kb) {
+      unsigned char* st = smem + stage * Cfg::STAGE + kb * Cfg::KSTAGE + wave * 1024;
+      const unsigned ao = (unsigned)(ks * KB + kb) * a_slab, wo = (unsigned)(ks * KB + kb) * w_slab;
 #pragma unroll
-      for (int c = 0; c < Cfg::A_DMA; ++c)
-        dma16_to_lds(a_rsrc, st + pl * Cfg::A_PLANE + c * (1024 * Cfg::NW), a_voff[pl] + c * (1024 * Cfg::NW), ao);
+      for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+        for (int c = 0; c < Cfg::A_DMA; ++c)
+          dma16_to_lds(a_rsrc, st + pl * Cfg::A_PLANE + c * (1024 * Cfg::NW), a_voff[pl] + c * (1024 * Cfg::NW), ao);
 #pragma unroll
-      for (int c = 0; c < Cfg::W_DMA; ++c)
-        dma16_to_lds(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * (1024 * Cfg::NW), w_voff[pl] + c * (1024 * Cfg::NW), wo);
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int c = 0; c < Cfg::W_DMA; ++c)
+          dma16_to_lds(w_rsrc, st + Cfg::A_OP + pl * Cfg::W_PLANE + c * (1024 * Cfg::NW), w_voff[pl] + c * (1024 * Cfg::NW), wo);
+    }
   };
 
   const int fr = lane & 31, fh = lane >> 5;
@@ -116,35 +123,40 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-  const int nk = p.K16;
+  const int nk = (p.K16 + KB - 1) / KB;                    // stage steps
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
 
   auto slab = [&](int kt, int stage) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::NDMA) : "memory");
     __builtin_amdgcn_s_barrier();
-    const unsigned char* sa = frag + stage * Cfg::STAGE + (wm * 32 * MI) * 32;
-    const unsigned char* sw = frag + stage * Cfg::STAGE + Cfg::A_OP + (wn * 32 * NI) * 32;
-    f16x8 a[MI][2], b[NI][2];
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
+    for (int kb = 0; kb < KB; ++kb) {
+      const unsigned char* sa = frag + stage * Cfg::STAGE + kb * Cfg::KSTAGE + (wm * 32 * MI) * 32;
+      const unsigned char* sw = frag + stage * Cfg::STAGE + kb * Cfg::KSTAGE + Cfg::A_OP + (wn * 32 * NI) * 32;
+      f16x8 a[MI][2], b[NI][2];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi][pl] = *reinterpret_cast<const f16x8*>(sa + pl * Cfg::A_PLANE + mi * 1024);
+      for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni][pl] = *reinterpret_cast<const f16x8*>(sw + pl * Cfg::W_PLANE + ni * 1024);
-    }
-    issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);   // past the last k-block: out of range, zero-fills
+        for (int mi = 0; mi < MI; ++mi) a[mi][pl] = *reinterpret_cast<const f16x8*>(sa + pl * Cfg::A_PLANE + mi * 1024);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni][pl] = *reinterpret_cast<const f16x8*>(sw + pl * Cfg::W_PLANE + ni * 1024);
+      }
+      if (kb == 0) issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
 #define ANYLOC_H3_TERM(pa, pb)                                                                       \
   _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
-    ANYLOC_H3_TERM(1, 0) ANYLOC_H3_TERM(0, 1) ANYLOC_H3_TERM(0, 0)
+      ANYLOC_H3_TERM(1, 0) ANYLOC_H3_TERM(0, 1) ANYLOC_H3_TERM(0, 0)
 #undef ANYLOC_H3_TERM
-    constexpr int PIECES = Cfg::NDMA, G = (3 * MI * NI) / (PIECES + 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
+    }
+    if constexpr (KB == 1) {
+      constexpr int PIECES = Cfg::NDMA, G = (3 * MI * NI) / (PIECES + 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      for (int i = 0; i < PIECES; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
     }
   };
   for (int kt = 0; kt < nk; kt += STAGES) {
@@ -437,16 +449,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
 // (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
 // store chunk i (256 columns) of 16 rows, already scaled and sitting in the LDS tile, in IMAGE order
 // (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
+template <int RB = 16>
 __device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, int dim, int64_t row0, int64_t rows,
                                                unsigned char* out, int64_t R) {
+  static_assert(RB == 16 || RB == 4, "16 rows per block (4 per wave) or 4 (1 per wave)");
   const int tid = threadIdx.x;
+  constexpr int ITEMS = RB * 32;                           // (k-block, row, half) triples of one 256-column chunk
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < (ITEMS + 255) / 256; ++u) {
     const int item = tid + 256 * u;
-    const int kbl = item >> 5, r = (item >> 1) & 15, half = item & 1;
+    const int kbl = item / (2 * RB), r = (item >> 1) & (RB - 1), half = item & 1;
     const int k0 = 256 * i + 16 * kbl + 8 * half;
     const int64_t row = row0 + r;
-    if (k0 < dim && row < rows) {
+    if (item < ITEMS && k0 < dim && row < rows) {
       const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
       hu32x4 ph, plo;
@@ -471,8 +486,8 @@ __device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, in
 }
 
 // rows held in registers: the scaled values of 16 rows go through the LDS tile chunk by chunk
-template <int NV>
-__device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[4][NV], const float (&scale)[4], float (*tile)[256 + 4],
+template <int NV, int RPW = 4>
+__device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[RPW][NV], const float (&scale)[RPW], float (*tile)[256 + 4],
                                               int dim, int64_t row0, int64_t rows, unsigned char* out, int64_t R) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n4 = dim >> 2;
@@ -482,15 +497,15 @@ __device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[4][NV], const flo
     if (i > 0) __syncthreads();
     if (idx < n4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < RPW; ++q) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = v[q][i][j] * scale[q];
-        *reinterpret_cast<f32x4*>(&tile[wave * 4 + q][4 * lane]) = o;
+        *reinterpret_cast<f32x4*>(&tile[wave * RPW + q][4 * lane]) = o;
       }
     }
     __syncthreads();
-    h2_store_chunk(tile, i, dim, row0, rows, out, R);
+    h2_store_chunk<4 * RPW>(tile, i, dim, row0, rows, out, R);
   }
 }
 
@@ -570,20 +585,23 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
 // bound_inv[row] = 2^-e, where 2^e scales an UPPER BOUND of |act(fc1(y_row))| into [2^14, 2^15).  Cauchy-Schwarz:
 // |fc1_j(y)| <= ||y||_2 max_j ||W_j||_2 + max_j |b_j|, |gelu(t)| <= |t|, |silu(g) v| <= |g| |v|; bound4 = {gate (or fc1)
 // row-norm maximum, gate bias maximum, value row-norm maximum, value bias maximum} (value pair 0 / 0: GELU MLP).
-template <int NV>
+// RPW rows per wave (4 waves per block): 4 by default; 1 when there are few rows (one or two images: 530 rows are 34
+// blocks of 16 rows on 256 CUs -- 25 us of latency per launch; 133 blocks of 4 rows spread them).  Per-row arithmetic does
+// not depend on RPW, so the results are bitwise the same.
+template <int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, int dim, int64_t rows, float eps,
                                                            unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
                                                            const f32x4 bound4, float* __restrict__ bound_inv) {
-  __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+  __shared__ __attribute__((aligned(16))) float tile[4 * RPW][256 + 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n4 = dim >> 2;
-  const int64_t row0 = (int64_t)blockIdx.x * 16;
-  f32x4 v[4][NV];
-  float scale[4];
+  const int64_t row0 = (int64_t)blockIdx.x * (4 * RPW);
+  f32x4 v[RPW][NV];
+  float scale[RPW];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
+  for (int q = 0; q < RPW; ++q) {
+    const int64_t row = min(row0 + wave * RPW + q, rows - 1);
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
     float s = 0.f;
 #pragma unroll
@@ -619,17 +637,17 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
     }
     float iv;
     scale[q] = h2_row_scale(wave_max(amax), iv);
-    if (lane == 0 && row0 + wave * 4 + q < rows) inv[row] = iv;
+    if (lane == 0 && row0 + wave * RPW + q < rows) inv[row] = iv;
     if (bound_inv) {
       const float yn = sqrtf(wave_sum(ysq)) * 1.001f;                 // 0.1 % head room for the fp32 roundings
       const float bg = yn * bound4[0] + bound4[1];
       const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
       float biv;
       h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
-      if (lane == 0 && row0 + wave * 4 + q < rows) bound_inv[row] = biv;
+      if (lane == 0 && row0 + wave * RPW + q < rows) bound_inv[row] = biv;
     }
   }
-  h2_store_rows<NV>(v, scale, tile, dim, row0, rows, out, R);
+  h2_store_rows<NV, RPW>(v, scale, tile, dim, row0, rows, out, R);
 }
 
 }  // namespace
@@ -662,14 +680,24 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
                  float* inv_scale, hipStream_t stream, const float* bound, float* bound_inv) {
   ANYLOC_CHECK_ARG(dim % 16 == 0 && dim <= 2048, "layernorm_h2: dim %d (needs a multiple of 16, at most 2048)", dim);
   ProfScope prof("layernorm_h2", stream, 8.0 * rows * dim, 8.0 * rows * dim);
-  const dim3 grid((unsigned)((rows + 15) / 16));
   unsigned char* out = static_cast<unsigned char*>(h2);
   const int nv = (dim / 4 + 63) / 64;
   f32x4 b4;                                                  // bound: HOST array of 4 floats (or null)
   for (int i = 0; i < 4; ++i) b4[i] = bound ? bound[i] : 0.0f;
-#define ANYLOC_LN_H2(NVV) \
-  hipLaunchKernelGGL(layernorm_h2_kernel<NVV>, grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, rows, \
-                     b4, bound ? bound_inv : nullptr)
+  // few rows (ANYLOC_LN_SMALL_ROWS, default 4096 = seven 322 x 322 images): one row per wave, four per block
+  const char* sr = getenv("ANYLOC_LN_SMALL_ROWS");          // read per call (tests flip it)
+  const int64_t small_rows = sr ? atoll(sr) : 4096;
+  const bool small = rows < small_rows;
+  const dim3 grid((unsigned)(small ? (rows + 3) / 4 : (rows + 15) / 16));
+#define ANYLOC_LN_H2(NVV)                                                                                                \
+  do {                                                                                                                   \
+    if (small)                                                                                                           \
+      hipLaunchKernelGGL((layernorm_h2_kernel<NVV, 1>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
+                         rows, b4, bound ? bound_inv : nullptr);                                                         \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((layernorm_h2_kernel<NVV, 4>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
+                         rows, b4, bound ? bound_inv : nullptr);                                                         \
+  } while (0)
   if (nv <= 1) ANYLOC_LN_H2(1);
   else if (nv <= 2) ANYLOC_LN_H2(2);
   else if (nv <= 3) ANYLOC_LN_H2(3);
@@ -689,17 +717,18 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
     const char* e = getenv("ANYLOC_H3_CFG");
     cfg = e ? atoi(e) : 0;
   }
-#define ANYLOC_LAUNCH_H3(MI, NI, WM, WN, ST, OCC)                                                                     \
+#define ANYLOC_LAUNCH_H3(MI, NI, WM, WN, ST, OCC) ANYLOC_LAUNCH_H3K(MI, NI, WM, WN, ST, OCC, 1)
+#define ANYLOC_LAUNCH_H3K(MI, NI, WM, WN, ST, OCC, KB)                                                                \
   do {                                                                                                                \
-    using Cfg = H3Cfg<MI, NI, WM, WN, ST>;                                                                            \
+    using Cfg = H3Cfg<MI, NI, WM, WN, ST, KB>;                                                                        \
     const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);         \
     static bool attr_set = false;                                                                                     \
     if (!attr_set) {                                                                                                  \
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI>),     \
+      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI, KB>), \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));                          \
       attr_set = true;                                                                                                \
     }                                                                                                                 \
-    hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI>), dim3((unsigned)(tiles_m * tiles_n)),            \
+    hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI, KB>), dim3((unsigned)(tiles_m * tiles_n)),        \
                        dim3(64 * WM * WN), Cfg::LDS, stream, p, tiles_m, tiles_n);                                    \
   } while (0)
   const bool small = ((p.M + 127) / 128) * ((p.N + 255) / 256) < 512;
@@ -712,7 +741,24 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
       const char* e = getenv("ANYLOC_H3_TINY_MAX");
       tiny_max = e ? atoll(e) : 256;
     }
+    // read per call: tests/test_gpu_vit.py flips them inside one process
+    const char* d = getenv("ANYLOC_H3_DEEP_MAX");
+    const char* d2 = getenv("ANYLOC_H3_DEEP2_MAX");
+    const int64_t deep_max = d ? atoll(d) : 320, deep2_max = d2 ? atoll(d2) : 500;
     if (((p.M + 127) / 128) * ((p.N + 127) / 128) < tiny_max) {
+      // fewer 64x64 tiles than ~1.25 per CU (ViT-g proj / fc2 of one image: 216): a workgroup is alone on its CU, nothing
+      // hides its per-k-block barrier and LDS round trip (measured 625 cycles per k-block for 192 cycles of MFMA), so
+      // the ring stage holds FOUR k-blocks -- one barrier and one counted wait per 64 k.  Same k order per output element:
+      // bitwise the result of the one-k-block kernel (ANYLOC_H3_DEEP_MAX=0 restores it).  B=1: fc2 80 -> 49 us, proj 36 -> 24 us
+      // per launch; with 320 ... 500 tiles (two images) two k-blocks per stage (profiles/r02_small_batch_kernels.log).
+      if (((p.M + 63) / 64) * ((p.N + 63) / 64) < deep_max) {
+        ANYLOC_LAUNCH_H3K(1, 2, 2, 1, 3, 2, 4);             // 64x64, 2 waves, 3 stages of 4 k-blocks (96 KiB)
+        return launch_status("gemm_h3_kernel");
+      }
+      if (((p.M + 63) / 64) * ((p.N + 63) / 64) < deep2_max) {
+        ANYLOC_LAUNCH_H3K(1, 2, 2, 1, 3, 2, 2);             // the same with 2 k-blocks per stage (48 KiB: three workgroups per CU)
+        return launch_status("gemm_h3_kernel");
+      }
       ANYLOC_LAUNCH_H3(1, 2, 2, 1, 3, 2);                   // 64x64, 2 waves
       return launch_status("gemm_h3_kernel");
     }
@@ -728,6 +774,7 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
     default: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 3, 2); break;
   }
 #undef ANYLOC_LAUNCH_H3
+#undef ANYLOC_LAUNCH_H3K
   return launch_status("gemm_h3_kernel");
 }
 

@@ -172,3 +172,23 @@ def test_hip_graph_replay_is_bit_equal(c1, monkeypatch):
         assert torch.equal(w, g)
     big = torch.cat([imgs[:6]]).to(DEV)          # above the threshold: plain launches, no new graph
     assert ext(big).shape[0] == 6 and ext.dino_model.graph_stats() == (graphs, replays)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_small_batch_kernels_are_bitwise_the_plain_ones(batch, monkeypatch):
+    """One or two images run 64x64 GEMM tiles with four / two k-blocks per ring stage (proj, fc2) and a LayerNorm with one
+    row per wave (csrc/gemm_h3.hip): scheduling changes only -- the tokens must equal, bit for bit, those of the kernels
+    with one k-block per stage and four rows per wave (ANYLOC_H3_DEEP_MAX=0 ANYLOC_H3_DEEP2_MAX=0 ANYLOC_LN_SMALL_ROWS=0)."""
+    import utilities
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device=DEV, depth=3))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
+        img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(batch)).to(DEV)
+        got = ext(img).clone()
+        for var in ("ANYLOC_H3_DEEP_MAX", "ANYLOC_H3_DEEP2_MAX", "ANYLOC_LN_SMALL_ROWS"):
+            monkeypatch.setenv(var, "0")
+        want = ext(img).clone()
+        assert torch.isfinite(got).all() and torch.equal(got, want)
+    finally:
+        weights.unregister_state_dict(name)
