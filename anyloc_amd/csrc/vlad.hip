@@ -212,13 +212,21 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
   sums[i] = s;
 }
 
-__global__ void reduce_counts_kernel(const unsigned* __restrict__ cnt_part, int64_t n_chunks, int K,
-                                     float* __restrict__ counts) {
-  const int k = threadIdx.x;
+// counts[k] = sum over chunks of cnt_part[chunk][k]: one wave per cluster, lane l takes chunks l, l + 64, ... (integer
+// sums: exact in any order), 64-lane butterfly.  (One thread per cluster walking the chunks serially took 158 us for 512
+// chunks -- 3 % of a 5 M-row step.)
+__global__ __launch_bounds__(64) void reduce_counts_kernel(const unsigned* __restrict__ cnt_part, int64_t n_chunks, int K,
+                                                           float* __restrict__ counts) {
+  const int k = blockIdx.x, lane = threadIdx.x;
   if (k >= K) return;
   unsigned long long t = 0;
-  for (int64_t ch = 0; ch < n_chunks; ++ch) t += cnt_part[ch * K + k];
-  counts[k] = (float)t;
+  for (int64_t ch = lane; ch < n_chunks; ch += 64) t += cnt_part[ch * K + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)t, o, 64), hi = __shfl_xor((unsigned)(t >> 32), o, 64);
+    t += ((unsigned long long)hi << 32) | lo;
+  }
+  if (lane == 0) counts[k] = (float)t;
 }
 
 // soft assignment weights: w[n,k] = softmax_k(temp * cos(x_n, c_k)),  F.cosine_similarity eps 1e-8:
@@ -724,7 +732,7 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
                          chunks, K * D, sums);
       ANYLOC_TRY(launch_status("reduce_chunks_kernel"));
     }
-    hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(256), 0, stream, cnt_part, chunks, (int)K, counts);
+    hipLaunchKernelGGL(reduce_counts_kernel, dim3((unsigned)K), dim3(64), 0, stream, cnt_part, chunks, (int)K, counts);
     return launch_status("reduce_counts_kernel");
   }
   ANYLOC_TRY(run_scores(x, n, D, w, K, mode == 1, stream, "kmeans_scores_gemm"));
@@ -755,7 +763,7 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
                        K * D, sums);
     ANYLOC_TRY(launch_status("reduce_chunks_kernel"));
   }
-  hipLaunchKernelGGL(reduce_counts_kernel, dim3(1), dim3(256), 0, stream, cnt_part, chunks, (int)K, counts);
+  hipLaunchKernelGGL(reduce_counts_kernel, dim3((unsigned)K), dim3(64), 0, stream, cnt_part, chunks, (int)K, counts);
   return launch_status("reduce_counts_kernel");
 }
 
