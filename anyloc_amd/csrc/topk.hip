@@ -154,9 +154,16 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
   };
 
   int64_t c0 = 0;
+  // block-uniform copy of n_s: read after the post-scatter barrier of a step, and nobody appends again before the
+  // pre-scatter barrier of the next step, which every thread reaches only after its own read -- so all threads take the
+  // same branch below (a decision made from n_s itself could see a faster wave's atomicAdd of the next step)
+  int n_now = 0;
   while (c0 < ncols) {
     const int step = (first && c0 == 0) ? BOOT : TILE;    // the first step only seeds the threshold
-    if (n_s + step > CAP) select();                       // n_s is uniform here: every path to this line ends in a barrier
+    if (n_now + step > CAP) {
+      select();
+      n_now = 0;
+    }
     const float tv = thr_v;
     const long long ti = thr_i;
     float v[TILE / 256];
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         if (metric) v[j] = -((qq + dn[c]) - 2.0f * v[j]);
       }
     }
+    __syncthreads();                                      // every thread has read n_s / the threshold of this step
 #pragma unroll
     for (int j = 0; j < TILE / 256; ++j) {
       const int64_t c = c0 + tid + 256 * j;
@@ -181,7 +189,12 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
       }
     }
     __syncthreads();
-    if (first && c0 == 0) select();                       // the seed columns become the first list: a real threshold from here on
+    if (first && c0 == 0) {
+      select();                                           // the seed columns become the first list: a real threshold from here on
+      n_now = 0;
+    } else {
+      n_now = n_s;
+    }
     c0 += step;
   }
   select();

@@ -9,6 +9,7 @@ Differences from the reference that do not change results:
     blocks + final norm + head and discards them);
   * batches ``B > 1`` are processed in one launch sequence.
 """
+import contextlib
 import ctypes as C
 import math
 
@@ -24,6 +25,11 @@ DEFAULT_GEMM = "h3"      # block-GEMM arithmetic when neither the constructor no
 _DINO_V2_MODELS = ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14", "dinov2_vitg14")
 _DINO_FACETS = ("query", "key", "value", "token")
 INTERP_OFFSET = 0.1
+
+
+def _on_device(device):
+    """Context that makes ``device`` the current HIP device (kernels launch on the current device and stream)."""
+    return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
 def _graph_max_rows():
@@ -191,7 +197,13 @@ class HipDinoV2:
 
     @torch.no_grad()
     def forward_taps(self, img, taps, use_cls=False, norm_taps=True, norm_concat=False):
-        """img [B,3,H,W] -> [B, N(+1), len(taps)*D]; taps = [(layer, facet_name), ...] ascending."""
+        """img [B,3,H,W] -> [B, N(+1), len(taps)*D]; taps = [(layer, facet_name), ...].  The kernels launch on the
+        CURRENT HIP device and stream, so the call runs with this model's device current (a caller that built the
+        extractor with device="cuda:N" need not have called torch.cuda.set_device(N))."""
+        with _on_device(self.device):
+            return self._forward_taps(img, taps, use_cls, norm_taps, norm_concat)
+
+    def _forward_taps(self, img, taps, use_cls, norm_taps, norm_concat):
         if img.ndim != 4 or img.shape[1] != 3:
             raise ValueError(f"expected an image batch [B,3,H,W], got {tuple(img.shape)}")
         B, _, H, W = img.shape
@@ -206,7 +218,7 @@ class HipDinoV2:
         if order != list(range(len(taps))):
             # ... and the caller gets its feature blocks in the order it asked for ("l n d -> n (l d)", reference
             # scripts/dino_v2_vlad_viz.py:175-196); every normalisation is invariant to the block order
-            res = self.forward_taps(img, [taps[i] for i in order], use_cls, norm_taps, norm_concat)
+            res = self._forward_taps(img, [taps[i] for i in order], use_cls, norm_taps, norm_concat)
             blocks = res.reshape(res.shape[0], res.shape[1], len(taps), self.dim)
             inv = [order.index(i) for i in range(len(taps))]
             return blocks[:, :, inv].reshape(res.shape[0], res.shape[1], -1).contiguous()
@@ -219,7 +231,7 @@ class HipDinoV2:
         chunk = max(1, self.max_rows // (np_ + 1))
         if self.gemm in ("x6", "h3") and B > chunk:
             for s0 in range(0, B, chunk):
-                out[s0:s0 + chunk] = self.forward_taps(img[s0:s0 + chunk], taps, use_cls, norm_taps, norm_concat)
+                out[s0:s0 + chunk] = self._forward_taps(img[s0:s0 + chunk], taps, use_cls, norm_taps, norm_concat)
             return out
         lib = _lib.load()
         ws_bytes = lib.anyloc_vit_workspace_bytes(self._handle, B, H, W)
@@ -281,16 +293,16 @@ class DinoV2ExtractFeatures:
             raise ValueError(f"facet must be one of {_DINO_FACETS}")
         self.vit_type: str = dino_model
         self.device = torch.device(device)
-        gpu = _lib.require_gpu()
-        if self.device.type == "cuda" and self.device.index is not None and self.device.index != gpu.index:
-            # kernels are launched on the CURRENT HIP device and stream (one process per GPU): weights on another
-            # device would be reached through peer access at best
-            raise ValueError(f"device {self.device} is not the current ROCm device ({gpu}); this library drives one GPU "
-                             f"per process -- call torch.cuda.set_device({self.device.index}) first")
-        self._gpu = gpu
+        cur = _lib.require_gpu()
+        # the reference accepts any device string (utilities.py:242 `.to(device)`): "cuda:N" selects GPU N for the weights
+        # and every later call, whatever the process' current device is ("cuda" / "cpu" = the current GPU; the model
+        # always lives on a GPU, CPU tensors are staged in and out)
+        pick = self.device.type == "cuda" and self.device.index is not None and cur.type == "cuda"
+        self._gpu = torch.device("cuda", self.device.index) if pick else cur
         self.layer: int = layer
         self.facet = facet
-        self.dino_model = HipDinoV2(dino_model, weights.resolve_state_dict(dino_model), gpu)
+        with _on_device(self._gpu):
+            self.dino_model = HipDinoV2(dino_model, weights.resolve_state_dict(dino_model), self._gpu)
         if not 0 <= layer < self.dino_model.depth:
             raise IndexError(f"layer {layer} outside [0, {self.dino_model.depth})")
         self.fh_handle = _NullHandle()

@@ -48,16 +48,24 @@ class KMeans:
             return ops._f32c(t, _lib.require_gpu())
         return t.to(torch.float32)
 
+    def _comm_device(self, like):
+        """Device the collectives of ``process_group`` move: the tensors' own GPU for RCCL (backend "nccl" rejects CPU
+        tensors), the host for a gloo group (CPU tests, single-GPU tests)."""
+        import torch.distributed as dist
+        if dist.get_backend(self.process_group) == "gloo":
+            return torch.device("cpu")
+        return like.device
+
     def _all_reduce(self, *tensors):
         """Sum over the ranks of ``process_group`` in place (RCCL; gloo groups are staged through the host, gloo has
         no device all-reduce for every dtype / build)."""
         if self.process_group is None:
             return
         import torch.distributed as dist
-        host = dist.get_backend(self.process_group) == "gloo"
         for t in tensors:
-            if host and t.is_cuda:
-                c = t.cpu()
+            comm = self._comm_device(t)
+            if comm != t.device:
+                c = t.to(comm)
                 dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.process_group)
                 t.copy_(c)
             else:
@@ -66,22 +74,25 @@ class KMeans:
     def _sharded_init(self, x):
         """Initial centroids of a row-sharded fit, identical to the flat fit on the concatenated rows: rank 0 draws
         ``np.random.choice(N_total, K, replace=False)`` from NumPy's global RNG (what fpk does on the whole array),
-        the draw is broadcast, every rank contributes the drawn rows it owns and the [K, D] table is all-reduced."""
+        the draw is broadcast, every rank contributes the drawn rows it owns and the [K, D] table is all-reduced.
+        Every tensor handed to a collective lives on the group's comm device (``_comm_device``)."""
         import torch.distributed as dist
         g = self.process_group
         world, rank = dist.get_world_size(g), dist.get_rank(g)
-        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64), group=g)
-        counts = [int(c) for c in counts]
+        comm = self._comm_device(x)
+        counts = torch.zeros(world, dtype=torch.int64, device=comm)
+        dist.all_gather_into_tensor(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=comm), group=g)
+        counts = [int(c) for c in counts.cpu()]
         n_total, off = sum(counts), sum(counts[:rank])
-        pick = torch.zeros(self.n_clusters, dtype=torch.int64)
+        pick = torch.zeros(self.n_clusters, dtype=torch.int64, device=comm)
         if rank == 0:
-            pick = torch.from_numpy(np.random.choice(n_total, size=[self.n_clusters], replace=False)).to(torch.int64)
+            pick = torch.from_numpy(np.random.choice(n_total, size=[self.n_clusters], replace=False)).to(torch.int64).to(comm)
         dist.broadcast(pick, src=dist.get_global_rank(g, 0) if g is not dist.group.WORLD else 0, group=g)
+        pick = pick.to(x.device)
         c = torch.zeros(self.n_clusters, x.shape[1], dtype=torch.float32, device=x.device)
         mine = (pick >= off) & (pick < off + x.shape[0])
         if bool(mine.any()):
-            c[mine.to(x.device)] = x[(pick[mine] - off).to(x.device)]
+            c[mine] = x[pick[mine] - off]
         self._all_reduce(c)
         return c
 

@@ -12,8 +12,9 @@ run on the fp32 MFMA GEMM of the library (``anyloc_gemm_nt``):
   eigendecomposition (float64, ``torch.linalg.eigh`` -- a dense-solver library call, not a kernel of this
   package) gives the singular values and one side of the SVD; for the Gram side the principal axes follow
   from one more GEMM, V^T = diag(1/s) U^T Xc.
-  Signs follow sklearn's ``svd_flip``: by default the convention of sklearn >= 1.5 (largest-magnitude entry of
-  every axis positive); ``sign_convention="u"`` gives the u-based rule of the sklearn versions the reference pins.
+  Signs follow sklearn's ``svd_flip``: by default the rule of the sklearn installed next to this package (what the
+  reference's own call would produce here): u-based (largest-magnitude entry of every U column positive) for the
+  versions the reference pins, v-based from sklearn 1.5 on; ``sign_convention="u"`` / ``"v"`` force one.
 * transform:  one GEMM with the bias epilogue,  X W^T - W mean,  W = components (/ sqrt(explained variance)
   when whitening) -- the order sklearn's ``_BasePCA._transform`` uses.
 
@@ -35,15 +36,31 @@ def _gemm(a, w, bias=None):
     return ops.gemm_nt(a, w, bias)
 
 
+def default_sign_convention():
+    """The ``svd_flip`` rule of the sklearn the reference would import here: u-based before 1.5 (incl. the pinned
+    0.24.2 / 1.0.2), v-based from 1.5 on; "u" when sklearn is not installed."""
+    try:
+        import sklearn
+        major, minor = (int(p) for p in sklearn.__version__.split(".")[:2])
+        return "v" if (major, minor) >= (1, 5) else "u"
+    except Exception:
+        return "u"
+
+
 class PCA:
-    def __init__(self, n_components: int, whiten: bool = False, precise: bool = True, sign_convention: str = "v"):
-        """``sign_convention``: which factor of the SVD fixes the sign of every axis -- "v" (default): the
-        largest-magnitude entry of each principal axis is positive, sklearn >= 1.5 (``svd_flip(u, vt,
-        u_based_decision=False)``; the version installed next to this package); "u": the largest-magnitude entry of each
-        column of U is positive, sklearn < 1.5 incl. the 0.24.2 / 1.0.2 the reference pins.  Projected coordinates differ
-        by a per-axis sign between the two; retrieval is unaffected, element-wise comparison of dumps is not."""
+    def __init__(self, n_components: int, whiten: bool = False, precise: bool = True, sign_convention: str = "auto"):
+        """``sign_convention``: which factor of the SVD fixes the sign of every axis -- "u": the largest-magnitude entry
+        of each column of U is positive, the ``svd_flip`` of sklearn < 1.5 incl. the 0.24.2 / 1.0.2 the reference pins
+        (``setup_conda.sh:234``); "v": the largest-magnitude entry of each principal axis is positive, sklearn >= 1.5
+        (``svd_flip(u, vt, u_based_decision=False)``); "auto" (default): what the reference's own
+        ``sklearn.decomposition.PCA`` call would do in THIS environment -- the rule of the installed sklearn, "u" when
+        none is installed -- so dumps compare element-wise with the reference run side by side, in its pinned
+        environment as well as in a current one.  Projected coordinates differ by a per-axis sign between the two rules;
+        retrieval is unaffected."""
+        if sign_convention == "auto":
+            sign_convention = default_sign_convention()
         if sign_convention not in ("v", "u"):
-            raise ValueError("sign_convention must be 'v' or 'u'")
+            raise ValueError("sign_convention must be 'auto', 'v' or 'u'")
         self.sign_convention = sign_convention
         self.n_components = int(n_components)
         self.whiten = bool(whiten)
@@ -53,12 +70,6 @@ class PCA:
         # torch.matmul -- a plain library GEMM -- which brings the fit to the accuracy of the reference's float32
         # LAPACK SVD or better; precise=False keeps everything on the fp32 MFMA kernel (fine for leading axes).
         self.precise = bool(precise)
-
-    def _self_product(self, m):
-        if self.precise:
-            m = m.double()
-            return m @ m.t()
-        return _gemm(m, m)
 
     # ---------------------------------------------------------------- fit ----
     def fit(self, X):
@@ -71,30 +82,45 @@ class PCA:
         if not 1 <= k <= min(n, f):
             raise ValueError(f"n_components={k} must be between 1 and min(n_samples, n_features)={min(n, f)} "
                              f"with svd_solver='full'")
-        self.mean_ = X.mean(dim=0, dtype=torch.float64).to(torch.float32)
+        mean64 = X.mean(dim=0, dtype=torch.float64)
+        self.mean_ = mean64.to(torch.float32)
         xc = X - self.mean_
+        # precise: centre, form the symmetric matrix and back-project in float64 (library GEMMs); the fp32 copy `xc` is
+        # then only used for the sign rule
+        xw = (X.double() - mean64) if self.precise else xc
         if n <= f:
-            gram = self._self_product(xc)                                    # [n, n] = Xc Xc^T
+            gram = xw @ xw.t() if self.precise else _gemm(xc, xc)            # [n, n] = Xc Xc^T
             lam, vec = self._eigh_desc(gram)
             s = lam.clamp_min(0).sqrt()
             if self.precise:
-                axes = (vec[:, :k].t() @ xc.double()) / s[:k].clamp_min(1e-300)[:, None]      # [k, f] = U^T Xc / s
+                axes = (vec[:, :k].t() @ xw) / s[:k].clamp_min(1e-300)[:, None]               # [k, f] = U^T Xc / s
                 axes = axes.to(torch.float32)
             else:
                 u_t = vec[:, :k].t().to(torch.float32).contiguous()            # [k, n]
                 axes = _gemm(u_t, xc.t().contiguous())
                 axes = axes / s[:k].to(torch.float32).clamp_min(torch.finfo(torch.float32).tiny)[:, None]
         else:
-            xt = xc.t().contiguous()
-            scatter = self._self_product(xt)                              # [f, f] = Xc^T Xc
+            if self.precise:
+                scatter = xw.t() @ xw                                      # [f, f] = Xc^T Xc
+            else:
+                xt = xc.t().contiguous()
+                scatter = _gemm(xt, xt)
             lam, vec = self._eigh_desc(scatter)
             s = lam.clamp_min(0).sqrt()
             axes = vec[:, :k].t().to(torch.float32).contiguous()
+        del xw
         # axes of (numerically) zero variance -- rank-deficient data, e.g. n_components == n_samples after centring -- carry
         # no direction: U^T Xc / s would divide noise by ~0.  They are set to zero (every projection onto them is 0,
         # also under whitening) instead of being blown up to inf / NaN.
-        # (threshold: the singular values rounding noise of the fp32 data itself reaches, ~ eps32 * sqrt(max(n, f)) * s_0)
-        dead = s[:k] <= s[0] * 4.0 * float(max(n, f)) ** 0.5 * torch.finfo(torch.float32).eps
+        # Threshold = the singular values the decomposition's own rounding noise reaches.  `precise`: the symmetric matrix is
+        # formed and decomposed in float64, its eigenvalues are good to ~ max(n, f) eps64 lambda_0, i.e. singular values to
+        # sqrt(4 max(n, f) eps64) s_0 ~ 1e-6 s_0 (the Gram route squares the condition number) -- small but real components
+        # of the data above that are kept, as sklearn keeps them.  All-fp32 path: eps32 sqrt(max(n, f)) s_0 of the fp32 data.
+        big = float(max(n, f))
+        if self.precise:
+            dead = s[:k] <= s[0] * (4.0 * big * torch.finfo(torch.float64).eps) ** 0.5
+        else:
+            dead = s[:k] <= s[0] * 4.0 * big ** 0.5 * torch.finfo(torch.float32).eps
         axes = torch.where(dead[:, None].to(axes.device), torch.zeros_like(axes), axes)
         # unit length in fp32 (the GEMM above leaves ~1e-7 of drift) and sklearn's sign rule
         axes = torch.nn.functional.normalize(axes, dim=1)
@@ -147,7 +173,7 @@ class PCA:
         return self.fit(X).transform(X)
 
 
-def joint_pca_project(db_descs, qu_descs, lower_dim: int = 512, whiten: bool = False, sign_convention: str = "v"):
+def joint_pca_project(db_descs, qu_descs, lower_dim: int = 512, whiten: bool = False, sign_convention: str = "auto"):
     """Joint PCA projection of several datasets' global descriptors (reference ``scripts/joint_pca_project.py:62-101``):
     ONE PCA is fitted on the concatenation of all database descriptor sets, and every database / query set is projected
     with it.  ``db_descs`` / ``qu_descs``: lists of [n_i, f] tensors (or arrays), one entry per dataset, as the script

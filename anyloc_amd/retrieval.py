@@ -86,6 +86,39 @@ def merge_shard_topk(dists, idxs, k, metric="ip"):
     return np.take_along_axis(d, order, 1), np.take_along_axis(i, order, 1)
 
 
+def comm_device(group, like):
+    """Device whose tensors the collectives of ``group`` move: the GPU for RCCL (backend "nccl" rejects CPU tensors),
+    the host for gloo."""
+    import torch.distributed as dist
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device(like)
+
+
+def gather_rows(local, counts, rank, group, comm):
+    """All-gather of row blocks [counts[r], D] into ONE [sum(counts), D] buffer on ``comm`` without padded or
+    per-rank staging copies: equal shares are a single ``all_gather_into_tensor`` straight into the result; uneven
+    shares (Q % world != 0) are one broadcast per rank into that rank's row range of the result (same bytes on the wire
+    as the all-gather; the only copy is each rank's own share into its slot)."""
+    import torch.distributed as dist
+    world = len(counts)
+    total = sum(counts)
+    out = torch.empty(total, local.shape[1], dtype=torch.float32, device=comm)
+    src = local.to(comm, torch.float32).contiguous()
+    if len(set(counts)) == 1:
+        if total:
+            dist.all_gather_into_tensor(out, src, group=group)
+        return out
+    off = 0
+    for r in range(world):
+        view = out[off:off + counts[r]]
+        if r == rank:
+            view.copy_(src)
+        if counts[r]:
+            dist.broadcast(view, src=r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r),
+                           group=group)
+        off += counts[r]
+    return out
+
+
 def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_descs=True,
                    group=None, search_fn=None):
     """Database-sharded retrieval, one process per GPU.
@@ -101,16 +134,13 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     # RCCL moves device tensors over xGMI; a gloo group (CPU tests, single-GPU tests) is staged through the host
-    comm = torch.device("cpu") if dist.get_backend(group) == "gloo" else qu_local.device
-    counts = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([qu_local.shape[0]], dtype=torch.int64, device=comm), group=group)
-    counts = [int(c) for c in counts]
-    mx = max(counts)
-    padded = torch.zeros(mx, qu_local.shape[1], dtype=torch.float32, device=comm)
-    padded[:qu_local.shape[0]] = qu_local.to(comm)
-    gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded, group=group)
-    qu_all = torch.cat([g[:c] for g, c in zip(gathered, counts)], 0).to(qu_local.device)
+    comm = comm_device(group, qu_local.device)
+    counts = torch.zeros(world, dtype=torch.int64, device=comm)
+    dist.all_gather_into_tensor(counts, torch.tensor([qu_local.shape[0]], dtype=torch.int64, device=comm), group=group)
+    counts = [int(c) for c in counts.cpu()]
+    qu_all = gather_rows(qu_local, counts, rank, group, comm)
+    if qu_all.device != qu_local.device:
+        qu_all = qu_all.to(qu_local.device)
     if search_fn is None:
         d, i = search(db_shard, qu_all, k, method, norm_descs)
         i = torch.where(i >= 0, i + shard_base, i)

@@ -14,8 +14,10 @@ import torch
 from . import _lib, ops
 from .kmeans import KMeans
 
-# compact <id>_r.pt: {"format": LAZY_FORMAT, "tokens": normalised tokens [N,D], "num_clusters": K}; the [N,K,D] residual
-# tensor of the reference is tokens[:, None, :] - c_centers[None] and is only formed when generate_res_vec is asked for it
+# compact <id>_t.pt (opt-in, cache_format = "lazy"): {"format": LAZY_FORMAT, "tokens": normalised tokens [N,D],
+# "num_clusters": K}; the [N,K,D] residual tensor of the reference is tokens[:, None, :] - c_centers[None] and is only
+# formed when generate_res_vec is asked for it.  It lives in its OWN file name so that a reference-side reader, which
+# does torch.load(<id>_r.pt) and indexes it as a dense tensor (utilities.py:843-847, 951-954), never opens it.
 LAZY_FORMAT = "anyloc_amd.lazy_residuals.v1"
 
 
@@ -49,8 +51,12 @@ class VLAD:
         self.c_centers = None
         self.kmeans = None
         # Set the caching
-        # "lazy" (default; ANYLOC_CACHE_FORMAT) or "reference": how <id>_r.pt is WRITTEN; both are read
-        self.cache_format = os.environ.get("ANYLOC_CACHE_FORMAT", "lazy")
+        # how residual caches are WRITTEN: "reference" (default) = the reference's dense [N,K,D] tensor in <id>_r.pt,
+        # byte-compatible with reference-side readers; "lazy" (opt-in, also ANYLOC_CACHE_FORMAT=lazy) = the compact
+        # token file <id>_t.pt (3.25 MB instead of 104 MB per image at the headline shape).  Both are READ.
+        self.cache_format = os.environ.get("ANYLOC_CACHE_FORMAT", "reference")
+        if self.cache_format not in ("reference", "lazy"):
+            raise ValueError(f"ANYLOC_CACHE_FORMAT must be 'reference' or 'lazy', got {self.cache_format!r}")
         self.cache_dir = cache_dir
         if self.cache_dir is not None:
             self.cache_dir = os.path.abspath(os.path.expanduser(self.cache_dir))
@@ -73,7 +79,7 @@ class VLAD:
 
     def can_use_cache_ids(self, cache_ids: Union[List[str], str, None],
                           only_residuals: bool = False) -> bool:
-        """True iff every cache id has ``<id>_r.pt`` and (unless
+        """True iff every cache id has ``<id>_r.pt`` (or this package's compact ``<id>_t.pt``) and (unless
         ``only_residuals``) ``<id>_l.pt`` (hard) / ``<id>_s.pt`` (soft)."""
         if not self.can_use_cache_vlad():
             return False
@@ -82,7 +88,7 @@ class VLAD:
         if isinstance(cache_ids, str):
             cache_ids = [cache_ids]
         for cache_id in cache_ids:
-            if not os.path.exists(f"{self.cache_dir}/{cache_id}_r.pt"):
+            if self._residual_file(cache_id) is None:
                 return False
             if self.vlad_mode == "hard" and not os.path.exists(
                     f"{self.cache_dir}/{cache_id}_l.pt") and not only_residuals:
@@ -154,9 +160,19 @@ class VLAD:
         base = f"{self.cache_dir}/{cache_id}"
         return base + "_r.pt", base + "_l.pt", base + "_s.pt"
 
+    def _residual_file(self, cache_id):
+        """Path of the residual cache of ``cache_id``: the reference's ``<id>_r.pt`` first, else the compact
+        ``<id>_t.pt``; None when neither exists."""
+        for suffix in ("_r.pt", "_t.pt"):
+            path = f"{self.cache_dir}/{cache_id}{suffix}"
+            if os.path.isfile(path):
+                return path
+        return None
+
     def _load_residual_file(self, r_path):
-        """``<id>_r.pt`` -> ("lazy", normalised tokens [N,D]) for the compact format this class writes, or
-        ("dense", residual tensor [N,K,D]) for a file written by the reference itself (utilities.py:963-970)."""
+        """residual cache file -> ("lazy", normalised tokens [N,D]) for the compact format (``<id>_t.pt``; round-2
+        builds wrote the same dict under ``<id>_r.pt``), or ("dense", residual tensor [N,K,D]) for the reference's
+        own format (utilities.py:963-970)."""
         obj = torch.load(r_path)
         if isinstance(obj, dict) and obj.get("format") == LAZY_FORMAT:
             return "lazy", obj["tokens"]
@@ -168,8 +184,8 @@ class VLAD:
         ``ops.vlad_assigned`` sums ``token - centre`` under the cached labels / soft weights.  A dense ``_r`` file
         written by the reference is honoured too: only the slice ``residuals[n, label_n]`` of every token is read
         (hard), i.e. N*D of its N*K*D values."""
-        r_path, l_path, s_path = self._cached_paths(cache_id)
-        kind, data = self._load_residual_file(r_path)
+        _, l_path, s_path = self._cached_paths(cache_id)
+        kind, data = self._load_residual_file(self._residual_file(cache_id))
         K, D = self.num_clusters, self.desc_dim
         c = self._centers_dev()
         if self.vlad_mode == "hard":
@@ -193,8 +209,8 @@ class VLAD:
                 # so all N*K*D stored values are needed; reduced once over the cluster axis on the host, the rest on the
                 # device (interchange path for files the reference wrote, not the hot path)
                 dev = _lib.require_gpu()
-                r_sum = data.to(torch.float32).sum(1).to(dev)                           # [N,D]
-                un = (soft.to(dev).t() @ r_sum)
+                r_sum = data.to(dev).sum(1, dtype=torch.float64)                        # [N,D]
+                un = (soft.to(dev).double().t() @ r_sum).to(torch.float32)
                 if self.intra_norm:
                     un = ops.l2norm_rows(un)
                 out = ops.l2norm_rows(un.reshape(1, K * D))[0]
@@ -202,9 +218,9 @@ class VLAD:
 
     def _write_cache(self, cache_id, descs_home):
         """Store what a later cache hit needs (reference utilities.py:850-852, :876-878, :963-970): ``_r`` + ``_l``
-        (hard) / ``_s`` (soft).  ``_r`` is written in the compact lazy format -- the normalised tokens [N,D], from which
-        ``residual[n,k] = token[n] - c_centers[k]`` is recomputed on demand, 3.25 MB instead of 104 MB per image at the
-        headline shape -- unless ``cache_format == "reference"`` asks for the reference's dense [N,K,D] tensor."""
+        (hard) / ``_s`` (soft).  By default ``_r`` is the reference's dense [N,K,D] tensor (written by the HIP residual
+        kernel); ``cache_format == "lazy"`` writes the compact ``_t`` file instead -- the normalised tokens [N,D], from
+        which ``residual[n,k] = token[n] - c_centers[k]`` is recomputed on demand."""
         r_path, l_path, s_path = self._cached_paths(cache_id)
         cid_dir = f"{self.cache_dir}/" f"{os.path.split(cache_id)[0]}"
         if not os.path.isdir(cid_dir):
@@ -213,20 +229,22 @@ class VLAD:
         dev = _lib.require_gpu()
         x = ops._f32c(descs_home, dev)
         c = self._centers_dev()
-        if not os.path.isfile(r_path):
-            self._save_residuals(x, r_path)
+        if self._residual_file(cache_id) is None:
+            self._save_residuals(x, cache_id)
         if self.vlad_mode == "hard":
             if not os.path.isfile(l_path):
                 torch.save(self.kmeans.predict(x).cpu(), l_path)
         elif not os.path.isfile(s_path):
             torch.save(ops.vlad_soft_weights(x, c, self.soft_temp).cpu(), s_path)
 
-    def _save_residuals(self, x_dev, r_path):
+    def _save_residuals(self, x_dev, cache_id):
         if self.cache_format == "reference":
-            torch.save(ops.vlad_residuals(x_dev, self._centers_dev(), self.norm_descs).cpu(), r_path)
+            torch.save(ops.vlad_residuals(x_dev, self._centers_dev(), self.norm_descs).cpu(),
+                       f"{self.cache_dir}/{cache_id}_r.pt")
         else:
             xh = ops.l2norm_rows(x_dev) if self.norm_descs else x_dev
-            torch.save({"format": LAZY_FORMAT, "tokens": xh.cpu(), "num_clusters": self.num_clusters}, r_path)
+            torch.save({"format": LAZY_FORMAT, "tokens": xh.cpu(), "num_clusters": self.num_clusters},
+                       f"{self.cache_dir}/{cache_id}_t.pt")
 
     def _generate_batch(self, multi_query):
         """[n_img,N,D] tensor or list of [N_i,D] -> [n_img, K*D] on the inputs' device."""
@@ -247,8 +265,7 @@ class VLAD:
         if self.desc_dim is None:
             self.desc_dim = self.c_centers.shape[1]
         if cache_id is not None and self.can_use_cache_vlad():
-            r_path, _, _ = self._cached_paths(cache_id)
-            if os.path.isfile(r_path):
+            if self._residual_file(cache_id) is not None:
                 res = self._from_cache(cache_id)
                 if res is not None:
                     return res
@@ -283,12 +300,11 @@ class VLAD:
                          cache_id: Union[str, None] = None) -> torch.Tensor:
         """Residual tensor [n_q, n_c, d] = normalise(q)[:,None,:] - c_centers[None] (reference
         utilities.py:928-972).  The VLAD path of this class never forms it; this method does, on request, with the
-        HIP kernel behind ``ops.vlad_residuals`` (a pure HBM write).  A cached ``<id>_r.pt`` is honoured in both
-        formats; a new cache entry is written in the compact format (see ``_write_cache``)."""
+        HIP kernel behind ``ops.vlad_residuals`` (a pure HBM write).  A cached ``<id>_r.pt`` / ``<id>_t.pt`` is honoured;
+        a new cache entry is written in ``cache_format`` (see ``_write_cache``)."""
         self._check_fitted()
-        if cache_id is not None and self.can_use_cache_vlad() and \
-                os.path.isfile(f"{self.cache_dir}/{cache_id}_r.pt"):
-            kind, data = self._load_residual_file(f"{self.cache_dir}/{cache_id}_r.pt")
+        if cache_id is not None and self.can_use_cache_vlad() and self._residual_file(cache_id) is not None:
+            kind, data = self._load_residual_file(self._residual_file(cache_id))
             if kind == "dense":
                 return data
             return ops.vlad_residuals(data, self._centers_dev(), norm_descs=False).to(data.device)
@@ -302,7 +318,7 @@ class VLAD:
             if not os.path.isdir(cid_dir):
                 os.makedirs(cid_dir)
                 print(f"Created directory: {cid_dir}")
-            self._save_residuals(x, f"{self.cache_dir}/{cache_id}_r.pt")
+            self._save_residuals(x, cache_id)
         return residuals
 
     def generate_multi_res_vec(self, multi_query: Union[np.ndarray, torch.Tensor, list],

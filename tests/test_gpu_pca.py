@@ -115,7 +115,8 @@ def test_pca_u_based_sign_rule_and_rank_deficient_axes():
     want = (vt * sign_u[:, None])[:12]
     ours = pca.PCA(12, sign_convention="u").fit(x.to(DEV))
     assert float((ours.components_.cpu().double() - want).abs().max()) < 2e-5
-    v_rule = pca.PCA(12).fit(x.to(DEV)).components_.cpu()
+    assert pca.PCA(12).sign_convention == pca.default_sign_convention()               # "auto": the installed sklearn's rule
+    v_rule = pca.PCA(12, sign_convention="v").fit(x.to(DEV)).components_.cpu()
     assert float((v_rule.abs() - ours.components_.cpu().abs()).abs().max()) < 2e-5   # same axes up to sign
     full = pca.PCA(40, whiten=True).fit(x.to(DEV))                                     # rank 39 after centring
     z = full.transform(x.to(DEV))

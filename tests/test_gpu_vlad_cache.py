@@ -1,8 +1,9 @@
 """VLAD residual / cache surface on the HIP kernels (GPU box): ``generate_res_vec`` / ``generate_multi_res_vec``
 (reference utilities.py:928-1008), ``fit_and_generate`` (:793-817) and the ``cache_dir`` protocol of ``generate``
-(:843-852, :864-878: ``<id>_r.pt`` + ``<id>_l.pt`` / ``<id>_s.pt``) against the CPU oracle.  The cache is written in the
-compact lazy format (normalised tokens; the [N,K,D] residual tensor is never stored or rebuilt on a hit) and a dense
-cache written the way the reference writes it is honoured as well."""
+(:843-852, :864-878: ``<id>_r.pt`` + ``<id>_l.pt`` / ``<id>_s.pt``) against the CPU oracle.  By default the cache is
+written the way the reference writes it (dense [N,K,D] ``<id>_r.pt``, readable by the reference's own indexing); the
+opt-in compact format (``cache_format = "lazy"``: normalised tokens in ``<id>_t.pt``, the residual tensor is never stored
+or rebuilt on a hit) lives under its own file name so a reference-side reader never opens it."""
 import os
 
 import numpy as np
@@ -54,14 +55,17 @@ def test_generate_res_vec_vs_reference_expression(K, D, N):
     assert l2rel(v.generate(x[0]), vl) < VLAD_RTOL
 
 
+@pytest.mark.parametrize("fmt", ["reference", "lazy"])
 @pytest.mark.parametrize("mode", ["hard", "soft"])
-def test_cache_dir_round_trip_without_residual_tensor(tmp_path, mode):
+def test_cache_dir_round_trip(tmp_path, mode, fmt):
     K, D, N = (32, 1536, 529) if mode == "hard" else (8, 384, 200)
     cache = str(tmp_path / "cache")
     v, centers = _fitted(K, D, mode, cache_dir=None)
     x = synth.clustered_tokens(3, N, D, n_modes=K, seed=9)
     direct = v.generate_multi(x)
     vc, _ = _fitted(K, D, mode, cache_dir=cache)
+    assert vc.cache_format == "reference"                                # the default is the reference's own file format
+    vc.cache_format = fmt
     torch.save(centers, f"{cache}/c_centers.pt")                         # what VLAD.fit leaves behind (utilities.py:788-791)
     assert vc.can_use_cache_vlad()
     ids = [f"db/img{i}" for i in range(3)]
@@ -69,10 +73,17 @@ def test_cache_dir_round_trip_without_residual_tensor(tmp_path, mode):
     first = vc.generate_multi(x, ids)                                    # miss: computes and writes _r + _l / _s
     assert l2rel(first, direct) < 1e-6
     assert vc.can_use_cache_ids(ids)
-    # the residual file is the compact one: normalised tokens, K times smaller than the reference's tensor
-    r_obj = torch.load(f"{cache}/{ids[0]}_r.pt")
-    assert isinstance(r_obj, dict) and tuple(r_obj["tokens"].shape) == (N, D)
-    assert os.path.getsize(f"{cache}/{ids[0]}_r.pt") < 1.1 * N * D * 4 + 4096
+    if fmt == "lazy":
+        # the compact file: normalised tokens, K times smaller than the reference's tensor, and NOT named <id>_r.pt
+        assert not os.path.exists(f"{cache}/{ids[0]}_r.pt")
+        r_obj = torch.load(f"{cache}/{ids[0]}_t.pt")
+        assert isinstance(r_obj, dict) and tuple(r_obj["tokens"].shape) == (N, D)
+        assert os.path.getsize(f"{cache}/{ids[0]}_t.pt") < 1.1 * N * D * 4 + 4096
+    else:
+        # what a reference-side reader does with the file (utilities.py:843-847): torch.load + residuals[labels == k, k]
+        r_obj = torch.load(f"{cache}/{ids[0]}_r.pt")
+        assert torch.is_tensor(r_obj) and tuple(r_obj.shape) == (N, K, D) and not os.path.exists(f"{cache}/{ids[0]}_t.pt")
+        assert float((r_obj - (torch.nn.functional.normalize(x[0])[:, None, :] - centers[None])).abs().max()) < 2e-7
     side = torch.load(f"{cache}/{ids[0]}_{'l' if mode == 'hard' else 's'}.pt")
     if mode == "hard":
         assert torch.equal(side, vlad_ref.hard_labels(x[0], centers))
@@ -83,7 +94,7 @@ def test_cache_dir_round_trip_without_residual_tensor(tmp_path, mode):
         ref = (vlad_ref.vlad_hard if mode == "hard" else lambda t, c: vlad_ref.vlad_soft(t, c, 1.0))(x[i], centers)[0]
         assert l2rel(hit[i], ref) < VLAD_RTOL
         assert l2rel(hit[i], direct[i]) < 2e-6
-    # generate_res_vec on a hit rebuilds the tensor from the compact file
+    # generate_res_vec on a hit: the stored tensor, or rebuilt from the compact file
     res = vc.generate_res_vec(None, ids[1])
     assert float((res - (torch.nn.functional.normalize(x[1])[:, None, :] - centers[None])).abs().max()) < 2e-7
 
@@ -101,7 +112,7 @@ def test_dense_cache_written_like_the_reference_is_honoured(tmp_path):
     out = v.generate(None, "q0")
     assert l2rel(out, vlad_ref.vlad_hard(x, centers)[0]) < VLAD_RTOL
     assert torch.equal(v.generate_res_vec(None, "q0"), torch.load(f"{cache}/q0_r.pt"))
-    v.cache_format = "reference"
+    assert v.cache_format == "reference"
     v.generate(x, "q1")
     dense = torch.load(f"{cache}/q1_r.pt")
     assert torch.is_tensor(dense) and tuple(dense.shape) == (N, K, D)
@@ -110,7 +121,7 @@ def test_dense_cache_written_like_the_reference_is_honoured(tmp_path):
     vs, _ = _fitted(K, D, "soft", cache_dir=cache)
     w = vlad_ref.vlad_soft(x, centers, 1.0)[1]
     torch.save(w, f"{cache}/q0_s.pt")
-    assert l2rel(vs.generate(None, "q0"), vlad_ref.vlad_soft(x, centers, 1.0)[0]) < 5e-5
+    assert l2rel(vs.generate(None, "q0"), vlad_ref.vlad_soft(x, centers, 1.0)[0]) < VLAD_RTOL
 
 
 def test_fit_and_generate_and_assigned_kernel(tmp_path):
@@ -122,8 +133,18 @@ def test_fit_and_generate_and_assigned_kernel(tmp_path):
     v = utilities.VLAD(K, None, cache_dir=None)
     out = v.fit_and_generate(x)                                           # utilities.py:793-817
     assert tuple(out.shape) == (6, K * D) and v.desc_dim == D
+    # north-star bar on every image; an image may exceed it only through a PROVEN tie: a cluster id that differs from the
+    # oracle's at an oracle top-2 cosine gap below fp32 resolution (then the oracle VLAD under the kernel's ids must match)
+    _, lab_all = ops.vlad(x.to(DEV), v.c_centers.to(DEV), return_labels=True)
+    lab_all = lab_all.cpu().reshape(6, N)
     for i in range(6):
-        assert l2rel(out[i], vlad_ref.vlad_hard(x[i], v.c_centers)[0]) < 1e-4      # (label ties aside)
+        lab_ref = vlad_ref.hard_labels(x[i], v.c_centers)
+        if torch.equal(lab_all[i], lab_ref):
+            assert l2rel(out[i], vlad_ref.vlad_hard(x[i], v.c_centers)[0]) < VLAD_RTOL
+        else:
+            sc = vlad_ref.fpk_cosine_scores(x[i][lab_all[i] != lab_ref], v.c_centers).topk(2, dim=1)[0]
+            assert float((sc[:, 0] - sc[:, 1]).max()) < 1e-6
+            assert l2rel(out[i], vlad_ref.vlad_hard(x[i], v.c_centers, labels=lab_all[i])[0]) < VLAD_RTOL
     # ops.vlad_assigned == ops.vlad when fed the labels ops.vlad chose itself
     c = v.c_centers.to(DEV)
     full, lab = ops.vlad(x[:1].to(DEV), c, return_labels=True)
