@@ -54,6 +54,9 @@ class VitBlockH2(C.Structure):
 SIGNATURES = {
     "anyloc_version": (C.c_int, []),
     "anyloc_last_error": (C.c_char_p, []),
+    "anyloc_set_option": (C.c_int, [C.c_char_p, c_i64]),
+    "anyloc_get_option": (C.c_int, [C.c_char_p, C.POINTER(c_i64)]),
+    "anyloc_reset_options": (C.c_int, []),
     "anyloc_l2norm_rows": (C.c_int, [c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),
     "anyloc_preprocess_u8": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(C.c_float),
                                        C.POINTER(C.c_float), c_f32p, C.c_void_p]),
@@ -98,7 +101,6 @@ SIGNATURES = {
     "anyloc_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_f32p, C.c_int32,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint, c_f32p,
                                      C.c_void_p, c_sz, C.c_void_p]),
-    "anyloc_vit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "anyloc_profile_enable": (C.c_int, [C.c_int]),
     "anyloc_profile_reset": (C.c_int, []),
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),

@@ -681,188 +681,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   }
 }
 
-// Software-pipelined variant (ANYLOC_ATTN_H3_CFG=2): the score MFMAs of key tile t + 1 are issued BEFORE the softmax of tile t,
-// so inside one wave the matrix cores work on S(t+1) while the VALU does exp / split of P(t) (in the kernel above the chain
-// S -> softmax -> PV leaves one of the two pipes idle at any time; only other waves fill the gaps).  Needs K(t+1) and V(t)
-// in LDS at once: a 3-stage ring, the DMA of tile t + 2 issued at the top of iteration t.  Four waves of 32 queries.
-__global__ __launch_bounds__(256, 2) void attention_h3p_kernel(const unsigned char* __restrict__ planes,
-                                                               const float* __restrict__ inv, int T, int heads, int64_t G,
-                                                               unsigned char* __restrict__ out2, float* __restrict__ out_inv,
-                                                               int64_t R) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];   // 3 stages + 16 bytes
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y;
-  const int64_t b = blockIdx.z;
-  const int64_t r0 = b * T, r1 = r0 + T;
-  const int64_t g_first = r0 >> 5, g_last = (r1 - 1) >> 5;
-  const int ng = (int)(g_last - g_first + 1);
-  const int64_t gq0 = g_first + blockIdx.x * 4 + wave;
-  const bool wave_active = gq0 <= g_last;
-  const int ql = lane & 31, h2 = lane >> 5;
-  const int64_t tile_bytes = 8192;
-
-  float fm = 0.f;
-  for (int i = tid; i < heads * ng; i += 256) {
-    const int hh = i / ng, gg = i - hh * ng;
-    fm = fmaxf(fm, inv[((int64_t)2 * heads + hh) * G + g_first + gg]);
-  }
-  fm = wave_max(fm);
-  float* red = reinterpret_cast<float*>(ah_smem + 3 * AH_STAGE);
-  if (lane == 0) red[wave] = fm;
-  __syncthreads();
-  fm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-
-  attn_u32x4 qf[2][4];
-  const int64_t gq = min(gq0, g_last);
-  const float fq = inv[((int64_t)h) * G + gq];
-  {
-    const unsigned char* qb = planes + (((int64_t)h) * G + gq) * tile_bytes + ql * 128;
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        qf[pl][s] = *reinterpret_cast<const attn_u32x4*>(qb + pl * 4096 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
-  }
-  const int64_t part_bytes = (int64_t)heads * G * tile_bytes;
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(planes + part_bytes), 0, (int)part_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(planes + 2 * part_bytes), 0, (int)part_bytes, 0x00020000);
-  const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
-  auto issue = [&](int t, int stage) {
-    const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
-    unsigned char* st = ah_smem + stage * AH_STAGE + wave * 1024;
-    dma16_to_lds(k_rsrc, st, voff, soff);
-    dma16_to_lds(k_rsrc, st + 4096, voff + 4096, soff);
-    dma16_to_lds(v_rsrc, st + 8192, voff, soff);
-    dma16_to_lds(v_rsrc, st + 12288, voff + 4096, soff);
-  };
-  float fk_lane = 1.0f, fv_lane = 1.0f;
-  if (lane < ng) {
-    fk_lane = inv[((int64_t)heads + h) * G + g_first + lane];
-    fv_lane = inv[((int64_t)2 * heads + h) * G + g_first + lane];
-  }
-  auto scores = [&](int stage, f32x16& sacc) {            // S^T = K_tile Q^T, raw (unscaled) accumulators
-    const unsigned char* Ks = ah_smem + stage * AH_STAGE;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      attn_u32x4 kf[2];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
-      sacc = ANYLOC_MFMA_F16(kf[1], qf[0][s], sacc);
-      sacc = ANYLOC_MFMA_F16(kf[0], qf[1][s], sacc);
-      sacc = ANYLOC_MFMA_F16(kf[0], qf[0][s], sacc);
-    }
-  };
-
-  f32x16 oacc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f, fv_run = 1.0f;
-
-  issue(0, 0);
-  if (ng > 1) issue(1, 1);
-  __syncthreads();
-  f32x16 sacc;
-  if (wave_active) scores(0, sacc);
-
-  for (int t = 0; t < ng; ++t) {
-    const int stage = t % 3;
-    if (t + 2 < ng) issue(t + 2, (t + 2) % 3);
-    if (wave_active) {
-      const int64_t gk = g_first + t;
-      const float fk = ng <= 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fk_lane), t))
-                                : inv[((int64_t)heads + h) * G + gk];
-      const float fv = ng <= 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fv_lane), t))
-                                : inv[((int64_t)2 * heads + h) * G + gk];
-      f32x16 snext;
-      if (t + 1 < ng) scores((t + 1) % 3, snext);          // matrix cores busy with S(t+1) during the softmax below
-      const unsigned char* Vs = ah_smem + stage * AH_STAGE + 8192;
-      attn_u32x4 vf[2][2][2];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int d = db * 32 + ql;
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-            vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
-        }
-      const float c = fq * fk * (0.125f * 1.44269504088896340736f);
-      if (gk == g_first || gk == g_last) {
-        asm volatile("" ::: "memory");
-        const int klo = (int)(r0 - gk * 32) - 4 * h2, khi = (int)(r1 - gk * 32) - 4 * h2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ko = (r & 3) + 8 * (r >> 2);
-          if (ko < klo || ko >= khi) sacc[r] = -INFINITY;
-        }
-      }
-      float mloc = sacc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c;
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      const float moff = 14.0f - m_new;
-      float lsum = 0.f;
-      attn_u32x4 pf[2][2];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c, moff));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r + 1], c, moff));
-        lsum += p0;
-        lsum += p1;
-        unsigned hi, lo;
-        ah_pack2(p0, p1, hi, lo);
-        pf[0][r >> 3][(r & 7) >> 1] = hi;
-        pf[1][r >> 3][(r & 7) >> 1] = lo;
-      }
-      lsum += __shfl_xor(lsum, 32, 64);
-      l_run = l_run * alpha + lsum;
-      m_run = m_new;
-      const float resc = alpha * (t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv));
-      fv_run = fv;
-      if (!__all(resc == 1.0f)) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[0][r] *= resc; oacc[1][r] *= resc; }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          oacc[db] = ANYLOC_MFMA_F16(vf[1][db][s2], pf[0][s2], oacc[db]);
-          oacc[db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[1][s2], oacc[db]);
-          oacc[db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[0][s2], oacc[db]);
-        }
-      if (t + 1 < ng) sacc = snext;
-    }
-    __syncthreads();
-  }
-
-  const int64_t row = gq0 * 32 + ql;
-  if (wave_active && row >= r0 && row < r1) {
-    const float f = fv_run * ah_pow2_recip(fm) / l_run;
-    if (h == 0 && h2 == 0) out_inv[row] = fm;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int k0 = h * HD + db * 32 + 8 * g + 4 * h2, e = k0 & 15;
-        unsigned char* dst = out2 + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + (((e >> 3) ^ (int)((row >> 3) & 1)) << 4) + (e & 7) * 2;
-        uint2 ph, plo;
-        ah_pack2(oacc[db][4 * g + 0] * f, oacc[db][4 * g + 1] * f, ph.x, plo.x);
-        ah_pack2(oacc[db][4 * g + 2] * f, oacc[db][4 * g + 3] * f, ph.y, plo.y);
-        *reinterpret_cast<uint2*>(dst) = ph;
-        *reinterpret_cast<uint2*>(dst + R * 32) = plo;
-      }
-  }
-}
-
 // fp32 [rows, 3D] (q | k | v, heads contiguous) -> the tiles of common.hpp (what gemm_h3's EPI_QKV_PLANES writes).
 // One block per (32-row group, head, part); used by the kernel tests and by callers that hold fp32 projections.
 __global__ __launch_bounds__(256) void qkv_planes_kernel(const float* __restrict__ qkv, int64_t rows, int D, int heads, int64_t G,
@@ -933,27 +751,10 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   ProfScope prof("attention", stream, flops, 8.0 * batch * T * D * 2);
   const int qgroups = (T + 31) / 32 + 1;                    // an image intersects at most this many 32-row groups
   const size_t lds = 2 * AH_STAGE + 64;
-  // ANYLOC_ATTN_H3_CFG (A/B): 0 (default) = four waves of 32 queries per workgroup, 1 = two waves of 64 queries
-  // (measured at B=61: 12.7 vs 13.7 ms per step)
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("ANYLOC_ATTN_H3_CFG");
-    cfg = e ? atoi(e) : 0;
-  }
+  // four waves of 32 queries per workgroup.  Measured slower and removed: two waves of 64 queries (12.7 vs 13.7 ms per step
+  // at B=61) and a software-pipelined loop with a 3-stage ring (15.0 ms) -- DESIGN.md 4.2b
   const dim3 grid((qgroups + 3) / 4, heads, (unsigned)batch);
-  if (cfg == 2) {
-    const size_t lds3 = 3 * AH_STAGE + 64;
-    static bool attr3 = false;
-    if (!attr3) {
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds3));
-      attr3 = true;
-    }
-    hipLaunchKernelGGL(attention_h3p_kernel, grid, dim3(256), lds3, stream, planes, inv, T, heads, G, out2, out_inv, R);
-  } else if (cfg == 0)
-    hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
-  else
-    hipLaunchKernelGGL((attention_h3_kernel<2, 2>), grid, dim3(128), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
+  hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
   return launch_status("attention_h3_kernel");
 }
 
@@ -964,20 +765,13 @@ int attention(const float* qkv, float* out, int64_t batch, int T, int D, int hea
   ANYLOC_CHECK_ARG(T > 0 && batch > 0 && batch < 65536, "attention: bad T/batch");
   const double flops = 4.0 * (double)batch * heads * (double)T * T * HD;
   ProfScope prof("attention", stream, flops, 16.0 * batch * T * D);
-  // ANYLOC_ATTN_CFG (micro-benchmarks): 0 = default (fast exp + operand preload), 1 = neither, 2 = fast exp, 3 = preload
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("ANYLOC_ATTN_CFG");
-    cfg = e ? atoi(e) : 0;
-  }
+  // option attn_cfg (micro-benchmarks): 0 = default (fast exp + operand preload), 1 = neither, 2 = fast exp, 3 = preload
+  const int cfg = (int)option(OPT_ATTN_CFG);
   const dim3 g4((T + 127) / 128, heads, (unsigned)batch), g2((T + 63) / 64, heads, (unsigned)batch);
   (void)g2;
   const int64_t R3 = batch * T;
-  // ANYLOC_ATTN_X6: 1 = split-bf16 kernel for every call (kernel tests), 0 = never, unset = when the caller asks
-  {
-    const char* e = getenv("ANYLOC_ATTN_X6");
-    if (e) x6 = atoi(e) != 0;
-  }
+  // option attn_x6: 1 = split-bf16 kernel for every call (kernel tests), 0 = never, -1 (default) = when the caller asks
+  if (option(OPT_ATTN_X6) >= 0) x6 = option(OPT_ATTN_X6) != 0;
   if (x6) {
     if (out3) hipLaunchKernelGGL((attention_x6_kernel<true>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3);
     else hipLaunchKernelGGL((attention_x6_kernel<false>), g4, dim3(256), 0, stream, qkv, out, T, D, 0.125f, out3, R3);

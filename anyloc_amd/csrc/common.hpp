@@ -49,6 +49,34 @@ struct ProfScope {
 
 bool profiling_enabled();
 
+// ---- tuning options (anyloc_set_option / anyloc_get_option; include/anyloc_hip.h lists the names) ------------------
+// Process-wide integers read by the host-side dispatch code; never read from the environment on a call path: the one
+// environment variable, ANYLOC_OPTIONS="name=value,...", is parsed once when the first option is looked up.
+enum Option {
+  OPT_GEMM_F32_CFG,      // gemm_f32.hip tile configuration (micro-benchmarks); 0 = default
+  OPT_X6_CFG,            // gemm_x6.hip tile configuration; 0 = default
+  OPT_H3_CFG,            // gemm_h3.hip tile configuration; 0 = default (128x256, 3-deep ring)
+  OPT_H3_GROUP_M,        // gemm_h3: tile rows per XCD scheduling group
+  OPT_H3_TINY_MAX,       // gemm_h3: below this many 128x128 tiles run 64x64 two-wave tiles
+  OPT_H3_DEEP_MAX,       // ... and below this many 64x64 tiles a ring stage holds four k-blocks
+  OPT_H3_DEEP2_MAX,      // ... below this many, two
+  OPT_H3_EPI_LDS,        // gemm_h3 LayerScale-residual epilogue: 1 = 16-byte accesses through LDS, 0 = dword read-modify-write
+  OPT_LN_SMALL_ROWS,     // layernorm_h2: below this many rows one row per wave
+  OPT_H3_FUSE,           // h3 forward: 1 = q|k|v, attention output and FFN activation stay in fp16 planes; 0 = fp32 + quantiser passes
+  OPT_X6_FUSE,           // x6 forward: the same for the bf16 plane images
+  OPT_H3_MIN_ROWS,       // h3 forward: below this many token rows use the fp32-MFMA kernels
+  OPT_X6_MIN_ROWS,       // x6 forward: the same
+  OPT_ATTN_CFG,          // fp32-MFMA attention: workgroup shape (micro-benchmarks)
+  OPT_ATTN_X6,           // anyloc_attention: 1 = split-bf16 products for every call, 0 = never, -1 = as the caller asks
+  OPT_VLAD_PARTS,        // workgroups per image of the fused VLAD kernel (0 = chosen from the image count)
+  OPT_VLAD_TWO_PASS,     // 1 = force the general two-pass VLAD path
+  OPT_VLAD_FUSED_V,      // fused VLAD kernel: 0 = default choice, 1 = exact-score kernel, 3 / 4 = screening kernel with 4 / 8 waves
+  OPT_KMEANS_FUSED_V,    // the same for the k-means step
+  OPT_KMEANS_MAX_CHUNKS, // k-means: upper limit of row chunks (partial sums); 0 = two per CU
+  OPT_COUNT
+};
+int64_t option(Option o);
+
 int launch_status(const char* what);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -229,7 +257,6 @@ struct FusedArgs {
   int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
   float* part_buf;         // [units, parts, K, D] partial sums
   unsigned* part_tickets;  // [units] arrival counters (zeroed by the launcher)
-  unsigned long long* stamps;   // tools only (ANYLOC_KM_STAMPS = device address): per-tile phase timestamps of unit 0
 };
 bool fused_supported(int64_t D, int64_t K);
 int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream);

@@ -373,16 +373,9 @@ int launch_cfg(const GemmProblem& p, hipStream_t stream) {
   return launch_status("gemm_nt_kernel");
 }
 
-// tile configuration of the wide (ViT / retrieval) GEMMs; ANYLOC_GEMM_CFG selects an
+// tile configuration of the wide (ViT / retrieval) GEMMs; option gemm_f32_cfg selects an
 // alternative at run time (micro-benchmarks only)
-int gemm_cfg() {
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("ANYLOC_GEMM_CFG");
-    cfg = e ? atoi(e) : 0;
-  }
-  return cfg;
-}
+int gemm_cfg() { return (int)option(OPT_GEMM_F32_CFG); }
 
 template <int EPI, bool KFULL>
 int launch_wide(const GemmProblem& p, hipStream_t stream) {

@@ -664,13 +664,11 @@ int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, flo
   const int nv = (int)((K / 4 + 63) / 64);
 #define ANYLOC_SPLIT_H2(NVV) \
   hipLaunchKernelGGL(split_h2_kernel<NVV>, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, out, inv_scale, rows)
-  const char* force_reg = getenv("ANYLOC_H2_REG");          // A/B switch: rows in registers at every width
   if (nv <= 1) ANYLOC_SPLIT_H2(1);
   else if (nv <= 2) ANYLOC_SPLIT_H2(2);
   else if (nv <= 4) ANYLOC_SPLIT_H2(4);
   else if (nv <= 6) ANYLOC_SPLIT_H2(6);
   else if (nv <= 8) ANYLOC_SPLIT_H2(8);
-  else if (force_reg && atoi(force_reg) == 1) ANYLOC_SPLIT_H2(16);
   else hipLaunchKernelGGL(split_h2_stream_kernel, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, out, inv_scale, rows);
 #undef ANYLOC_SPLIT_H2
   return launch_status("split_h2_kernel");
@@ -684,10 +682,8 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   const int nv = (dim / 4 + 63) / 64;
   f32x4 b4;                                                  // bound: HOST array of 4 floats (or null)
   for (int i = 0; i < 4; ++i) b4[i] = bound ? bound[i] : 0.0f;
-  // few rows (ANYLOC_LN_SMALL_ROWS, default 4096 = seven 322 x 322 images): one row per wave, four per block
-  const char* sr = getenv("ANYLOC_LN_SMALL_ROWS");          // read per call (tests flip it)
-  const int64_t small_rows = sr ? atoll(sr) : 4096;
-  const bool small = rows < small_rows;
+  // few rows (option ln_small_rows, default 4096 = seven 322 x 322 images): one row per wave, four per block
+  const bool small = rows < option(OPT_LN_SMALL_ROWS);
   const dim3 grid((unsigned)(small ? (rows + 3) / 4 : (rows + 15) / 16));
 #define ANYLOC_LN_H2(NVV)                                                                                                \
   do {                                                                                                                   \
@@ -710,13 +706,9 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
 
 template <int EPI>
 int dispatch_h3(const H3Problem& p, hipStream_t stream) {
-  // ANYLOC_H3_CFG (micro-benchmarks): 0 = 128x256 tile, 3-deep ring (default; 128x128 when there are few tiles); 1 = 2-deep;
+  // option h3_cfg (micro-benchmarks): 0 = 128x256 tile, 3-deep ring (default; 128x128 when there are few tiles); 1 = 2-deep;
   // 2-5 = 256x256 tiles (see the switch)
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("ANYLOC_H3_CFG");
-    cfg = e ? atoi(e) : 0;
-  }
+  const int cfg = (int)option(OPT_H3_CFG);
 #define ANYLOC_LAUNCH_H3(MI, NI, WM, WN, ST, OCC) ANYLOC_LAUNCH_H3K(MI, NI, WM, WN, ST, OCC, 1)
 #define ANYLOC_LAUNCH_H3K(MI, NI, WM, WN, ST, OCC, KB)                                                                \
   do {                                                                                                                \
@@ -734,22 +726,15 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
   const bool small = ((p.M + 127) / 128) * ((p.N + 255) / 256) < 512;
   if (small && cfg == 0) {
     // one or two images (the reference's scripts call the extractor per image): with 128x128 tiles proj / fc2 of ViT-g
-    // are 60 workgroups on 256 CUs -- below ANYLOC_H3_TINY_MAX (default 256) such tiles the GEMM runs 64x64 tiles on
+    // are 60 workgroups on 256 CUs -- below option h3_tiny_max (default 256) such tiles the GEMM runs 64x64 tiles on
     // two-wave workgroups instead
-    static int64_t tiny_max = -1;
-    if (tiny_max < 0) {
-      const char* e = getenv("ANYLOC_H3_TINY_MAX");
-      tiny_max = e ? atoll(e) : 256;
-    }
-    // read per call: tests/test_gpu_vit.py flips them inside one process
-    const char* d = getenv("ANYLOC_H3_DEEP_MAX");
-    const char* d2 = getenv("ANYLOC_H3_DEEP2_MAX");
-    const int64_t deep_max = d ? atoll(d) : 320, deep2_max = d2 ? atoll(d2) : 500;
+    const int64_t tiny_max = option(OPT_H3_TINY_MAX);
+    const int64_t deep_max = option(OPT_H3_DEEP_MAX), deep2_max = option(OPT_H3_DEEP2_MAX);
     if (((p.M + 127) / 128) * ((p.N + 127) / 128) < tiny_max) {
       // fewer 64x64 tiles than ~1.25 per CU (ViT-g proj / fc2 of one image: 216): a workgroup is alone on its CU, nothing
       // hides its per-k-block barrier and LDS round trip (measured 625 cycles per k-block for 192 cycles of MFMA), so
       // the ring stage holds FOUR k-blocks -- one barrier and one counted wait per 64 k.  Same k order per output element:
-      // bitwise the result of the one-k-block kernel (ANYLOC_H3_DEEP_MAX=0 restores it).  B=1: fc2 80 -> 49 us, proj 36 -> 24 us
+      // bitwise the result of the one-k-block kernel (option h3_deep_max = 0 restores it).  B=1: fc2 80 -> 49 us, proj 36 -> 24 us
       // per launch; with 320 ... 500 tiles (two images) two k-blocks per stage (profiles/r02_small_batch_kernels.log).
       if (((p.M + 63) / 64) * ((p.N + 63) / 64) < deep_max) {
         ANYLOC_LAUNCH_H3K(1, 2, 2, 1, 3, 2, 4);             // 64x64, 2 waves, 3 stages of 4 k-blocks (96 KiB)
@@ -786,22 +771,17 @@ int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
                    "gemm_h3: operand image exceeds the 2 GiB buffer-addressing range");
   const int64_t K = 16ll * p.K16;
   ProfScope prof(p.tag ? p.tag : "gemm_h3", stream, 2.0 * p.M * p.N * K, 4.0 * (p.M + p.N) * K + 4.0 * p.M * p.N);
-  // tile-rows per scheduling group (co-resident workgroups of an XCD share A / W panels through its L2); ANYLOC_H3_GM
-  // overrides the default of 8 (micro-benchmarks)
-  static int gm = -1;
-  if (gm < 0) {
-    const char* e = getenv("ANYLOC_H3_GM");
-    gm = e ? std::max(1, atoi(e)) : 8;
-  }
-  p.group_m = gm;
+  // tile-rows per scheduling group (co-resident workgroups of an XCD share A / W panels through its L2): option
+  // h3_group_m, default 8
+  p.group_m = (int)std::max<int64_t>(1, option(OPT_H3_GROUP_M));
   switch (epilogue) {
     case EPI_STORE: return dispatch_h3<EPI_STORE>(p, stream);
     case EPI_GELU: return dispatch_h3<EPI_GELU>(p, stream);
     case EPI_LS_RESID: {
       ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_h3: LS_RESID needs gamma and resid");
       H3Problem q = p;
-      const char* e = getenv("ANYLOC_H3_EPI_LDS");          // A/B switch: 0 = dword read-modify-write epilogue
-      q.epi_lds = !(e && atoi(e) == 0) && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+      // option h3_epi_lds = 0: the dword read-modify-write epilogue (also the fallback for unaligned C)
+      q.epi_lds = option(OPT_H3_EPI_LDS) != 0 && p.N % 4 == 0 && p.ldc % 4 == 0 &&
                   (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
       return dispatch_h3<EPI_LS_RESID>(q, stream);
     }

@@ -233,14 +233,9 @@ int dispatch_x6(const X6Problem& p, hipStream_t stream) {
   if constexpr (EPI == EPI_GELU || EPI == EPI_SWIGLU)
     if (p.C3) return small ? launch_x6<2, 2, 2, 2, 3, 2, EPI, 1, true>(p, stream)
                            : launch_x6<2, 4, 2, 2, 2, 2, EPI, 1, true>(p, stream);
-  // ANYLOC_X6_CFG (micro-benchmarks): 0 = 128x256 tile, 4 waves, 2-deep ring, two blocks per CU (default);
+  // option x6_cfg (micro-benchmarks): 0 = 128x256 tile, 4 waves, 2-deep ring, two blocks per CU (default);
   //   1 = 128x128 3-deep; 2 = 256x128 3-deep (1 block/CU); 3 = 256x128 2-deep; 7 / 8 = 256x256 with 8 waves
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("ANYLOC_X6_CFG");
-    cfg = e ? atoi(e) : 0;
-  }
-  switch (cfg) {
+  switch ((int)option(OPT_X6_CFG)) {
     case 1: return launch_x6<2, 2, 2, 2, 3, 2, EPI>(p, stream);
     case 2: return launch_x6<4, 2, 2, 2, 3, 1, EPI>(p, stream);
     case 3: return launch_x6<4, 2, 2, 2, 2, 2, EPI>(p, stream);

@@ -1,4 +1,5 @@
 // Error reporting, launch checking and the per-kernel HIP-event profiler.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -35,6 +36,54 @@ int hip_fail(hipError_t e, const char* what) {
 
 bool profiling_enabled() { return g_prof_on; }
 
+namespace {
+struct OptDef {
+  const char* name;
+  int64_t def;
+};
+// order = enum Option (common.hpp)
+const OptDef kOptDefs[OPT_COUNT] = {
+    {"gemm_f32_cfg", 0},      {"x6_cfg", 0},          {"h3_cfg", 0},        {"h3_group_m", 8},   {"h3_tiny_max", 256},
+    {"h3_deep_max", 320},     {"h3_deep2_max", 500},  {"h3_epi_lds", 1},    {"ln_small_rows", 4096}, {"h3_fuse", 1},
+    {"x6_fuse", 1},           {"h3_min_rows", 0},     {"x6_min_rows", 1600}, {"attn_cfg", 0},    {"attn_x6", -1},
+    {"vlad_parts", 0},    {"vlad_two_pass", 0}, {"vlad_fused_v", 0},
+    {"kmeans_fused_v", 0},    {"kmeans_max_chunks", 0},
+};
+std::mutex g_opt_mu;
+int64_t g_opt[OPT_COUNT];
+bool g_opt_init = false;
+
+int find_option(const char* name, size_t len) {
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strlen(kOptDefs[i].name) == len && strncmp(kOptDefs[i].name, name, len) == 0) return i;
+  return -1;
+}
+
+// defaults, then ANYLOC_OPTIONS="name=value,name=value" (the library's only environment variable; unknown names and
+// malformed items are reported once on stderr and ignored).  Caller holds g_opt_mu.
+void init_options() {
+  if (g_opt_init) return;
+  for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = kOptDefs[i].def;
+  g_opt_init = true;
+  const char* e = getenv("ANYLOC_OPTIONS");
+  while (e && *e) {
+    const char* end = strchr(e, ',');
+    const size_t len = end ? (size_t)(end - e) : strlen(e);
+    const char* eq = static_cast<const char*>(memchr(e, '=', len));
+    const int id = eq ? find_option(e, (size_t)(eq - e)) : -1;
+    if (id >= 0) g_opt[id] = strtoll(eq + 1, nullptr, 0);
+    else if (len) fprintf(stderr, "[anyloc] ANYLOC_OPTIONS: ignoring '%.*s'\n", (int)len, e);
+    e = end ? end + 1 : nullptr;
+  }
+}
+}  // namespace
+
+int64_t option(Option o) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  init_options();
+  return g_opt[o];
+}
+
 int launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, what);
@@ -68,6 +117,33 @@ extern "C" {
 
 int anyloc_version(void) { return ANYLOC_ABI_VERSION; }
 const char* anyloc_last_error(void) { return g_err; }
+
+int anyloc_set_option(const char* name, int64_t value) {
+  ANYLOC_CHECK_ARG(name, "set_option: null name");
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  init_options();
+  const int id = find_option(name, strlen(name));
+  ANYLOC_CHECK_ARG(id >= 0, "set_option: unknown option '%s'", name);
+  g_opt[id] = value;
+  return ANYLOC_OK;
+}
+
+int anyloc_get_option(const char* name, int64_t* value) {
+  ANYLOC_CHECK_ARG(name && value, "get_option: null pointer");
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  init_options();
+  const int id = find_option(name, strlen(name));
+  ANYLOC_CHECK_ARG(id >= 0, "get_option: unknown option '%s'", name);
+  *value = g_opt[id];
+  return ANYLOC_OK;
+}
+
+int anyloc_reset_options(void) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  g_opt_init = false;
+  init_options();
+  return ANYLOC_OK;
+}
 
 int anyloc_profile_enable(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -31,23 +31,6 @@ struct anyloc_vit {
   std::vector<anyloc_vit_block_weights> blocks;
   std::vector<anyloc_vit_block_x3> x3;      // optional: three-plane bf16 images of the four weight matrices
   std::vector<anyloc_vit_block_h2> h2;      // optional: two-plane fp16 images + row scales of the same matrices
-  // ANYLOC_VIT_GRAPH: instantiated launch sequences, keyed by everything a sequence depends on (shape, taps, flags,
-  // the four caller pointers, the environment switches read per forward); at most kMaxGraphs, least recently used out
-  struct Graph {
-    std::vector<int64_t> key;
-    hipGraphExec_t exec;
-    uint64_t stamp;
-  };
-  static constexpr size_t kMaxGraphs = 8;
-  std::vector<Graph> graphs;
-  std::vector<std::vector<int64_t>> seen;   // keys that ran eagerly once (the second call captures)
-  hipStream_t capture_stream = nullptr;     // capture needs a non-default stream; replay goes to the caller's stream
-  uint64_t clock = 0;
-  int64_t replays = 0;                      // hipGraphLaunch calls so far
-  ~anyloc_vit() {
-    for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
-    if (capture_stream) (void)hipStreamDestroy(capture_stream);
-  }
 };
 
 namespace anyloc {
@@ -95,33 +78,10 @@ int linear(const float* A, int64_t lda, const float* Wt, int64_t K, const float*
   return gemm_nt(g, epi, stream);
 }
 
-// ANYLOC_X6_FUSE=0: keep fp32 activations and split them in front of every GEMM (A/B measurements)
-bool x6_fused() {
-  const char* e = getenv("ANYLOC_X6_FUSE");      // read per forward: tests flip it inside one process
-  return !(e && atoi(e) == 0);
-}
-
-// ANYLOC_H3_FUSE=0: fp16 mode with fp32 q|k|v / attention output / FFN activation and separate quantiser passes (the
-// round-1 data flow; A/B measurements and tests)
-// 2 / 3 fuse only the attention / only the FFN side (bisecting)
-int h3_fused() {
-  const char* e = getenv("ANYLOC_H3_FUSE");
-  return e ? atoi(e) : 1;
-}
-
-int64_t x6_min_rows() {
-  const char* e = getenv("ANYLOC_X6_MIN_ROWS");
-  return e ? atoll(e) : 1600;
-}
-// the two-term fp16 forward has no such threshold any more: with q | k | v, the attention output and the FFN activation
-// kept in fp16 planes it beats the fp32-MFMA kernels at every batch (B=1: 9.6 vs 16.5 ms, B=2: 11.3 vs 21.4 ms per batch,
-// profiles/r02_extractor_vs_batch.log); ANYLOC_H3_MIN_ROWS (or the older ANYLOC_X6_MIN_ROWS) restores one
-int64_t h3_min_rows() {
-  const char* e = getenv("ANYLOC_H3_MIN_ROWS");
-  if (e) return atoll(e);
-  e = getenv("ANYLOC_X6_MIN_ROWS");
-  return e ? atoll(e) : 0;
-}
+// options (common.hpp): x6_fuse / h3_fuse = 0 keep fp32 activations and quantise them in front of every GEMM (the round-1
+// data flows; A/B measurements and tests).  The two-term fp16 forward has no row threshold by default: with q | k | v, the
+// attention output and the FFN activation kept in fp16 planes it beats the fp32-MFMA kernels at every batch (B=1: 9.6 vs
+// 16.5 ms, profiles/r02_extractor_vs_batch.log); the split-bf16 forward switches at 1600 rows.
 
 // y = act(A W^T + b) on the six-product bf16 GEMM.  A is given as fp32 (split into planes here) or, when A == nullptr,
 // a3 already holds its plane image (written by the producer).  c3 != nullptr: the activation is written as the plane
@@ -291,13 +251,13 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
                    "vit_forward: ANYLOC_VIT_SPLIT_BF16 without anyloc_vit_attach_x3");
   // below ~3 images of 530 tokens the GEMMs have too few 128-row tiles to fill 256 CUs twice over: the fp32-MFMA
   // kernel with its 64-row split is faster there (measured B=1: 60 vs 40 images/s), so the split-bf16 request is
-  // honoured from x6_min_rows() rows up (ANYLOC_X6_MIN_ROWS overrides)
+  // honoured from option x6_min_rows rows up
   ANYLOC_CHECK_ARG(!(flags & ANYLOC_VIT_SPLIT_FP16) || !h->h2.empty(),
                    "vit_forward: ANYLOC_VIT_SPLIT_FP16 without anyloc_vit_attach_h2");
-  const bool h3m = (flags & ANYLOC_VIT_SPLIT_FP16) && M >= h3_min_rows();
-  const bool x6 = !h3m && (flags & ANYLOC_VIT_SPLIT_BF16) && M >= x6_min_rows();
-  const bool fuse_x6 = x6 && x6_fused();
-  const int h3f = h3m ? h3_fused() : 0;
+  const bool h3m = (flags & ANYLOC_VIT_SPLIT_FP16) && M >= option(OPT_H3_MIN_ROWS);
+  const bool x6 = !h3m && (flags & ANYLOC_VIT_SPLIT_BF16) && M >= option(OPT_X6_MIN_ROWS);
+  const bool fuse_x6 = x6 && option(OPT_X6_FUSE) != 0;
+  const bool h3f = h3m && option(OPT_H3_FUSE) != 0;
   const bool use_cls = flags & ANYLOC_VIT_USE_CLS;
   const int rows_per_img = use_cls ? T : np, skip = use_cls ? 0 : 1;
   const int64_t ldo = (int64_t)n_taps * D;
@@ -356,7 +316,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
     bool qkv_tap = false;                       // a q / k / v tap of this layer needs the fp32 projection
     for (int t = 0; t < n_taps; ++t)
       if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN) qkv_tap = true;
-    const bool fuse_attn = (h3f == 1 || h3f == 2) && !qkv_tap && D % 128 == 0;
+    const bool fuse_attn = h3f && !qkv_tap && D % 128 == 0;
     if (fuse_attn) {
       // fp16 mode, fused: the QKV GEMM writes per-head two-plane fp16 tiles, attention_h3 consumes them by DMA and writes
       // the image of the projection GEMM -- q, k, v and the attention output never exist in fp32
@@ -389,7 +349,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       else
         ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
     }
-    const float* fb = (h3f == 1 || h3f == 3) ? h->h2[l].fc1_bound : nullptr;
+    const float* fb = h3f ? h->h2[l].fc1_bound : nullptr;
     const bool fuse_ffn = fb && (fb[0] > 0.f || fb[1] > 0.f);
     if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, fuse_ffn ? fb : nullptr, w.hinv));
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
@@ -458,72 +418,8 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch, int64_t
     ANYLOC_CHECK_ARG(tap_facets[t] >= 0 && tap_facets[t] <= 3, "vit_forward: facet %d", tap_facets[t]);
     ANYLOC_CHECK_ARG(t == 0 || tap_layers[t] >= tap_layers[t - 1], "vit_forward: tap layers must ascend");
   }
-  auto eager = [&]() {
-    return vit_forward_launches(h, img, batch, img_h, img_w, pos, n_taps, tap_layers, tap_facets, flags, out, workspace,
-                                workspace_bytes, stream);
-  };
-  // Small batches are bound by launch latency, not by throughput (ViT-g, one 322 x 322 image: ~220 dependent launches of
-  // 20-40 us): with ANYLOC_VIT_GRAPH the sequence is captured once per key into a HIP graph and replayed with a single
-  // hipGraphLaunch.  The first call of a key runs eagerly (it sets kernel attributes and loads the code objects, and
-  // one-off shapes never pay for an instantiation), the second captures.  Not while the per-kernel profiler is on (its
-  // events bracket individual launches).
-  if (!(flags & ANYLOC_VIT_GRAPH) || profiling_enabled()) return eager();
-  std::vector<int64_t> key = {batch, img_h, img_w, (int64_t)flags, (int64_t)n_taps, (int64_t)(uintptr_t)img,
-                              (int64_t)(uintptr_t)pos, (int64_t)(uintptr_t)out, (int64_t)(uintptr_t)workspace,
-                              (int64_t)workspace_bytes, (int64_t)h3_fused(), (int64_t)x6_fused(), h3_min_rows(), x6_min_rows()};
-  for (int t = 0; t < n_taps; ++t) key.push_back(((int64_t)tap_layers[t] << 8) | tap_facets[t]);
-  ++h->clock;
-  for (auto& g : h->graphs)
-    if (g.key == key) {
-      g.stamp = h->clock;
-      ANYLOC_HIP(hipGraphLaunch(g.exec, stream));
-      ++h->replays;
-      return ANYLOC_OK;
-    }
-  bool seen = false;
-  for (auto& k : h->seen) seen = seen || k == key;
-  if (!seen) {
-    if (h->seen.size() >= 64) h->seen.erase(h->seen.begin());
-    h->seen.push_back(key);
-    return eager();
-  }
-  if (!h->capture_stream) ANYLOC_HIP(hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
-  ANYLOC_HIP(hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal));
-  const int rc = vit_forward_launches(h, img, batch, img_h, img_w, pos, n_taps, tap_layers, tap_facets, flags, out, workspace,
-                                      workspace_bytes, h->capture_stream);
-  hipGraph_t graph = nullptr;
-  const hipError_t ec = hipStreamEndCapture(h->capture_stream, &graph);
-  if (rc != ANYLOC_OK || ec != hipSuccess || !graph) {
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    if (rc != ANYLOC_OK) return rc;                        // the sequence itself is invalid: report that
-    return eager();                                        // capture refused: run as usual
-  }
-  hipGraphExec_t exec = nullptr;
-  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess || !exec) {
-    (void)hipGetLastError();
-    return eager();
-  }
-  if (h->graphs.size() >= anyloc_vit::kMaxGraphs) {
-    size_t victim = 0;
-    for (size_t i = 1; i < h->graphs.size(); ++i)
-      if (h->graphs[i].stamp < h->graphs[victim].stamp) victim = i;
-    (void)hipGraphExecDestroy(h->graphs[victim].exec);
-    h->graphs.erase(h->graphs.begin() + victim);
-  }
-  h->graphs.push_back({key, exec, h->clock});
-  ANYLOC_HIP(hipGraphLaunch(exec, stream));
-  ++h->replays;
-  return ANYLOC_OK;
-}
-
-int anyloc_vit_graph_stats(const anyloc_vit_t* h, int64_t* graphs, int64_t* replays) {
-  ANYLOC_CHECK_ARG(h && graphs && replays, "vit_graph_stats: null pointer");
-  *graphs = (int64_t)h->graphs.size();
-  *replays = h->replays;
-  return ANYLOC_OK;
+  return vit_forward_launches(h, img, batch, img_h, img_w, pos, n_taps, tap_layers, tap_facets, flags, out, workspace,
+                              workspace_bytes, stream);
 }
 
 }  // extern "C"

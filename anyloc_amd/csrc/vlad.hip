@@ -350,34 +350,11 @@ __global__ __launch_bounds__(256) void assigned_prep_kernel(const float* __restr
 
 inline int64_t kpad_of(int64_t K) { return (K + 31) / 32 * 32; }
 
-inline bool fused_forced() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ANYLOC_VLAD_FUSED");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
-// images from which the single-launch fused kernel is used; ANYLOC_VLAD_FUSED_MIN overrides
-inline int64_t fused_min_images() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char* e = getenv("ANYLOC_VLAD_FUSED_MIN");
-    v = e ? atoll(e) : 1;
-  }
-  return v;
-}
-
 // Workgroups per image of the fused kernel: one workgroup per image cannot fill 256 CUs below ~200 images, so a small
 // batch splits every image's token tiles over up to 8 workgroups (the last to finish reduces, vlad_fused.hip); every
-// part keeps >= 2 tiles of 16 tokens on average.  ANYLOC_VLAD_PARTS forces a count (A/B, tests).
+// part keeps >= 2 tiles of 16 tokens on average.  Option vlad_parts forces a count (A/B, tests).
 inline int fused_parts(int64_t n_img, int64_t total) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("ANYLOC_VLAD_PARTS");
-    forced = e ? atoi(e) : 0;
-  }
+  const int forced = (int)option(OPT_VLAD_PARTS);
   if (n_img <= 0) return 1;
   if (forced > 0) return forced > 64 ? 64 : forced;
   int64_t p = 256 / n_img;
@@ -387,15 +364,8 @@ inline int fused_parts(int64_t n_img, int64_t total) {
   return p < 1 ? 1 : (int)p;
 }
 
-// ANYLOC_VLAD_TWO_PASS=1 selects the two-pass path even where the fused kernel applies (A/B tests)
-inline bool two_pass_forced() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ANYLOC_VLAD_TWO_PASS");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
+// option vlad_two_pass = 1 selects the two-pass path even where the fused kernel applies (A/B tests)
+inline bool two_pass_forced() { return option(OPT_VLAD_TWO_PASS) != 0; }
 
 struct VladWs {
   float *chat, *cb, *scores, *rowsq, *nrm;
@@ -466,7 +436,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ANYLOC_TRY(vlad_common_checks(tokens, offsets, n_img, total_tokens, D, centers, K, out));
   if (n_img == 0) return ANYLOC_OK;
-  const bool fused = fused_supported(D, K) && !two_pass_forced() && (n_img >= fused_min_images() || fused_forced());
+  const bool fused = fused_supported(D, K) && !two_pass_forced();
   const int parts = fused ? fused_parts(n_img, total_tokens) : 1;
   VladWs w = carve(workspace, workspace_bytes, total_tokens, D, K, n_img, parts);
   if (!workspace || w.bytes > workspace_bytes) {
@@ -477,7 +447,7 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   // labels = kmeans.predict(tokens) in the metric the vocabulary was built with (reference utilities.py:849 with
   // VLAD(dist_mode=...)): fpk cosine score, or fpk euclidean similarity 2ab - a^2 - b^2 (arg-max = nearest centre)
   const int metric = (flags & ANYLOC_VLAD_EUCLIDEAN) ? 1 : 0;
-  // The fused kernel wherever it applies (K <= 32, the ViT widths); ANYLOC_VLAD_TWO_PASS=1 selects the general path.
+  // The fused kernel wherever it applies (K <= 32, the ViT widths); option vlad_two_pass = 1 selects the general path.
   if (fused) {
     // single-pass fused kernel (vlad_fused.hip): tokens are read from HBM once
     {
@@ -669,22 +639,22 @@ int anyloc_vlad_assigned(const float* tokens, int64_t n_tok, int64_t D, const fl
 
 // ------------------------------------------------------------------ k-means
 // rows per chunk of the k-means step: one workgroup and one partial [K, D] sum per chunk, the partial sums added in chunk
-// order by reduce_chunks_kernel.  At least 1024 rows per chunk and at most two chunks per CU (ANYLOC_KMEANS_MAX_CHUNKS
+// order by reduce_chunks_kernel.  At least 1024 rows per chunk and at most two chunks per CU (option kmeans_max_chunks
 // overrides): every chunk costs a prologue, 196 KB of partial sums written and re-read, and with one fused workgroup
 // filling a CU more chunks only add rounds -- 5 M x 1536 rows: 2048 chunks 6.67 ms, 1024 6.20, 512 5.87, 256 5.87 per
 // step on clustered rows (profiles/r02_kmeans_chunks.log); two per CU keeps some slack for CUs of unequal speed.
 static int64_t kmeans_chunk_rows(int64_t n) {
-  static int64_t max_chunks = 0;
-  if (max_chunks == 0) {
-    const char* e = getenv("ANYLOC_KMEANS_MAX_CHUNKS");
-    int dev = 0, cus = 0;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         cus <= 0) {
       (void)hipGetLastError();
       cus = 256;
     }
-    max_chunks = (e && atoll(e) > 0) ? atoll(e) : 2ll * cus;
   }
+  const int64_t forced = option(OPT_KMEANS_MAX_CHUNKS);
+  const int64_t max_chunks = forced > 0 ? forced : 2ll * cus;
   int64_t rows = (n + max_chunks - 1) / max_chunks;
   return rows < 1024 ? 1024 : rows;
 }

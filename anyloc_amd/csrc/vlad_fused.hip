@@ -4,9 +4,8 @@
 // per-cluster sums / intra-norm / global norm of VLAD.generate :854-861,:889 (VLAD mode), and the
 // assign + update body of fast-pytorch-kmeans' fit loop reached from VLAD.fit :786 (k-means mode).
 //
-// Three structures live here (vlad_fused() picks; ANYLOC_VLAD_FUSED_V / ANYLOC_KMEANS_FUSED_V select one for A/B runs):
+// Two structures live here (vlad_fused() picks; options vlad_fused_v / kmeans_fused_v select one for A/B runs and tests):
 //   vlad_fused_kernel     exact fp32-MFMA scores, centres streamed from L2, one owner thread per (cluster, column)
-//   kmeans_fused2_kernel  the same arithmetic, 512 threads, part of the centres register-resident (k-means only)
 //   fused3_kernel         fp16 screening scores from register-resident centres + exact fp32 resolution of close calls,
 //                         balanced register-indexed gather -- the default
 // The first structure, described: one 1024-thread workgroup (16 waves, one per CU) owns a *unit*: an image (VLAD) or a chunk
@@ -356,213 +355,8 @@ __global__ __launch_bounds__(NTH) void vlad_fused_kernel(FusedArgs a) {
 }
 
 
-// ---- k-means iteration, second structure: 512 threads, software-pipelined scoring ----
-// One workgroup per CU either way (the tile fills LDS); with 512 threads (8 waves) a thread has 256 VGPRs instead of 128, so
-// EVERY wave scores its D/8 slice with the B fragments (normalised centres, streamed from L2) in a 3-deep register ring and
-// the A fragments read one group ahead -- in the first structure the compiler's schedule waits for each L2 / LDS load right
-// after issuing it, and the second wave of a SIMD only starts when the first is done (s_memtime stamps: 13 400 cycles of
-// scoring per tile against 6 144 of matrix-core time).  Every thread owns (cluster tid/16, columns 4 (tid%16) + 64 m) =
-// 2 NV float4 accumulators.  k-means mode only: VLAD subtracts the raw centre from every
-// token, and a third K x D operand in registers does not fit (summing tokens first and subtracting n_k c_k at the end would
-// round the large running sum: above the 1e-5 parity bar for big clusters).
-template <int NV, int NGRQ>
-__global__ __launch_bounds__(512) void kmeans_fused2_kernel(FusedArgs a) {
-  constexpr int D = NV * 128;
-  constexpr int LD = D + 4;
-  constexpr int NT2 = 512;
-  constexpr int NF = NV;                      // staged float4 per thread per tile: 16 * D / 4 / 512
-  constexpr int SW = 8;                       // every wave scores its D/8 slice
-  constexpr int NG = NV;                      // 16-wide k-groups per wave
-  constexpr int NA = 2 * NV;                  // accumulator float4 per thread
-  constexpr int NGR = NV > NGRQ ? NGRQ : NV;  // k-groups whose B fragments stay in registers (NGRQ = 4: the most that compiles
-                                              // without spills at D = 1536; 6 spills 12 registers into the tile loop and is
-                                              // slower, measured); the others stream from L2 in a 3-deep ring.  Streaming all
-                                              // 12 groups (196 KB per tile and CU) runs into the L2s' bandwidth: the scoring
-                                              // phase then takes 12 000 cycles per tile whatever the schedule.
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* tile = lds;                          // [TT][LD]
-  float* part = tile + TT * LD;               // [SW][TT][32]
-  int* lab = reinterpret_cast<int*>(part + SW * TT * 32);   // [TT]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t unit = blockIdx.x;
-  const int64_t n0 = unit * a.chunk_rows, n1 = min(n0 + a.chunk_rows, a.total);
-  const int64_t nrows = n1 - n0;
-  const int ntiles = (int)((nrows + TT - 1) / TT);
-
-  // the descriptor must be PROVABLY wave-uniform, or every buffer load is wrapped in a waterfall loop (15 instructions each)
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(const_cast<float*>(a.x + n0 * D)), 0,
-      __builtin_amdgcn_readfirstlane((int)imin64(nrows * D * 4, 0x7fffffff)), 0x00020000);
-  f32x4 stg[NF];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int t) {
-    const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      const int f = tid + NT2 * i, row = f / (D / 4), c4 = f - row * (D / 4);
-      stg[i] = bload16(x_rsrc, (unsigned)((row * D + 4 * c4) * 4), so);
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      const int f = tid + NT2 * i, row = f / (D / 4), c4 = f - row * (D / 4);
-      *reinterpret_cast<f32x4*>(tile + row * LD + 4 * c4) = stg[i];
-    }
-  };
-
-  // owner coordinates: cluster tid / 16, columns 4 (tid % 16) + 64 m
-  const int ok_ = tid >> 4, oj = tid & 15;
-  f32x4 acc[NA];
-#pragma unroll
-  for (int m = 0; m < NA; ++m) acc[m] = zero4;
-  unsigned my_count = 0;
-  const bool k_live = ok_ < a.K;
-
-  // scoring coordinates: slice `wave`, 16x16x4 fragments (row / centre = lane & 15, k-quad = lane >> 4)
-  const int fr = lane & 15, fq = lane >> 4;
-  const __amdgpu_buffer_rsrc_t c_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float*>(a.chat)), 0, 32 * D * 4, 0x00020000);
-  const unsigned b_off0 = (unsigned)(((fr)*D + wave * (D / SW) + 4 * fq) * 4);
-  const unsigned b_off1 = (unsigned)(((16 + fr) * D + wave * (D / SW) + 4 * fq) * 4);
-  const float* a_frag = tile + fr * LD + wave * (D / SW) + 4 * fq;
-  const float my_bias = a.cbias[tid & 31];    // score bias of centre tid % 32 (assign phase): loaded once, not per tile
-  f32x4 br0[NGR], br1[NGR];
-#pragma unroll
-  for (int g = 0; g < NGR; ++g) {
-    br0[g] = bload16(c_rsrc, b_off0, (unsigned)(64 * g));
-    br1[g] = bload16(c_rsrc, b_off1, (unsigned)(64 * g));
-  }
-
-  if (ntiles > 0) {
-    fetch(0);
-    stash();
-  }
-  __syncthreads();
-
-  const bool stamp = a.stamps && unit == 0 && tid == 0;
-  const bool wstamp = a.stamps && unit == 0 && lane == 0;      // one lane per wave: per-wave phase ends
-  for (int t = 0; t < ntiles; ++t) {
-    const int valid = (int)imin64(TT, nrows - (int64_t)t * TT);
-    if (stamp) a.stamps[t * 24 + 0] = __builtin_readcyclecounter();
-    {
-      // ---- scores: S[16 tokens][32 centres] over this wave's D/8 slice.  The B fragments (normalised centres, L2-resident)
-      //      travel in a 3-deep register ring: the loads of group g + 2 are issued before the MFMAs of group g, the A
-      //      fragment of group g + 1 is read from LDS before them too -- no load is waited for right after its issue ----
-      constexpr int NS = NG - NGR;                          // streamed groups (consumed last)
-      f32x4 bq0[3], bq1[3];
-#pragma unroll
-      for (int j = 0; j < 2 && j < NS; ++j) {
-        bq0[j] = bload16(c_rsrc, b_off0, (unsigned)(64 * (NGR + j)));
-        bq1[j] = bload16(c_rsrc, b_off1, (unsigned)(64 * (NGR + j)));
-      }
-      // FOUR accumulator chains (two ran the dependent 16x16x4 fp32 MFMAs at half rate)
-      f32x4 s00 = zero4, s01 = zero4, s10 = zero4, s11 = zero4;
-      f32x4 av = *reinterpret_cast<const f32x4*>(a_frag);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int j = g - NGR;                              // index among the streamed groups (when >= 0)
-        if (j >= 0 && j + 2 < NS) {
-          bq0[(j + 2) % 3] = bload16(c_rsrc, b_off0, (unsigned)(64 * (g + 2)));
-          bq1[(j + 2) % 3] = bload16(c_rsrc, b_off1, (unsigned)(64 * (g + 2)));
-        }
-        f32x4 av_n = zero4;
-        if (g + 1 < NG) av_n = *reinterpret_cast<const f32x4*>(a_frag + 16 * (g + 1));
-        const f32x4 b0 = g < NGR ? br0[g < NGR ? g : 0] : bq0[(j >= 0 ? j : 0) % 3];
-        const f32x4 b1 = g < NGR ? br1[g < NGR ? g : 0] : bq1[(j >= 0 ? j : 0) % 3];
-        s00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[0], s00, 0, 0, 0);
-        s10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b1[0], s10, 0, 0, 0);
-        s01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b0[1], s01, 0, 0, 0);
-        s11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b1[1], s11, 0, 0, 0);
-        s00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b0[2], s00, 0, 0, 0);
-        s10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b1[2], s10, 0, 0, 0);
-        s01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b0[3], s01, 0, 0, 0);
-        s11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b1[3], s11, 0, 0, 0);
-        if (j >= 0 && j + 2 < NS) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // 2 VMEM reads (B two groups ahead)
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 LDS read (A of group g + 1)
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // 8 MFMAs (group g)
-        av = av_n;
-      }
-      f32x4 s0, s1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s0[r] = s00[r] + s01[r]; s1[r] = s10[r] + s11[r]; }
-      float* p = part + wave * (TT * 32) + (4 * fq) * 32 + fr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r * 32] = s0[r];
-        p[r * 32 + 16] = s1[r];
-      }
-      if (wstamp) a.stamps[t * 24 + 4 + wave] = __builtin_readcyclecounter();
-      if (t + 1 < ntiles) fetch(t + 1);                    // HBM loads of the next tile fly during assign + gather
-    }
-    lds_barrier();
-    if (stamp) a.stamps[t * 24 + 1] = __builtin_readcyclecounter();
-    {
-      // ---- assign: fixed-order sum of the 8 partials, first arg-max over k < K (all 512 threads: 16 tokens x 32) ----
-      const int row = tid >> 5, k = tid & 31;
-      float s = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < SW; ++w2) s += part[w2 * (TT * 32) + row * 32 + k];
-      s += my_bias;
-      float best = (k < a.K) ? s : -INFINITY;
-      int bi = (k < a.K && best == best) ? k : 0x7fffffff;
-      if (!(best == best)) best = -INFINITY;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      }
-      if (k == 0) {
-        if (bi == 0x7fffffff) bi = 0;
-        const bool live = row < valid;
-        lab[row] = live ? bi : -1;
-        if (live && a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
-      }
-    }
-    lds_barrier();
-    if (stamp) a.stamps[t * 24 + 2] = __builtin_readcyclecounter();
-    if (k_live) {
-      // ---- gather: the 16 owners of a cluster add its tokens (in order) ----
-      const float* tp = tile + 4 * oj;
-      unsigned mine = 0;
-#pragma unroll
-      for (int n = 0; n < TT; n += 4) {
-        const i32x4_t q = *reinterpret_cast<const i32x4_t*>(lab + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mine |= (q[e] == ok_ ? 1u : 0u) << (n + e);
-      }
-      for (int n = 0; n < TT; ++n) {
-        if (!((mine >> n) & 1u)) continue;
-        const float* rp = tp + n * LD;
-#pragma unroll
-        for (int m = 0; m < NA; ++m) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 64 * m);
-          acc[m][0] += v[0]; acc[m][1] += v[1]; acc[m][2] += v[2]; acc[m][3] += v[3];
-        }
-        ++my_count;
-      }
-    }
-    if (wstamp) a.stamps[t * 24 + 12 + wave] = __builtin_readcyclecounter();
-    lds_barrier();
-    if (stamp) a.stamps[t * 24 + 3] = __builtin_readcyclecounter();
-    if (t + 1 < ntiles) stash();
-    lds_barrier();
-    if (stamp) a.stamps[t * 24 + 20] = __builtin_readcyclecounter();
-  }
-
-  if (k_live) {
-    float* o = a.out + (unit * a.K + ok_) * (int64_t)D + 4 * oj;
-#pragma unroll
-    for (int m = 0; m < NA; ++m) *reinterpret_cast<f32x4*>(o + 64 * m) = acc[m];
-    if (oj == 0) a.cnt_part[unit * a.K + ok_] = my_count;
-  }
-}
-
-
 // ---- third structure: fp16 screening scores from register-resident centres + exact resolution of close calls ----
-// What bounds the two kernels above is the centre stream: 196 KB of normalised centres from L2 per 16-token tile and CU
+// What bounds the kernel above is the centre stream: 196 KB of normalised centres from L2 per 16-token tile and CU
 // (scoring 12 000 of 22 000 cycles per tile).  Here every wave keeps its D/8 slice of all 32 centres in REGISTERS as one
 // fp16 plane (48 VGPRs at D = 1536) and scores the tile on v_mfma_f32_16x16x32_f16 with the tokens split into two fp16
 // terms on the fly (x = hi + lo to ~2^-19): a screening score with a PROVEN error bound
@@ -757,11 +551,8 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   }
   __syncthreads();
 
-  const bool stamp = a.stamps && blockIdx.x == 0 && tid == 0;
-  const bool wstamp = a.stamps && blockIdx.x == 0 && lane == 0;
   for (int t = 0; t < ntiles; ++t) {
     const int valid = (int)imin64(TT, nrows - (int64_t)t * TT);
-    if (stamp) a.stamps[t * 24 + 0] = __builtin_readcyclecounter();
     if (tid == 0) *npairs = 0;                 // (read after barrier B; barrier A orders this store before the atomics)
     // The HBM loads of the next tile go out during scoring: scoring and assign wait for no vector memory, so by the time
     // the exact resolution or the VLAD gather wait for their own (L2) loads -- the counter retires in order -- these
@@ -802,10 +593,8 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
       if (fq == 0) rsqp[wave * TT + fr] = rs;
-      if (wstamp) a.stamps[t * 24 + 4 + wave] = __builtin_readcyclecounter();
     }
     lds_barrier();
-    if (stamp) a.stamps[t * 24 + 1] = __builtin_readcyclecounter();
 #pragma unroll
     for (int it = 0; it < 8 / SW; ++it) {
       // ---- assign: fixed-order sum of the SW partials; arg-max; candidates within the error bound ----
@@ -857,7 +646,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       }
     }
     lds_barrier();
-    if (stamp) a.stamps[t * 24 + 2] = __builtin_readcyclecounter();
     // ---- exact resolution: the queued (row, centre) pairs are dealt round-robin to the waves (a close row has 2-3
     //      candidates; dealing whole rows left most waves idle behind the one that had a row), each scored exactly in
     //      fp32 by a whole wave; then the rows' arg-max over their candidates' exact scores ----
@@ -911,7 +699,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       }
       lds_barrier();                           // (np is workgroup-uniform: with nothing queued, lab[] is final already)
     }
-    if (stamp) a.stamps[t * 24 + 21] = __builtin_readcyclecounter();
     {
       // ---- gather: every wave adds every token (in order) to its columns of the token's cluster ----
       const float* tp = tile + gcol;
@@ -982,12 +769,9 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         }
       }
     }
-    if (wstamp) a.stamps[t * 24 + 12 + wave] = __builtin_readcyclecounter();
     lds_barrier();
-    if (stamp) a.stamps[t * 24 + 3] = __builtin_readcyclecounter();
     if (t + 1 < ntiles) stash();
     lds_barrier();
-    if (stamp) a.stamps[t * 24 + 20] = __builtin_readcyclecounter();
   }
 
   const bool g_live = lane < GL;
@@ -1085,27 +869,8 @@ int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
     ANYLOC_HIP(hipMemsetAsync(a.part_tickets, 0, sizeof(unsigned) * units, stream));
     grid = (unsigned)(units * a.parts);
   }
-  FusedArgs b = a;
-  if (const char* e = getenv("ANYLOC_KM_STAMPS")) b.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * SW), lds, stream, b);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * SW), lds, stream, a);
   return launch_status("fused3_kernel");
-}
-
-template <int NV, int NGRQ>
-int launch_kmeans2(const FusedArgs& a, int64_t units, hipStream_t stream) {
-  constexpr int D = NV * 128;
-  const size_t lds = sizeof(float) * (TT * (D + 4) + 8 * TT * 32 + TT);
-  auto kern = kmeans_fused2_kernel<NV, NGRQ>;
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
-  ProfScope prof("kmeans_fused", stream, 2.0 * a.total * D * 32, 4.0 * ((double)a.total * D + 2.0 * (double)units * a.K * D));
-  FusedArgs b = a;
-  if (const char* e = getenv("ANYLOC_KM_STAMPS")) b.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
-  hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), lds, stream, b);
-  return launch_status("kmeans_fused2_kernel");
 }
 
 template <int NV, bool KMEANS>
@@ -1141,17 +906,10 @@ bool fused_supported(int64_t D, int64_t K) {
 int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream) {
   if (units <= 0) return ANYLOC_OK;
   ANYLOC_CHECK_ARG(units < (1ll << 31), "vlad_fused: too many units");
-  // ANYLOC_KMEANS_FUSED_V / ANYLOC_VLAD_FUSED_V (A/B switches): 0 (default) = fused3_kernel -- 8 waves where D / 128 is
-  // even, 4 waves otherwise; VLAD with more than two workgroups per image stays on vlad_fused_kernel (its hand-off epilogue
-  // is cheaper); 1 = vlad_fused_kernel (both modes), 2 = kmeans_fused2_kernel, 3 = fused3 with 4 waves, 4 = fused3 with 8
-  static int kv = -1, vv = -1;
-  if (kv < 0) {
-    const char* e = getenv("ANYLOC_KMEANS_FUSED_V");
-    kv = e ? atoi(e) : 0;
-    e = getenv("ANYLOC_VLAD_FUSED_V");
-    vv = e ? atoi(e) : 0;
-  }
-  const int ver = kmeans ? kv : vv;
+  // options kmeans_fused_v / vlad_fused_v (A/B, tests): 0 (default) = fused3_kernel -- 8 waves where D / 128 is even, 4 waves
+  // otherwise; VLAD with more than two workgroups per image stays on vlad_fused_kernel (its hand-off epilogue is cheaper);
+  // 1 = vlad_fused_kernel (both modes), 3 = fused3 with 4 waves, 4 = fused3 with 8
+  const int ver = (int)option(kmeans ? OPT_KMEANS_FUSED_V : OPT_VLAD_FUSED_V);
   const bool f3 = ver == 0 ? (kmeans || a.parts <= 2) : ver >= 3;
 #define ANYLOC_FUSED_CASE(NV)                                                                         \
   case NV * 128:                                                                                      \
@@ -1162,7 +920,6 @@ int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t strea
       }                                                                                               \
       return kmeans ? launch_fused3<NV, 4, true>(a, units, stream) : launch_fused3<NV, 4, false>(a, units, stream);     \
     }                                                                                                 \
-    if (kmeans && ver == 2) return launch_kmeans2<NV, 4>(a, units, stream);                           \
     return kmeans ? launch_fused<NV, true>(a, units, stream) : launch_fused<NV, false>(a, units, stream);
   switch (a.D) {
     ANYLOC_FUSED_CASE(3)

@@ -32,14 +32,6 @@ def _on_device(device):
     return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
-def _graph_max_rows():
-    """HIP-graph replay threshold in token rows (0 = off, the default: on ROCm 7.2 a replayed graph of the ~220 dependent
-    launches of a ViT-g forward, or the ~75 of a ViT-S forward, takes exactly as long as the launches themselves --
-    profiles/r02_hipgraph_small_batch.log -- the gap between dependent kernels is paid inside the graph as well)."""
-    e = os.environ.get("ANYLOC_VIT_GRAPH_MAX_ROWS")
-    return int(e) if e else 0
-
-
 def interpolate_pos_embed(pos_embed, h_img, w_img):
     """Positional table for an ``h_img x w_img`` input: [1, 1+37*37, D] ->
     [1 + (h/14)*(w/14), D].  Input-independent, computed once per resolution on
@@ -88,7 +80,6 @@ class HipDinoV2:
             return t
         self.pos_embed_host = state_dict["pos_embed"].detach().to("cpu", torch.float32)
         self._pos_cache = {}
-        self._graph_io = {}      # (B, H, W, taps, cls, stream) -> (input, output) buffers a captured HIP graph is bound to
         patch_w = keep(state_dict["patch_embed.proj.weight"].reshape(dim, 3 * PATCH * PATCH))
         patch_b = keep(state_dict["patch_embed.proj.bias"])
         cls = keep(state_dict["cls_token"].reshape(dim))
@@ -165,12 +156,6 @@ class HipDinoV2:
                 pass
             self._handle = None
 
-    def graph_stats(self):
-        """(instantiated HIP graphs, graph launches so far) of this model's handle (ANYLOC_VIT_GRAPH)."""
-        n, r = C.c_int64(), C.c_int64()
-        _lib.check(_lib.load().anyloc_vit_graph_stats(self._handle, C.byref(n), C.byref(r)), "anyloc_vit_graph_stats")
-        return n.value, r.value
-
     def eval(self):
         return self
 
@@ -241,25 +226,9 @@ class HipDinoV2:
         flags = (ops.VIT_USE_CLS if use_cls else 0) | (ops.VIT_NORM_TAPS if norm_taps else 0) | \
             (ops.VIT_NORM_CONCAT if norm_concat else 0) | (ops.VIT_SPLIT_BF16 if self.gemm == "x6" else 0) | \
             (ops.VIT_SPLIT_FP16 if self.gemm == "h3" else 0)
-        # Opt-in: below ANYLOC_VIT_GRAPH_MAX_ROWS token rows the launch sequence is replayed as ONE HIP graph (csrc/vit.hip,
-        # ANYLOC_VIT_GRAPH).  A graph is bound to its pointers, so those calls go through an input / output pair owned by
-        # this object, per shape; the caller gets a copy.
-        io = None
-        if B * (np_ + 1) <= _graph_max_rows() and not torch.cuda.is_current_stream_capturing():
-            key = (B, H, W, n_taps, use_cls, torch.cuda.current_stream().cuda_stream)
-            io = self._graph_io.get(key)
-            if io is None:
-                if len(self._graph_io) >= 8:
-                    self._graph_io.pop(next(iter(self._graph_io)))
-                io = self._graph_io[key] = (torch.empty_like(img), torch.empty_like(out))
-            io[0].copy_(img)
-            img, flags = io[0], flags | ops.VIT_GRAPH
-        dst = out if io is None else io[1]
         _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
-                                          n_taps, layers, facets, flags, _lib.ptr(dst), _lib.ptr(ws),
+                                          n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
                                           ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")
-        if io is not None:
-            out.copy_(io[1])
         return out
 
 

@@ -14,7 +14,7 @@ VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
 VLAD_EUCLIDEAN = 4
 FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
-VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16, VIT_GRAPH = 1, 2, 4, 8, 16, 32
+VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1, 2, 4, 8, 16
 
 
 def _f32c(t, device=None):
@@ -341,6 +341,37 @@ def topk(queries, db, k, metric="ip", index_base=0, normalize_db=False):
                                _lib.ptr(dist), _lib.ptr(idx),
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "anyloc_topk")
     return dist, idx
+
+
+# ---- tuning options (anyloc_set_option; names in include/anyloc_hip.h) ----------------
+def set_option(name, value):
+    _lib.check(_lib.load().anyloc_set_option(name.encode(), int(value)), f"anyloc_set_option({name})")
+
+
+def get_option(name):
+    import ctypes
+    v = ctypes.c_int64()
+    _lib.check(_lib.load().anyloc_get_option(name.encode(), ctypes.byref(v)), f"anyloc_get_option({name})")
+    return v.value
+
+
+class options:
+    """``with ops.options(vlad_parts=4, h3_fuse=0): ...`` -- set library options for a block and restore the previous
+    values afterwards (A/B measurements and the tests that compare kernel variants)."""
+
+    def __init__(self, **kw):
+        self.new, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.new.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 # ---- profiler ----------------------------------------------------------------

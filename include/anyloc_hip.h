@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 2
+#define ANYLOC_ABI_VERSION 3
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -43,6 +43,31 @@ typedef enum anyloc_status {
 
 int anyloc_version(void);
 const char* anyloc_last_error(void);
+
+/* ------------------------------------------------------------ options ----
+ * Process-wide integer tuning options of the host-side dispatch (tile shapes,
+ * thresholds between kernel variants, the unfused data flows kept for A/B
+ * measurements and tests).  Defaults are the measured winners; nothing on a
+ * call path reads the environment.  The one environment variable,
+ * ANYLOC_OPTIONS="name=value,name=value", is parsed once, when the first
+ * option is looked up (and again by anyloc_reset_options).  Names:
+ *   gemm_f32_cfg x6_cfg h3_cfg        tile configuration of the three GEMM kernels (0 = default)
+ *   h3_group_m (8)                    gemm_h3 tile rows per XCD scheduling group
+ *   h3_tiny_max (256) h3_deep_max (320) h3_deep2_max (500)
+ *                                     gemm_h3 small-problem tile / ring-depth thresholds (tile counts)
+ *   h3_epi_lds (1)                    LayerScale-residual epilogue with 16-byte accesses through LDS
+ *   ln_small_rows (4096)              layernorm_h2: one row per wave below this many rows
+ *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
+ *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
+ *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
+ *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
+ *                                     which VLAD / k-means kernel serves a call
+ *   kmeans_max_chunks (0 = two per CU)
+ * Unknown names are rejected (ANYLOC_ERR_INVALID_ARG).  Not thread-safe against
+ * concurrent launches that read the option being changed. */
+int anyloc_set_option(const char* name, int64_t value);
+int anyloc_get_option(const char* name, int64_t* value /*host*/);
+int anyloc_reset_options(void);      /* defaults, then ANYLOC_OPTIONS */
 
 /* ---------------------------------------------------------------- rows ---
  * out[r,:] = x[r,:] / max(||x[r,:]||_2, eps)      (torch F.normalize, eps 1e-12)
@@ -320,13 +345,6 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*ho
 #define ANYLOC_VIT_NORM_TAPS 2u      /* L2-normalise each tap (utilities.py:282-283) */
 #define ANYLOC_VIT_NORM_CONCAT 4u    /* L2-normalise the concatenated taps again
                                         (scripts/dino_v2_vlad_viz.py:175-196) */
-#define ANYLOC_VIT_GRAPH 32u         /* replay the launch sequence as one HIP graph: the first call with a given
-                                        (shape, taps, flags, img / pos / out / workspace pointers) runs as usual, the
-                                        second captures it, later ones are a single hipGraphLaunch on `stream`.  For
-                                        launch-latency-bound calls (one or two images, as the reference's scripts call
-                                        the extractor, utilities.py:263-285); needs stable pointers to pay off and is
-                                        ignored while anyloc_profile_enable(1) is in effect.  Results are those of the
-                                        plain call (same kernels, same order). */
 
 size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch,
                                   int64_t img_h, int64_t img_w);
@@ -339,9 +357,6 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch,
                        int32_t n_taps, const int32_t* tap_layers,
                        const int32_t* tap_facets, unsigned flags, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
-
-/* ANYLOC_VIT_GRAPH bookkeeping: instantiated graphs held by the handle, graph launches so far. */
-int anyloc_vit_graph_stats(const anyloc_vit_t* h, int64_t* graphs, int64_t* replays);
 
 /* Name and average device time (ms, HIP events on the launch stream) of the
  * kernels issued by the most recent call with profiling enabled; used by

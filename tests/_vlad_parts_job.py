@@ -1,8 +1,8 @@
-"""Run by tests/test_gpu_vlad_topk.py::test_vlad_fused_parts in a subprocess (the path switches are read once per
-process): hard VLAD through the fused kernel with the environment's ANYLOC_VLAD_PARTS / ANYLOC_VLAD_TWO_PASS /
-ANYLOC_VLAD_FUSED_V against the CPU oracle, the same workspace reused across calls with different inputs (the reducing
+"""Run by tests/test_gpu_vlad_topk.py::test_vlad_fused_parts in a subprocess (a fresh process,
+configured through ANYLOC_OPTIONS): hard VLAD through the fused kernel with the options vlad_parts / vlad_two_pass /
+vlad_fused_v against the CPU oracle, the same workspace reused across calls with different inputs (the reducing
 workgroup of one call has the previous call's partial sums in its L1: the agent-scope acquire has to drop them); and one
-k-means step (ANYLOC_KMEANS_FUSED_V) on inputs chosen to hit the close-call logic of the fp16-screening kernel:
+k-means step (option kmeans_fused_v) on inputs chosen to hit the close-call logic of the fp16-screening kernel:
 isotropic rows (top-2 gaps of ~1e-3), duplicated centres (exact ties), zero / tiny / huge rows."""
 import sys
 

@@ -26,6 +26,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _library_options_back_to_defaults():
+    """Tests flip library options (anyloc_set_option) to compare kernel variants: every test starts from the defaults
+    (+ ANYLOC_OPTIONS) again."""
+    yield
+    from anyloc_amd import _lib
+    if _lib._lib is not None:
+        _lib._lib.anyloc_reset_options()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

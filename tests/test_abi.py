@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.anyloc_version() == 2      # ANYLOC_ABI_VERSION of include/anyloc_hip.h
+    assert lib.anyloc_version() == 3      # ANYLOC_ABI_VERSION of include/anyloc_hip.h
     assert isinstance(lib.anyloc_last_error(), bytes)
 
 
@@ -75,3 +75,21 @@ def test_product_does_not_import_oracle():
     if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
         bad.append("utilities.py")
     assert not bad, bad
+
+
+def test_options_registry_needs_no_gpu(lib):
+    """anyloc_set_option / anyloc_get_option / anyloc_reset_options: named integers with documented defaults, unknown
+    names rejected; ANYLOC_OPTIONS is the library's only environment variable (csrc/runtime.hip)."""
+    v = ctypes.c_int64()
+    assert lib.anyloc_reset_options() == 0
+    assert lib.anyloc_get_option(b"h3_group_m", ctypes.byref(v)) == 0 and v.value == 8
+    assert lib.anyloc_set_option(b"h3_group_m", 4) == 0
+    assert lib.anyloc_get_option(b"h3_group_m", ctypes.byref(v)) == 0 and v.value == 4
+    assert lib.anyloc_set_option(b"no_such_option", 1) == -1 and b"no_such_option" in lib.anyloc_last_error()
+    assert lib.anyloc_reset_options() == 0
+    assert lib.anyloc_get_option(b"h3_group_m", ctypes.byref(v)) == 0 and v.value == 8
+    for name in (b"h3_fuse", b"x6_min_rows", b"vlad_parts", b"attn_x6", b"kmeans_max_chunks"):
+        assert lib.anyloc_get_option(name, ctypes.byref(v)) == 0
+    import glob
+    n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "anyloc_amd", "csrc", "*")))
+    assert n_getenv == 1

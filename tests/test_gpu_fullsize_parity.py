@@ -162,10 +162,11 @@ def test_vitl_518_two_taps_vs_oracle(vitl_taps, mode, monkeypatch):
 
 
 def test_fused_and_unfused_h3_agree(vitg_plain, monkeypatch):
-    """A/B switch of the fused fp16-plane producers (ANYLOC_H3_FUSE=0: fp32 activations + separate
+    """A/B switch of the fused fp16-plane producers (option h3_fuse = 0: fp32 activations + separate
     quantiser passes): both meet the oracle bar and agree with each other far inside it."""
     t1 = _run_mode(vitg_plain, "h3", monkeypatch)[0]
-    monkeypatch.setenv("ANYLOC_H3_FUSE", "0")
+    from anyloc_amd import ops
+    ops.set_option("h3_fuse", 0)
     t0 = _run_mode(vitg_plain, "h3", monkeypatch)[0]
     assert float((t0 - vitg_plain.tok32).abs().max()) <= TOKEN_ATOL
     assert float((t1 - t0).abs().max()) <= 2e-6

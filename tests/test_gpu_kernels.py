@@ -75,9 +75,9 @@ def test_layernorm(dev, rows, dim):
 @pytest.mark.parametrize("B,T,heads", [(2, 257, 6), (1, 530, 24), (3, 33, 2), (1, 128, 1), (2, 1370, 2)])
 def test_attention(dev, B, T, heads, kernel, monkeypatch):
     """Both attention kernels behind anyloc_attention against float64: the exact-fp32 MFMA one and the
-    six-product split-bf16 one the x6 / h3 forwards use (ANYLOC_ATTN_X6 is read at every call)."""
+    six-product split-bf16 one the x6 forward uses (option attn_x6 selects it for anyloc_attention)."""
     from anyloc_amd import ops
-    monkeypatch.setenv("ANYLOC_ATTN_X6", "1" if kernel == "split-bf16" else "0")
+    ops.set_option("attn_x6", 1 if kernel == "split-bf16" else 0)
     D = heads * 64
     g = torch.Generator().manual_seed(B * T + heads)
     qkv = torch.randn(B, T, 3 * D, generator=g) * 1.5

@@ -153,32 +153,11 @@ def test_config1_pipeline_through_reference_surface(g1, c1, capsys):
     capsys.readouterr()
 
 
-def test_hip_graph_replay_is_bit_equal(c1, monkeypatch):
-    """ANYLOC_VIT_GRAPH (csrc/vit.hip): the launch sequence of a small-batch forward, captured into a HIP graph on the
-    second call with a key and replayed afterwards, produces exactly the tokens of the plain launches -- on changing
-    inputs (the graph is bound to the extractor's own input / output pair), for two shapes held at the same time."""
-    import utilities
-    sd, imgs, _ = c1
-    ext = utilities.DinoV2ExtractFeatures("dinov2_vits14", 9, "value", device=DEV)
-    batches = [imgs[0:1], imgs[1:2], imgs[2:3], imgs[3:5], imgs[5:7], imgs[0:1]]
-    monkeypatch.setenv("ANYLOC_VIT_GRAPH_MAX_ROWS", "0")
-    want = [ext(b.to(DEV)).clone() for b in batches]
-    assert ext.dino_model.graph_stats() == (0, 0)
-    monkeypatch.setenv("ANYLOC_VIT_GRAPH_MAX_ROWS", "1000")
-    got = [ext(b.to(DEV)).clone() for b in batches]
-    graphs, replays = ext.dino_model.graph_stats()
-    assert graphs == 2 and replays == 4          # B=1: eager, capture+launch, replay, replay; B=2: eager, capture+launch
-    for w, g in zip(want, got):
-        assert torch.equal(w, g)
-    big = torch.cat([imgs[:6]]).to(DEV)          # above the threshold: plain launches, no new graph
-    assert ext(big).shape[0] == 6 and ext.dino_model.graph_stats() == (graphs, replays)
-
-
 @pytest.mark.parametrize("batch", [1, 2])
 def test_small_batch_kernels_are_bitwise_the_plain_ones(batch, monkeypatch):
     """One or two images run 64x64 GEMM tiles with four / two k-blocks per ring stage (proj, fc2) and a LayerNorm with one
     row per wave (csrc/gemm_h3.hip): scheduling changes only -- the tokens must equal, bit for bit, those of the kernels
-    with one k-block per stage and four rows per wave (ANYLOC_H3_DEEP_MAX=0 ANYLOC_H3_DEEP2_MAX=0 ANYLOC_LN_SMALL_ROWS=0)."""
+    with one k-block per stage and four rows per wave (options h3_deep_max = h3_deep2_max = ln_small_rows = 0)."""
     import utilities
     name = "dinov2_vitg14"
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device=DEV, depth=3))
@@ -186,9 +165,9 @@ def test_small_batch_kernels_are_bitwise_the_plain_ones(batch, monkeypatch):
         ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
         img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(batch)).to(DEV)
         got = ext(img).clone()
-        for var in ("ANYLOC_H3_DEEP_MAX", "ANYLOC_H3_DEEP2_MAX", "ANYLOC_LN_SMALL_ROWS"):
-            monkeypatch.setenv(var, "0")
-        want = ext(img).clone()
+        from anyloc_amd import ops
+        with ops.options(h3_deep_max=0, h3_deep2_max=0, ln_small_rows=0):
+            want = ext(img).clone()
         assert torch.isfinite(got).all() and torch.equal(got, want)
     finally:
         weights.unregister_state_dict(name)

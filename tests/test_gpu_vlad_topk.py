@@ -96,22 +96,19 @@ def test_vlad_hard_vs_oracle_flags_and_ragged(K, D, N):
         assert l2rel(out[i], vlad_ref.vlad_hard(parts[i], centers)[0]) < VLAD_RTOL
 
 
-@pytest.mark.parametrize("env", [{"ANYLOC_VLAD_PARTS": "1"}, {"ANYLOC_VLAD_PARTS": "3"}, {"ANYLOC_VLAD_PARTS": "8"},
-                                 {"ANYLOC_VLAD_PARTS": "40"}, {}, {"ANYLOC_VLAD_TWO_PASS": "1"},
-                                 {"ANYLOC_VLAD_FUSED_V": "1", "ANYLOC_KMEANS_FUSED_V": "1"},
-                                 {"ANYLOC_VLAD_FUSED_V": "3", "ANYLOC_KMEANS_FUSED_V": "3", "ANYLOC_VLAD_PARTS": "2"},
-                                 {"ANYLOC_VLAD_FUSED_V": "4", "ANYLOC_KMEANS_FUSED_V": "4", "ANYLOC_VLAD_PARTS": "5"},
-                                 {"ANYLOC_KMEANS_FUSED_V": "2"}])
-def test_vlad_fused_parts(env):
+@pytest.mark.parametrize("opts", ["vlad_parts=1", "vlad_parts=3", "vlad_parts=8", "vlad_parts=40", "", "vlad_two_pass=1",
+                                  "vlad_fused_v=1,kmeans_fused_v=1", "vlad_fused_v=3,kmeans_fused_v=3,vlad_parts=2",
+                                  "vlad_fused_v=4,kmeans_fused_v=4,vlad_parts=5"])
+def test_vlad_fused_parts(opts):
     """The fused VLAD kernels with 1 / 3 / 8 / 40 (more parts than tiles) workgroups per image, their own choice, every
-    kernel version (ANYLOC_*_FUSED_V: the exact-score kernels 1 / 2, the fp16-screening kernel with 4 and 8 waves) and
-    the two-pass path: each against the oracle, bitwise reproducible run to run; plus one k-means step on close-call
-    inputs (tests/_vlad_parts_job.py)."""
+    kernel version (options *_fused_v: the exact-score kernel 1, the fp16-screening kernel with 4 and 8 waves) and the
+    two-pass path: each against the oracle, bitwise reproducible run to run; plus one k-means step on close-call inputs
+    (tests/_vlad_parts_job.py, a fresh process configured through ANYLOC_OPTIONS)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+    e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), ANYLOC_OPTIONS=opts)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "_vlad_parts_job.py")], env=e, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok worst=" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from anyloc_amd import synth, weights
+from anyloc_amd import ops as ops_mod
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -115,24 +116,19 @@ def test_gemm_h3_as_accurate_as_fp32(M, N, K):
 
 @pytest.mark.parametrize("name,layer,depth,hw", [("dinov2_vitg14", 1, 2, (322, 322)), ("dinov2_vits14", 5, 6, (224, 308))])
 def test_h3_epilogue_and_quantiser_variants_are_bit_identical(monkeypatch, name, layer, depth, hw):
-    """The LDS-transposed 16-byte LayerScale-residual epilogue vs the dword one (ANYLOC_H3_EPI_LDS=0), and the
-    streaming two-pass quantiser for wide rows vs the rows-in-registers one (ANYLOC_H2_REG=1), do the same
+    """The LDS-transposed 16-byte LayerScale-residual epilogue vs the dword one (option h3_epi_lds = 0) does the same
     arithmetic in the same order: identical bits."""
     import utilities
     monkeypatch.setenv("ANYLOC_GEMM", "h3")
-    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+    ops_mod.set_option("x6_min_rows", 0)
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, depth=depth))
     try:
         imgs = torch.cat(synth.synthetic_places(4, 1, hw[0], hw[1], seed=13)[:2]).to(DEV)
         base = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
-        monkeypatch.setenv("ANYLOC_H3_EPI_LDS", "0")
-        a = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
-        monkeypatch.delenv("ANYLOC_H3_EPI_LDS")
-        monkeypatch.setenv("ANYLOC_H2_REG", "1")
-        b = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
+        with ops_mod.options(h3_epi_lds=0):
+            a = utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False, device=DEV)(imgs)
         assert torch.isfinite(base).all()
         assert torch.equal(base, a)
-        assert torch.equal(base, b)
     finally:
         weights.unregister_state_dict()
 
@@ -152,7 +148,7 @@ def test_gemm_x6_deterministic_and_tail_rows_untouched():
 @pytest.mark.parametrize("name,layer,depth", [("dinov2_vits14", 9, None), ("dinov2_vitg14", 1, 2)])
 def test_vit_tokens_agree_between_gemm_modes(monkeypatch, name, layer, depth):
     import utilities
-    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")        # small test batches: force the split-bf16 kernels
+    ops_mod.set_option("x6_min_rows", 0)        # small test batches: force the split-bf16 kernels
     sd = synth.synthetic_state_dict(name, 0, depth=depth)
     weights.register_state_dict(name, sd)
     try:
@@ -176,17 +172,17 @@ def test_vit_tokens_agree_between_gemm_modes(monkeypatch, name, layer, depth):
                                                  ("dinov2_vitl14", 2, 3, (70, 98))])
 def test_fused_plane_producers_equal_split_passes(monkeypatch, name, layer, depth, hw):
     """LayerNorm / attention / GELU-SwiGLU epilogue writing the plane image directly vs fp32 activations + a
-    split pass (ANYLOC_X6_FUSE=0).  The split is exact, so the only difference is LayerNorm's reduction order
+    split pass (option x6_fuse = 0).  The split is exact, so the only difference is LayerNorm's reduction order
     (per-wave rows vs per-block rows): a few ulp on unit-norm tokens."""
     import utilities
     monkeypatch.setenv("ANYLOC_GEMM", "x6")
-    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+    ops_mod.set_option("x6_min_rows", 0)
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, depth=depth))
     try:
         imgs = torch.cat(synth.synthetic_places(4, 1, hw[0], hw[1], seed=9)[:2]).to(DEV)
         res = {}
         for fuse in ("1", "0"):
-            monkeypatch.setenv("ANYLOC_X6_FUSE", fuse)
+            ops_mod.set_option("x6_fuse", int(fuse))
             res[fuse] = (utilities.DinoV2ExtractFeatures(name, layer, "value", device=DEV)(imgs),
                          utilities.DinoV2ExtractFeatures(name, layer, "token", use_cls=True, norm_descs=False,
                                                          device=DEV)(imgs))
@@ -200,7 +196,7 @@ def test_fused_plane_producers_equal_split_passes(monkeypatch, name, layer, dept
 def test_golden_tokens_in_fp32_mfma_mode(monkeypatch, golden_dir):
     """The exact-fp32 MFMA path stays a supported mode (ANYLOC_GEMM=f32): same golden vector, same tolerance."""
     import utilities
-    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+    ops_mod.set_option("x6_min_rows", 0)
     g1 = np.load(os.path.join(golden_dir, "config1_vits14_l9_value_k8.npz"))
     name = str(g1["model"])
     weights.register_state_dict(name, synth.synthetic_state_dict(name, int(g1["weights_seed"])))
@@ -217,7 +213,7 @@ def test_golden_tokens_in_fp32_mfma_mode(monkeypatch, golden_dir):
 
 
 def test_small_batches_take_the_fp32_mfma_kernels(monkeypatch):
-    """Below ANYLOC_X6_MIN_ROWS token rows (default 1600, i.e. B <= 3 at 322x322) a split-bf16 forward runs the
+    """Below option x6_min_rows token rows (default 1600, i.e. B <= 3 at 322x322) a split-bf16 forward runs the
     exact-fp32 kernels (more, smaller tiles): bit-identical to ANYLOC_GEMM=f32, and different bits from the forced
     split-bf16 run of the same batch."""
     import utilities
@@ -227,7 +223,7 @@ def test_small_batches_take_the_fp32_mfma_kernels(monkeypatch):
         img = synth.synthetic_places(1, 0, 224, 224, seed=3)[0].to(DEV)            # 257 rows
         monkeypatch.setenv("ANYLOC_GEMM", "x6")
         auto = utilities.DinoV2ExtractFeatures(name, 3, "value", device=DEV)(img)
-        monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+        ops_mod.set_option("x6_min_rows", 0)
         forced = utilities.DinoV2ExtractFeatures(name, 3, "value", device=DEV)(img)
         monkeypatch.setenv("ANYLOC_GEMM", "f32")
         exact = utilities.DinoV2ExtractFeatures(name, 3, "value", device=DEV)(img)
@@ -241,7 +237,7 @@ def test_large_batches_are_chunked_below_the_plane_image_limit(monkeypatch):
     """One operand's plane image must stay inside 2 GiB of buffer addressing: the extractor splits the batch
     (``max_rows``); chunked and unchunked results are identical."""
     from anyloc_amd import extractor
-    monkeypatch.setenv("ANYLOC_X6_MIN_ROWS", "0")
+    ops_mod.set_option("x6_min_rows", 0)
     name = "dinov2_vits14"
     model = extractor.HipDinoV2(name, synth.synthetic_state_dict(name, 0, depth=3), torch.device(DEV), gemm="x6")
     imgs = torch.cat(synth.synthetic_places(6, 1, 112, 140, seed=2)[:2]).to(DEV)       # 7 images x 81 tokens

@@ -1,4 +1,4 @@
-"""Attention variants (ANYLOC_ATTN_CFG): time + error vs fp64 on the ViT-g shape."""
+"""Attention variants (ANYLOC_OPTIONS=attn_cfg=<n>): time + error vs fp64 on the ViT-g shape."""
 import os
 import sys
 import time
@@ -25,4 +25,4 @@ q, k, v = qkv[:4].double().reshape(4, T, 3, H, 64).permute(2, 0, 3, 1, 4)
 ref = (torch.softmax((q * 0.125) @ k.transpose(-2, -1), dim=-1) @ v).transpose(1, 2).reshape(4, T, H * 64)
 err = float((out[:4].double() - ref).abs().max())
 rel = float((out[:4].double() - ref).norm() / ref.norm())
-print(f"cfg{os.environ.get('ANYLOC_ATTN_CFG', '0')}: {dt*1e3:7.3f} ms  {4.0*B*H*T*T*64/dt/1e12:6.1f} TF/s  max abs err {err:.2e}  rel {rel:.2e}", flush=True)
+print(f"options[{os.environ.get('ANYLOC_OPTIONS', '')}]: {dt*1e3:7.3f} ms  {4.0*B*H*T*T*64/dt/1e12:6.1f} TF/s  max abs err {err:.2e}  rel {rel:.2e}", flush=True)

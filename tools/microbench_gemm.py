@@ -1,4 +1,4 @@
-"""GEMM tile-configuration sweep on the GPU box: ANYLOC_GEMM_CFG=<n> python tools/microbench_gemm.py [B]"""
+"""GEMM tile-configuration sweep on the GPU box: ANYLOC_OPTIONS=gemm_f32_cfg=<n> python tools/microbench_gemm.py [B]"""
 import os
 import sys
 import time
@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda")
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     M = B * 530
-    cfg = os.environ.get("ANYLOC_GEMM_CFG", "0")
+    cfg = os.environ.get("ANYLOC_OPTIONS", "")
     line = [f"cfg{cfg} B={B}"]
     tot_t, tot_f = 0.0, 0.0
     for (m, n, k, w) in [(M, 4608, 1536, 1), (M, 1536, 1536, 1), (M, 8192, 1536, 1), (M, 1536, 4096, 1),

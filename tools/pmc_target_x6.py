@@ -23,7 +23,7 @@ for _ in range(6):
 torch.cuda.synchronize()
 qkv = torch.randn(61, 530, 3 * 1536, device=dev)
 for mode in ("1", "0"):
-    os.environ["ANYLOC_ATTN_X6"] = mode
+    ops.set_option("attn_x6", int(mode))
     for _ in range(4):
         ops.attention(qkv, 24)
 torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""Time the two-term fp16 GEMM (ANYLOC_H3_CFG from the environment) on the ViT-g block shapes at the bench batch and
+"""Time the two-term fp16 GEMM (ANYLOC_OPTIONS=h3_cfg=<n>,h3_group_m=<g> from the environment) on the ViT-g block shapes at the bench batch and
 check it against float64 on a row sample.  One JSON line per shape."""
 import json
 import os
@@ -31,5 +31,5 @@ for (N, K) in ((4608, 1536), (1536, 1536), (8192, 1536), (1536, 4096)):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
-    print(json.dumps(dict(cfg=os.environ.get("ANYLOC_H3_CFG", "0"), M=M, N=N, K=K, ms=round(ms, 4),
+    print(json.dumps(dict(cfg=os.environ.get("ANYLOC_OPTIONS", ""), M=M, N=N, K=K, ms=round(ms, 4),
                           tflops=round(2.0 * M * N * K / ms / 1e9, 1), err=err)), flush=True)

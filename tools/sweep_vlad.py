@@ -1,5 +1,5 @@
 """VLAD (K=32, 529 x 1536 tokens per image) and one k-means step: fused single-launch kernel vs the two-pass path.
-usage: python tools/sweep_vlad.py [kmeans_rows]      env ANYLOC_VLAD_TWO_PASS=1 / ANYLOC_VLAD_PARTS=n select the path"""
+usage: python tools/sweep_vlad.py [kmeans_rows]      env ANYLOC_OPTIONS=vlad_two_pass=1 / vlad_parts=n selects the path"""
 import json
 import os
 import sys
@@ -24,7 +24,7 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n
 
 
-mode = "two_pass" if os.environ.get("ANYLOC_VLAD_TWO_PASS") == "1" else "fused parts=" + os.environ.get("ANYLOC_VLAD_PARTS", "auto")
+mode = "options[" + os.environ.get("ANYLOC_OPTIONS", "") + "]"
 for n_img in (1, 4, 16, 61, 122, 256, 1024):
     x = synth.clustered_tokens(n_img, N, D, n_modes=K, seed=3, device=dev)
     ms = timeit(lambda: ops.vlad(x, centers))

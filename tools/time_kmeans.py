@@ -32,6 +32,6 @@ for (rows, D, K) in shapes:
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
-    print(json.dumps(dict(v=os.environ.get("ANYLOC_KMEANS_FUSED_V", "default"), data="clustered" if clustered else "isotropic", rows=rows, D=D, K=K, ms=round(ms, 3),
+    print(json.dumps(dict(v=os.environ.get("ANYLOC_OPTIONS", "default"), data="clustered" if clustered else "isotropic", rows=rows, D=D, K=K, ms=round(ms, 3),
                           tb_s=round(rows * D * 4 / 1e9 / ms, 3))), flush=True)
     del x
