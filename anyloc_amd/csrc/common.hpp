@@ -73,6 +73,8 @@ enum Option {
   OPT_VLAD_FUSED_V,      // fused VLAD kernel: 0 = default choice, 1 = exact-score kernel, 3 / 4 = screening kernel with 4 / 8 waves
   OPT_KMEANS_FUSED_V,    // the same for the k-means step
   OPT_KMEANS_MAX_CHUNKS, // k-means: upper limit of row chunks (partial sums); 0 = two per CU
+  OPT_H3_FAST_SILU,      // fused SwiGLU epilogue of the h3 w12 GEMM: SiLU on v_exp_f32 + v_rcp_f32 instead of expf + IEEE division
+  OPT_TOPK_H3,           // retrieval score panels on the two-term fp16 GEMM: -1 = where it pays, 0 = never, 1 = wherever possible
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -190,6 +192,7 @@ struct H3Problem {
   const float* bias;
   const float* gamma;                       // EPI_LS_RESID
   const float* resid;                       // EPI_LS_RESID, leading dim ldc
+  int fast_silu;                            // EPI_SWIGLU_H2: SiLU on v_exp_f32 / v_rcp_f32 (set by gemm_h3 from option h3_fast_silu)
   int epi_lds;                              // EPI_LS_RESID: transposed 16-byte epilogue through LDS (set by gemm_h3)
   int group_m;                              // tile-rows per XCD scheduling group (set by gemm_h3)
   // EPI_QKV_PLANES: N = 3 * heads * 64; see QkvPlanes below
@@ -212,6 +215,9 @@ inline size_t qkv_planes_bytes(int64_t rows, int heads) { return (size_t)3 * hea
 inline size_t qkv_inv_count(int64_t rows, int heads) { return (size_t)3 * heads * ((rows + 31) / 32); }
 size_t h2_bytes(int64_t rows, int64_t K);
 int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream);
+// rows of any width (K % 16 == 0; used above 4096 columns): also returns the rows' sums of squares when row_sumsq != nullptr
+int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, float* row_sumsq,
+                  hipStream_t stream);
 // bound (HOST array of 4 floats) != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
 // (Cauchy-Schwarz: |fc1 output| <= ||ln(x)||_2 * max_j ||W_j||_2 + max |b|), bound = {gate_norm, gate_bias, val_norm, val_bias}
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,

@@ -71,6 +71,12 @@ __device__ __forceinline__ void h2_pack2(float a, float b, unsigned& hi, unsigne
 
 __device__ __forceinline__ float h3_gelu_erf(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float h3_silu(float v) { return v / (1.0f + expf(-v)); }
+// the same on the hardware transcendentals: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each -- ~5 instructions instead of ~25
+// (expf's range reduction + an IEEE division).  |error| <= ~3 ulp of silu(v), i.e. below the 2^-22 quantisation the value
+// gets on its way into the fc2 operand image.  v -> -inf: exp2 -> +inf, rcp -> 0, v * 0 = -0; v -> +inf: exp2 -> 0, v * 1.
+__device__ __forceinline__ float h3_silu_fast(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 
 template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p, int tiles_m, int tiles_n) {
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
             for (int r = 0; r < 16; ++r) {
               const float g = acc[mi][nj][r] * (ai[r] * sg) + bg;
               const float v = acc[mi][nj + 1][r] * (ai[r] * sv) + bv;
-              st[((r & 3) + 8 * (r >> 2) + 4 * hl) * 68 + (nj / 2) * 32 + (lane & 31)] = h3_silu(g) * v * cs[r];
+              st[((r & 3) + 8 * (r >> 2) + 4 * hl) * 68 + (nj / 2) * 32 + (lane & 31)] =
+                  (p.fast_silu ? h3_silu_fast(g) : h3_silu(g)) * v * cs[r];
             }
           }
         } else {
@@ -550,6 +557,87 @@ __global__ __launch_bounds__(256) void split_h2_stream_kernel(const float* __res
   }
 }
 
+// ---- very wide rows (retrieval: K = 49 152 VLAD columns; any K % 16 == 0 above 4096) -- two kernels, both with one
+// workgroup per small unit of work so that thousands of them stream HBM: (1) one workgroup per row finds the row's largest
+// magnitude (-> the power-of-two scale) and its sum of squares (the caller's F.normalize / L2 terms come out of the
+// same read); (2) one workgroup per (16 rows, 2048 columns) quantises with the scales of (1).
+__global__ __launch_bounds__(256) void row_amax_sq_kernel(const float* __restrict__ x, int64_t ldx, int64_t dim,
+                                                          float* __restrict__ inv, float* __restrict__ ss) {
+  __shared__ float red_m[4], red_s[4];
+  const f32x4* r = reinterpret_cast<const f32x4*>(x + (int64_t)blockIdx.x * ldx);
+  const int64_t n4 = dim >> 2;
+  float amax = 0.f, sq = 0.f;
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {        // four 16-byte loads in flight per thread
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = i + 256 * u;
+      if (j < n4) t[u] = r[j];
+      else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(t[u][0]), fabsf(t[u][1])), fmaxf(fabsf(t[u][2]), fabsf(t[u][3]))));
+      sq += (t[u][0] * t[u][0] + t[u][1] * t[u][1]) + (t[u][2] * t[u][2] + t[u][3] * t[u][3]);
+    }
+  }
+  amax = wave_max(amax);
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) {
+    red_m[threadIdx.x >> 6] = amax;
+    red_s[threadIdx.x >> 6] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float iv;
+    h2_row_scale(fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])), iv);
+    inv[blockIdx.x] = iv;
+    if (ss) ss[blockIdx.x] = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+  }
+}
+
+constexpr int WIDE_CHUNKS = 8;      // 256-column chunks per workgroup of the quantising kernel
+
+__global__ __launch_bounds__(256) void split_h2_wide_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
+                                                            unsigned char* __restrict__ out, const float* __restrict__ inv,
+                                                            int64_t R) {
+  __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int c0 = blockIdx.y * WIDE_CHUNKS;
+  const int nchunks = min(WIDE_CHUNKS, (dim + 255) / 256 - c0);
+  const int n4 = dim >> 2;
+  const f32x4* xr[4];
+  float scale[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
+    xr[q] = reinterpret_cast<const f32x4*>(x + row * ldx);
+    scale[q] = h2_scale_of_inv(inv[row]);
+  }
+  f32x4 cur[4], nxt[4];
+  auto load = [&](int i, f32x4 (&dst)[4]) {
+    const int idx = lane + 64 * (c0 + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = idx < n4 ? xr[q][idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  load(0, cur);
+  for (int i = 0; i < nchunks; ++i) {
+    if (i + 1 < nchunks) load(i + 1, nxt);                 // the next chunk's loads fly over this chunk's LDS round trip
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = cur[q];
+      o[0] *= scale[q]; o[1] *= scale[q]; o[2] *= scale[q]; o[3] *= scale[q];
+      *reinterpret_cast<f32x4*>(&tile[wave * 4 + q][4 * lane]) = o;
+    }
+    __syncthreads();
+    h2_store_chunk(tile, c0 + i, dim, row0, rows, out, R);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+  }
+}
+
 // fp32 row-major [rows, K] -> h2 image + inv[row] = 2^-e
 template <int NV>
 __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
@@ -654,10 +742,26 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
 
 size_t h2_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 2 * (size_t)rows * 32; }
 
+int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, float* row_sumsq,
+                  hipStream_t stream) {
+  ANYLOC_CHECK_ARG(x && h2 && inv_scale && rows > 0 && K > 0 && ldx >= K, "split_h2_wide: bad arguments");
+  ANYLOC_CHECK_ARG(K % 16 == 0 && ldx % 4 == 0 && K < (1ll << 31) && rows < (1ll << 31) && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                   "split_h2_wide: K must be a multiple of 16, rows 16-byte aligned (K=%lld)", (long long)K);
+  ProfScope prof("split_h2_wide", stream, 0.0, 12.0 * rows * K);
+  hipLaunchKernelGGL(row_amax_sq_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ldx, K, inv_scale, row_sumsq);
+  ANYLOC_TRY(launch_status("row_amax_sq_kernel"));
+  const int chunks = (int)((K + 255) / 256);
+  const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)((chunks + WIDE_CHUNKS - 1) / WIDE_CHUNKS));
+  ANYLOC_CHECK_ARG(grid.y < 65536, "split_h2_wide: K too large");
+  hipLaunchKernelGGL(split_h2_wide_kernel, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, static_cast<unsigned char*>(h2),
+                     inv_scale, rows);
+  return launch_status("split_h2_wide_kernel");
+}
+
 int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream) {
   ANYLOC_CHECK_ARG(x && h2 && inv_scale && rows > 0 && K > 0 && ldx >= K, "split_h2: bad arguments");
-  ANYLOC_CHECK_ARG(K % 16 == 0 && K <= 4096 && ldx % 4 == 0, "split_h2: K must be a multiple of 16, at most 4096 (got %lld)",
-                   (long long)K);
+  ANYLOC_CHECK_ARG(K % 16 == 0 && ldx % 4 == 0, "split_h2: K must be a multiple of 16 (got %lld)", (long long)K);
+  if (K > 4096) return split_h2_wide(x, ldx, rows, K, h2, inv_scale, nullptr, stream);
   ProfScope prof("split_h2", stream, 0.0, 8.0 * rows * K);
   const dim3 grid((unsigned)((rows + 15) / 16));
   unsigned char* out = static_cast<unsigned char*>(h2);
@@ -798,6 +902,7 @@ int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
       return dispatch_h3<EPI_GELU_H2>(p, stream);
     case EPI_SWIGLU_H2:
       ANYLOC_CHECK_ARG(p.C2 && p.c_inv && p.RC >= p.M && p.N % 128 == 0, "gemm_h3: SWIGLU_H2 needs an output image, c_inv and N %% 128 == 0");
+      p.fast_silu = option(OPT_H3_FAST_SILU) != 0;
       return dispatch_h3<EPI_SWIGLU_H2>(p, stream);
     default: set_error("gemm_h3: unsupported epilogue %d", epilogue); return ANYLOC_ERR_INVALID_ARG;
   }

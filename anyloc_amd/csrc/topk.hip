@@ -265,15 +265,41 @@ int choose_ksplit(int64_t rows, int64_t dim) {
   return best;
 }
 
+// Many queries against long rows: the score panels run on the two-term fp16 GEMM (gemm_h3.hip: three fp16 matrix-core products
+// per k-step of row-scaled 22-bit operands, fp32 accumulate -- the arithmetic of the ViT block GEMMs, 2.5-3x the fp32-MFMA
+// rate, as accurate as an fp32 GEMM).  Queries are quantised once per call, every database panel once per panel
+// (split_h2_wide: two reads + one write of the panel, a few % of its GEMM; the rows' sums of squares for F.normalize / L2
+// come out of the same pass).  An operand image must stay inside 2 GiB of buffer addressing: rows per image <=
+// (2^31 - 1) / (64 * dim / 16).  Option topk_h3: -1 (default) = where it pays (>= 256 queries, dim >= 1024, >= 2048 rows),
+// 0 = never, 1 = wherever the shape allows (tests).
+constexpr int64_t H3_PANEL = 8192;
+int64_t h3_rows_limit(int64_t dim) { return ((1ll << 31) - 1) / (4 * dim) / 256 * 256; }
+bool h3_scores(int64_t nq, int64_t ndb, int64_t dim) {
+  const int64_t mode = option(OPT_TOPK_H3);
+  if (mode == 0 || nq <= 64 || dim % 16 != 0 || h3_rows_limit(dim) < 256) return false;
+  return mode > 0 || (nq >= 256 && dim >= 1024 && ndb >= 2048);
+}
+
 struct TopkWs {
   float *scores, *qn, *dn, *dss, *dnorm, *part, *rsq_part;
+  unsigned char *qimg, *dimg;      // h3 path: operand images of the queries (per chunk of q_chunk rows) and of one panel
+  float *qinv, *dinv;
+  int64_t panel, q_chunk;
   size_t bytes;
 };
 TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim) {
   Arena a(ws, cap);
   TopkWs w;
-  const int64_t panel = std::min<int64_t>(PANEL, std::max<int64_t>(ndb, 1));
+  const bool h3 = h3_scores(nq, ndb, dim);
+  w.panel = h3 ? std::min(H3_PANEL, h3_rows_limit(dim)) : PANEL;
+  w.q_chunk = h3 ? std::min<int64_t>(nq, h3_rows_limit(dim)) : nq;
+  const int64_t panel = std::min<int64_t>(w.panel, std::max<int64_t>(ndb, 1));
   w.scores = a.take<float>(std::max<int64_t>(nq, 1) * panel);
+  const int64_t n_qchunks = h3 ? (nq + w.q_chunk - 1) / w.q_chunk : 0;
+  w.qimg = a.take<unsigned char>(h3 ? (size_t)n_qchunks * h2_bytes(w.q_chunk, dim) : 1);
+  w.dimg = a.take<unsigned char>(h3 ? h2_bytes(panel, dim) : 1);
+  w.qinv = a.take<float>(h3 ? nq : 1);
+  w.dinv = a.take<float>(h3 ? panel : 1);
   w.qn = a.take<float>(std::max<int64_t>(nq, 1));
   w.dn = a.take<float>(std::max<int64_t>(ndb, 1));
   w.dss = a.take<float>(std::max<int64_t>(ndb, 1));
@@ -313,11 +339,14 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
   TopkWs w = carve(workspace, workspace_bytes, nq, ndb, dim);
   const bool norm_db = (flags & ANYLOC_TOPK_NORMALIZE_DB) != 0;
   const bool few = few_queries(nq, dim);
+  const bool h3 = h3_scores(nq, ndb, dim);
+  const int64_t PANEL_ROWS = w.panel;
   if (!workspace || w.bytes > workspace_bytes) {
     set_error("topk: workspace %zu < %zu", workspace_bytes, w.bytes);
     return ANYLOC_ERR_WORKSPACE;
   }
-  static_assert(PANEL <= 0x8000 && CAP + KMAX + 2 <= 0xffff, "merge keys hold the column in 15 bits and the slot in 16");
+  static_assert(PANEL <= 0x8000 && H3_PANEL <= PANEL && CAP + KMAX + 2 <= 0xffff,
+                "merge keys hold the column in 15 bits and the slot in 16");
   const size_t k2 = (size_t)((k + 1) & ~1ll);
   const size_t lds = 16 * (k2 + CAP) + 12 * k2 + 16;      // 37 KiB at k = 20: four blocks per CU
   static bool attr = false;
@@ -330,7 +359,7 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
     hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)nq), dim3(256), 0, stream, queries, dim, w.qn);
     ANYLOC_TRY(launch_status("rownorm_sq_kernel(q)"));
   }
-  if ((metric == 1 || norm_db) && !few) {       // (the few-query path gets the row sums of squares from its GEMM)
+  if ((metric == 1 || norm_db) && !few && !h3) {   // (the few-query and fp16 paths get the rows' sums of squares from their own pass)
     ProfScope prof("topk_db_norms", stream, 2.0 * ndb * dim, 4.0 * ndb * dim);
     float* ss = norm_db ? w.dss : w.dn;
     for (int64_t r0 = 0; r0 < ndb; r0 += (1ll << 30)) {
@@ -351,11 +380,35 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
                        (int64_t)0, index_base, (int)k, metric, w.qn, w.dn, (const float*)nullptr, dist, idx_ll, 1);
     ANYLOC_TRY(launch_status("topk_merge_kernel"));
   }
-  for (int64_t c0 = 0; c0 < ndb; c0 += PANEL) {
-    const int64_t pc = std::min<int64_t>(PANEL, ndb - c0);
+  if (h3 && ndb > 0)
+    for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
+      const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
+      ANYLOC_TRY(split_h2_wide(queries + q0 * dim, dim, qc, dim, w.qimg + c * h2_bytes(w.q_chunk, dim), w.qinv + q0, nullptr, stream));
+    }
+  for (int64_t c0 = 0; c0 < ndb; c0 += PANEL_ROWS) {
+    const int64_t pc = std::min<int64_t>(PANEL_ROWS, ndb - c0);
     GemmProblem g{};
     g.tag = "topk_scores_gemm";
-    if (few) {
+    if (h3) {
+      // the panel's operand image + its rows' sums of squares (raw: the L2 term; or, normalising, the F.normalize divisor)
+      const bool want_ss = metric == 1 || norm_db;
+      ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, want_ss ? (norm_db ? w.dss : w.dn) + c0 : nullptr, stream));
+      if (norm_db) {
+        hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, w.dss + c0, pc, w.dnorm + c0,
+                           w.dn + c0);
+        ANYLOC_TRY(launch_status("dbnorm_kernel"));
+      }
+      for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
+        const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
+        H3Problem h{};
+        h.A2 = w.qimg + c * h2_bytes(w.q_chunk, dim); h.RA = qc; h.a_inv = w.qinv + q0;
+        h.W2 = w.dimg; h.RW = pc; h.w_inv = w.dinv;
+        h.C = w.scores + q0 * pc; h.ldc = pc;
+        h.M = qc; h.N = pc; h.K16 = (int)(dim / 16);
+        h.tag = "topk_scores_gemm";
+        ANYLOC_TRY(gemm_h3(h, EPI_STORE, stream));
+      }
+    } else if (few) {
       // database rows as the M operand, the (<= 64) queries as N, K cut into slices: enough workgroups to stream the
       // panel at HBM rate; the row sums of squares of the database come out of the same pass
       const int S = choose_ksplit(pc, dim);

@@ -63,6 +63,8 @@ const char* anyloc_last_error(void);
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
+ *   h3_fast_silu (1)                  fused SwiGLU epilogue: SiLU on the hardware exp2 / rcp (1 ulp each)
+ *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
  * Unknown names are rejected (ANYLOC_ERR_INVALID_ARG).  Not thread-safe against
  * concurrent launches that read the option being changed. */
 int anyloc_set_option(const char* name, int64_t value);

@@ -251,3 +251,95 @@ def test_reference_dino_v2_vlad_script_on_the_hip_path(tmp_path):
     assert 0.0 <= r["R@1"] <= r["R@3"] <= 1.0
     pts = [f for dp, _, fs in os.walk(cache) for f in fs if f.endswith(".pt")]
     assert "c_centers.pt" in pts and any(f.endswith("_r.pt") for f in pts) and any(f.endswith("_l.pt") for f in pts)
+
+
+# ------------------------------------------------------------- retrieval score panels on the two-term fp16 GEMM
+def _flat_oracle(qu, db, k, metric, norm):
+    from oracle import faiss_flat
+    q = torch.nn.functional.normalize(qu) if norm else qu
+    d = torch.nn.functional.normalize(db) if norm else db
+    return faiss_flat.flat_search(q, d, k, metric)
+
+
+def _check_topk(d_g, i_g, qu, db, k, metric, norm):
+    """Indices identical to the flat-index restatement except at PROVEN near-ties (float64 scores of the two swapped
+    rows closer than 2e-6), distances within 3e-6 of the float64 scores of the rows the kernel returned."""
+    d_r, i_r = _flat_oracle(qu, db, k, metric, norm)
+    q64 = (torch.nn.functional.normalize(qu.double()) if norm else qu.double())
+    d64 = (torch.nn.functional.normalize(db.double()) if norm else db.double())
+    i_g, d_g = i_g.cpu(), d_g.cpu()
+    for n in range(qu.shape[0]):
+        rows = d64[i_g[n]]
+        exact = rows @ q64[n] if metric == "ip" else ((rows - q64[n]) ** 2).sum(1)
+        scale = max(1.0, float(exact.abs().max()))
+        assert float((d_g[n].double() - exact).abs().max()) <= 3e-6 * scale, (n, float((d_g[n].double() - exact).abs().max()))
+        bad = (i_g[n] != i_r[n]).nonzero().flatten()
+        for j in bad.tolist():
+            other = d64[i_r[n, j]]
+            e_o = float(other @ q64[n]) if metric == "ip" else float(((other - q64[n]) ** 2).sum())
+            assert abs(e_o - float(exact[j])) <= 2e-6 * scale, (n, j, e_o, float(exact[j]))
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("norm", [False, True])
+def test_topk_fp16_score_panels_vs_oracle(metric, norm):
+    """Option topk_h3 = 1: the many-query score panels on gemm_h3 (22-bit row-scaled operands, fp32 accumulate) -- uneven
+    panel tail (8192 + 1808 rows), a tie across panels, rows of very different magnitude, k above one panel's merge step."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dim, ndb, nq, k = 2048, 10000, 150, 25
+    db = torch.randn(ndb, dim, generator=g) * (0.05 + torch.rand(ndb, 1, generator=g) * 20.0)
+    qu = torch.randn(nq, dim, generator=g)
+    qu[:40] = db[torch.arange(40) * 211 + 7] + 0.3 * torch.randn(40, dim, generator=g)
+    db[9000] = db[12]                                              # identical rows in two panels: lower index first
+    with ops.options(topk_h3=1):
+        d, i = ops.topk(torch.nn.functional.normalize(qu).to("cuda") if norm else qu.to("cuda"), db.to("cuda"), k, metric,
+                        normalize_db=norm)
+        d1, i1 = ops.topk(torch.nn.functional.normalize(qu).to("cuda") if norm else qu.to("cuda"), db.to("cuda"), k, metric,
+                          normalize_db=norm)
+    assert torch.equal(i, i1) and torch.equal(d, d1)               # run-to-run reproducible
+    _check_topk(d, i, qu, db, k, metric, norm)
+    hit = (i.cpu() == 12).nonzero()
+    for n, j in hit.tolist():                                      # the duplicated row: index 12 directly before 9000
+        if j + 1 < k:
+            assert int(i[n, j + 1]) == 9000 and float(d[n, j]) == float(d[n, j + 1])
+    # ... and the same lists as the fp32-MFMA panels give (identical except proven near-ties, checked against float64 above)
+    with ops.options(topk_h3=0):
+        d0, i0 = ops.topk(torch.nn.functional.normalize(qu).to("cuda") if norm else qu.to("cuda"), db.to("cuda"), k, metric,
+                          normalize_db=norm)
+    assert float((i0 != i).float().mean()) < 0.002
+
+
+def test_topk_fp16_score_panels_vlad_width():
+    """The config-3 row width (49 152) at a size the CPU can score: 300 queries x 3000 unit-block VLADs, cosine with the
+    database normalised inside the search."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    K, D = 32, 1536
+    db = torch.nn.functional.normalize(torch.randn(3000, K, D, generator=g), dim=-1).reshape(3000, K * D) * 3.0
+    qu = torch.nn.functional.normalize(torch.randn(300, K, D, generator=g), dim=-1).reshape(300, K * D)
+    qu[:50] = 0.8 * db[torch.arange(50) * 37 + 3] / 3.0 + 0.2 * qu[:50]
+    with ops.options(topk_h3=1):
+        d, i = ops.topk(torch.nn.functional.normalize(qu).to("cuda"), db.to("cuda"), 20, "ip", normalize_db=True)
+    assert torch.equal(i[:50, 0].cpu(), torch.arange(50) * 37 + 3)
+    _check_topk(d, i, qu, db, 20, "ip", True)
+
+
+def test_split_h2_wide_rows():
+    """anyloc_split_h2 above 4096 columns (retrieval rows): 22 bits relative to the row maximum, rows of any magnitude,
+    a zero row, a ragged last row group."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(1)
+    rows, K = 37, 49152
+    x = torch.randn(rows, K, generator=g) * torch.pow(10.0, torch.randint(-6, 6, (rows, 1), generator=g).float())
+    x[5] = 0.0
+    x[7, 100] = 3e4 * float(x[7].abs().max())                      # one element 3e4 above the rest of its row
+    img, inv = ops.split_h2(x.to("cuda"))
+    back = ops.h2_image_to_f32(img, inv, rows, K).cpu()
+    amax = x.double().abs().max(dim=1, keepdim=True)[0]
+    err = (back - x.double()).abs() / amax.clamp_min(1e-300)
+    assert float(err[torch.arange(rows) != 5].max()) <= 2.0 ** -21 and float(back[5].abs().max()) == 0.0
+    # the scale puts the row maximum in [2^14, 2^15)
+    top = amax.squeeze(1) / inv.cpu().double()
+    ok = (top >= 2.0 ** 14) & (top < 2.0 ** 15)
+    assert bool(ok[torch.arange(rows) != 5].all())

@@ -12,6 +12,10 @@ try:
         print("   parity", d["parity"])
     if "modes" in d:
         print("   modes", d["modes"])
+    for name, st in d.get("stages", {}).items():
+        print("   stage", name, {k: v for k, v in st.items() if k not in ("workload", "kernels_ms")})
+    if "cpu_baseline" in d:
+        print("   cpu_baseline", d["cpu_baseline"])
 except Exception as exc:          # noqa: BLE001
     print(tag, "no bench line:", exc)
     try:
