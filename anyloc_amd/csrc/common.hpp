@@ -67,6 +67,7 @@ enum Option {
   OPT_H3_MIN_ROWS,       // h3 forward: below this many token rows use the fp32-MFMA kernels
   OPT_X6_MIN_ROWS,       // x6 forward: the same
   OPT_ATTN_CFG,          // fp32-MFMA attention: workgroup shape (micro-benchmarks)
+  OPT_ATTN_H3_KBATCH,    // attention_h3: 1 = read all K fragments of a tile first, score MFMAs back to back
   OPT_ATTN_X6,           // anyloc_attention: 1 = split-bf16 products for every call, 0 = never, -1 = as the caller asks
   OPT_VLAD_PARTS,        // workgroups per image of the fused VLAD kernel (0 = chosen from the image count)
   OPT_VLAD_TWO_PASS,     // 1 = force the general two-pass VLAD path
