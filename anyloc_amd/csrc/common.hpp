@@ -61,6 +61,7 @@ enum Option {
   OPT_H3_DEEP_MAX,       // ... and below this many 64x64 tiles a ring stage holds four k-blocks
   OPT_H3_DEEP2_MAX,      // ... below this many, two
   OPT_H3_EPI_LDS,        // gemm_h3 LayerScale-residual epilogue: 1 = 16-byte accesses through LDS, 0 = dword read-modify-write
+  OPT_LN_ROWS_PER_WAVE,  // layernorm_h2: 0 = by ln_small_rows; 1 / 2 / 4 = rows per wave at every size (A/B)
   OPT_LN_SMALL_ROWS,     // layernorm_h2: below this many rows one row per wave
   OPT_H3_FUSE,           // h3 forward: 1 = q|k|v, attention output and FFN activation stay in fp16 planes; 0 = fp32 + quantiser passes
   OPT_X6_FUSE,           // x6 forward: the same for the bf16 plane images

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
 template <int RB = 16>
 __device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, int dim, int64_t row0, int64_t rows,
                                                unsigned char* out, int64_t R) {
-  static_assert(RB == 16 || RB == 4, "16 rows per block (4 per wave) or 4 (1 per wave)");
+  static_assert(RB == 16 || RB == 8 || RB == 4, "16 rows per block (4 per wave), 8 (2 per wave) or 4 (1 per wave)");
   const int tid = threadIdx.x;
   constexpr int ITEMS = RB * 32;                           // (k-block, row, half) triples of one 256-column chunk
 #pragma unroll
@@ -786,17 +786,19 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   const int nv = (dim / 4 + 63) / 64;
   f32x4 b4;                                                  // bound: HOST array of 4 floats (or null)
   for (int i = 0; i < 4; ++i) b4[i] = bound ? bound[i] : 0.0f;
-  // few rows (option ln_small_rows, default 4096 = seven 322 x 322 images): one row per wave, four per block
-  const bool small = rows < option(OPT_LN_SMALL_ROWS);
-  const dim3 grid((unsigned)(small ? (rows + 3) / 4 : (rows + 15) / 16));
-#define ANYLOC_LN_H2(NVV)                                                                                                \
-  do {                                                                                                                   \
-    if (small)                                                                                                           \
-      hipLaunchKernelGGL((layernorm_h2_kernel<NVV, 1>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
-                         rows, b4, bound ? bound_inv : nullptr);                                                         \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((layernorm_h2_kernel<NVV, 4>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
-                         rows, b4, bound ? bound_inv : nullptr);                                                         \
+  // few rows (option ln_small_rows, default 4096 = seven 322 x 322 images): one row per wave, four per block; option
+  // ln_rows_per_wave (0 = that rule) forces 1, 2 or 4 rows per wave at every size (A/B; same per-row arithmetic, same bits)
+  const int64_t forced = option(OPT_LN_ROWS_PER_WAVE);
+  const int rpw = (forced == 1 || forced == 2 || forced == 4) ? (int)forced : (rows < option(OPT_LN_SMALL_ROWS) ? 1 : 4);
+  const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+#define ANYLOC_LN_H2_R(NVV, RPWV)                                                                                        \
+  hipLaunchKernelGGL((layernorm_h2_kernel<NVV, RPWV>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
+                     rows, b4, bound ? bound_inv : nullptr)
+#define ANYLOC_LN_H2(NVV)              \
+  do {                                 \
+    if (rpw == 1) ANYLOC_LN_H2_R(NVV, 1);      \
+    else if (rpw == 2) ANYLOC_LN_H2_R(NVV, 2); \
+    else ANYLOC_LN_H2_R(NVV, 4);               \
   } while (0)
   if (nv <= 1) ANYLOC_LN_H2(1);
   else if (nv <= 2) ANYLOC_LN_H2(2);
@@ -804,6 +806,7 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   else if (nv <= 4) ANYLOC_LN_H2(4);
   else if (nv <= 6) ANYLOC_LN_H2(6);
   else ANYLOC_LN_H2(8);
+#undef ANYLOC_LN_H2_R
 #undef ANYLOC_LN_H2
   return launch_status("layernorm_h2_kernel");
 }

@@ -56,6 +56,7 @@ const char* anyloc_last_error(void);
  *   h3_tiny_max (256) h3_deep_max (320) h3_deep2_max (500)
  *                                     gemm_h3 small-problem tile / ring-depth thresholds (tile counts)
  *   h3_epi_lds (1)                    LayerScale-residual epilogue with 16-byte accesses through LDS
+ *   ln_rows_per_wave (0)              layernorm_h2: 1 / 2 / 4 rows per wave at every size (0 = by ln_small_rows)
  *   ln_small_rows (4096)              layernorm_h2: one row per wave below this many rows
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels

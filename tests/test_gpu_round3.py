@@ -343,3 +343,24 @@ def test_split_h2_wide_rows():
     top = amax.squeeze(1) / inv.cpu().double()
     ok = (top >= 2.0 ** 14) & (top < 2.0 ** 15)
     assert bool(ok[torch.arange(rows) != 5].all())
+
+
+# ------------------------------------------------------------------- scheduling variants must not change a bit
+def test_scheduling_variants_are_bitwise_equal():
+    """attention_h3 with the K fragments of a key tile read first (option attn_h3_kbatch) and layernorm_h2 with 1 / 2 / 4
+    rows per wave (option ln_rows_per_wave) reorder instructions, not arithmetic: the tokens are the same bits."""
+    import utilities
+    from anyloc_amd import ops, weights
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device="cuda", depth=3))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 2, "token", use_cls=True, norm_descs=False, device="cuda")
+        img = torch.randn(5, 3, 322, 322, generator=torch.Generator().manual_seed(4)).to("cuda")
+        base = ext(img).clone()
+        assert torch.isfinite(base).all()
+        for opts in (dict(attn_h3_kbatch=0), dict(attn_h3_kbatch=1), dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2),
+                     dict(ln_rows_per_wave=4)):
+            with ops.options(**opts):
+                assert torch.equal(ext(img), base), opts
+    finally:
+        weights.unregister_state_dict(name)
