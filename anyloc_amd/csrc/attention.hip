@@ -464,12 +464,7 @@ constexpr int AH_STAGE = 16384;       // K hi | K lo | V hi | V lo, 4 KiB each
 // QG = 32-query groups per wave (1 or 2), NW = waves per workgroup; a workgroup always covers QG * NW = 4 consecutive
 // groups (128 queries) of one (image, head).  QG = 2: a wave's K / V fragments serve 64 queries, i.e. half the LDS reads,
 // DMA issues and barriers per unit of work, at 2 waves per SIMD.
-// KB = 1: all eight K fragments of a key tile are read from LDS first and the twelve score MFMAs -- one dependent chain on
-// one accumulator -- are issued back to back (a dependent MFMA issues at full rate only directly behind its producer; with an
-// LDS wait between them every link of the chain pays the full result latency: SQ_WAIT_INST_ANY 36 % of wave cycles,
-// profiles/r02_pmc_attention_h3.md); the V fragments are read after the chain, under the softmax, into the registers the K
-// fragments leave.  KB = 0: the compiler's own order (one fragment pair at a time).
-template <int QG, int NW, int KB = 0>
+template <int QG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
                                                                   const float* __restrict__ inv, int T, int heads, int64_t G,
                                                                   unsigned char* __restrict__ out2, float* __restrict__ out_inv,
@@ -579,36 +574,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
       for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[qg][r] = 0.f;
-      if constexpr (KB == 1) {
-        attn_u32x4 kfa[4][2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        attn_u32x4 kf[2];
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            kfa[s][pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
-        __builtin_amdgcn_sched_barrier(0);                          // the eight K-fragment reads ...
+        for (int pl = 0; pl < 2; ++pl)
+          kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int qg = 0; qg < QG; ++qg) {
-            sacc[qg] = ANYLOC_MFMA_F16(kfa[s][1], qf[qg][0][s], sacc[qg]);
-            sacc[qg] = ANYLOC_MFMA_F16(kfa[s][0], qf[qg][1][s], sacc[qg]);
-            sacc[qg] = ANYLOC_MFMA_F16(kfa[s][0], qf[qg][0][s], sacc[qg]);
-          }
-        __builtin_amdgcn_sched_barrier(0);                          // ... then the whole chain, nothing between its links
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          attn_u32x4 kf[2];
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
-#pragma unroll
-          for (int qg = 0; qg < QG; ++qg) {
-            sacc[qg] = ANYLOC_MFMA_F16(kf[1], qf[qg][0][s], sacc[qg]);
-            sacc[qg] = ANYLOC_MFMA_F16(kf[0], qf[qg][1][s], sacc[qg]);
-            sacc[qg] = ANYLOC_MFMA_F16(kf[0], qf[qg][0][s], sacc[qg]);
-          }
+        for (int qg = 0; qg < QG; ++qg) {
+          sacc[qg] = ANYLOC_MFMA_F16(kf[1], qf[qg][0][s], sacc[qg]);
+          sacc[qg] = ANYLOC_MFMA_F16(kf[0], qf[qg][1][s], sacc[qg]);
+          sacc[qg] = ANYLOC_MFMA_F16(kf[0], qf[qg][0][s], sacc[qg]);
         }
       }
       // V^T fragments: lane (d = db*32 + ql, half h2), k-step s2: the 8 keys register r = 8 s2 + j of the score block holds
@@ -775,13 +751,11 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   ProfScope prof("attention", stream, flops, 8.0 * batch * T * D * 2);
   const int qgroups = (T + 31) / 32 + 1;                    // an image intersects at most this many 32-row groups
   const size_t lds = 2 * AH_STAGE + 64;
-  // four waves of 32 queries per workgroup.  Measured slower and removed: two waves of 64 queries (12.7 vs 13.7 ms per step
-  // at B=61) and a software-pipelined loop with a 3-stage ring (15.0 ms) -- DESIGN.md 4.2b
+  // four waves of 32 queries per workgroup.  Measured and removed: two waves of 64 queries (12.7 vs 13.7 ms per step at
+  // B=61), a software-pipelined loop with a 3-stage ring (15.0 ms), and (round 3) all K fragments of a tile read first with
+  // the twelve score MFMAs issued back to back (13.2 vs 13.2 ms: no effect) -- DESIGN.md 4.2b
   const dim3 grid((qgroups + 3) / 4, heads, (unsigned)batch);
-  if (option(OPT_ATTN_H3_KBATCH) != 0)
-    hipLaunchKernelGGL((attention_h3_kernel<1, 4, 1>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
-  else
-    hipLaunchKernelGGL((attention_h3_kernel<1, 4, 0>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
+  hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
   return launch_status("attention_h3_kernel");
 }
 

@@ -68,7 +68,6 @@ enum Option {
   OPT_H3_MIN_ROWS,       // h3 forward: below this many token rows use the fp32-MFMA kernels
   OPT_X6_MIN_ROWS,       // x6 forward: the same
   OPT_ATTN_CFG,          // fp32-MFMA attention: workgroup shape (micro-benchmarks)
-  OPT_ATTN_H3_KBATCH,    // attention_h3: 1 = read all K fragments of a tile first, score MFMAs back to back
   OPT_ATTN_X6,           // anyloc_attention: 1 = split-bf16 products for every call, 0 = never, -1 = as the caller asks
   OPT_VLAD_PARTS,        // workgroups per image of the fused VLAD kernel (0 = chosen from the image count)
   OPT_VLAD_TWO_PASS,     // 1 = force the general two-pass VLAD path
@@ -76,6 +75,7 @@ enum Option {
   OPT_KMEANS_FUSED_V,    // the same for the k-means step
   OPT_KMEANS_MAX_CHUNKS, // k-means: upper limit of row chunks (partial sums); 0 = two per CU
   OPT_H3_FAST_SILU,      // fused SwiGLU epilogue of the h3 w12 GEMM: SiLU on v_exp_f32 + v_rcp_f32 instead of expf + IEEE division
+  OPT_TOPK_FEWQ_X6,      // few-query retrieval scores: 1 = database split on the fly into bf16 planes (scores_x6.hip), 0 = fp32 MFMA
   OPT_TOPK_H3,           // retrieval score panels on the two-term fp16 GEMM: -1 = where it pays, 0 = never, 1 = wherever possible
   OPT_COUNT
 };
@@ -162,6 +162,10 @@ int gemm_nt(const GemmProblem& p, int epilogue, hipStream_t stream);
 // C_s[M, N<=64] = A[:, slice s] W[:, slice s]^T for s < ksplit in ONE launch (grid.y = slice) on 128 x 64 tiles, with the
 // partial row sums of squares of A: few-query retrieval, where a plain GEMM would have too few tiles to stream HBM
 int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream);
+// the same pass with both operands split on the fly into three bf16 planes (six bf16 MFMA products, fp32 accumulate):
+// part[s][row][0..63] and rsq_part[s][row] for K slices s < ksplit of length kslice (scores_x6.hip)
+int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {
@@ -194,6 +198,7 @@ struct H3Problem {
   const float* bias;
   const float* gamma;                       // EPI_LS_RESID
   const float* resid;                       // EPI_LS_RESID, leading dim ldc
+  int accumulate;                           // EPI_STORE: C += A W^T (a long contraction cut into K chunks, one launch each)
   int fast_silu;                            // EPI_SWIGLU_H2: SiLU on v_exp_f32 / v_rcp_f32 (set by gemm_h3 from option h3_fast_silu)
   int epi_lds;                              // EPI_LS_RESID: transposed 16-byte epilogue through LDS (set by gemm_h3)
   int group_m;                              // tile-rows per XCD scheduling group (set by gemm_h3)

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
             if (cok[ni]) {
               const float v = acc[mi][ni][r] * (ai * sw_[ni]) + bv[ni];
               const int64_t o = row * p.ldc + wcol0 + ni * 32;
-              if constexpr (EPI == EPI_STORE) p.C[o] = v;
+              if constexpr (EPI == EPI_STORE) p.C[o] = p.accumulate ? p.C[o] + v : v;
               else if constexpr (EPI == EPI_GELU) p.C[o] = h3_gelu_erf(v);
               else p.C[o] = p.resid[o] + v * gam[ni];
             }
@@ -786,10 +786,12 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   const int nv = (dim / 4 + 63) / 64;
   f32x4 b4;                                                  // bound: HOST array of 4 floats (or null)
   for (int i = 0; i < 4; ++i) b4[i] = bound ? bound[i] : 0.0f;
-  // few rows (option ln_small_rows, default 4096 = seven 322 x 322 images): one row per wave, four per block; option
-  // ln_rows_per_wave (0 = that rule) forces 1, 2 or 4 rows per wave at every size (A/B; same per-row arithmetic, same bits)
+  // few rows (option ln_small_rows, default 4096 = seven 322 x 322 images): one row per wave, four per block; otherwise two
+  // rows per wave (48 instead of 96 data registers: more waves in flight; B=61: 6.48 -> 5.65 ms per step, four rows per wave
+  // was the round-2 kernel, one row per wave at this size 11.4 ms -- profiles/r03_ab_attn_kbatch_ln_rpw.log).  Option
+  // ln_rows_per_wave (0 = that rule) forces 1, 2 or 4 at every size (A/B; same per-row arithmetic, same bits)
   const int64_t forced = option(OPT_LN_ROWS_PER_WAVE);
-  const int rpw = (forced == 1 || forced == 2 || forced == 4) ? (int)forced : (rows < option(OPT_LN_SMALL_ROWS) ? 1 : 4);
+  const int rpw = (forced == 1 || forced == 2 || forced == 4) ? (int)forced : (rows < option(OPT_LN_SMALL_ROWS) ? 1 : 2);
   const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
 #define ANYLOC_LN_H2_R(NVV, RPWV)                                                                                        \
   hipLaunchKernelGGL((layernorm_h2_kernel<NVV, RPWV>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \

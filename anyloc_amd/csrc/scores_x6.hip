@@ -1,0 +1,212 @@
+// Few-query retrieval scores with the database split ON THE FLY into bf16 planes: HBM-bound instead of fp32-MFMA-bound.
+//
+// replaces (with topk.hip): faiss IndexFlatIP / IndexFlatL2 .search for a handful of queries against a long database
+// (get_top_k_recall, reference utilities.py:439-450) -- the per-step retrieval of bench.py (61 query VLADs x 10 000 rows
+// x 49 152 columns), where the database is read once and every other cost should hide behind that read.
+//
+// The fp32-MFMA version of this pass (gemm_nt_splitk, gemm_f32.hip) is limited by the matrix cores: <= 64 queries padded to
+// 64 columns on v_mfma_f32_32x32x2_f32 cost 2048 matrix-core cycles per wave and 32-k slab, 0.40 ms at peak for the bench
+// shape against 0.30 ms of HBM time (measured 0.70 ms = 2.8 TB/s).  Here every fp32 operand is the EXACT sum of three bf16
+// terms (gemm_x6.hip's arithmetic: x = x1 + x2 + x3, round-to-nearest-even, residuals exact), the six leading plane
+// products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 768 matrix-core cycles per wave and slab, fp32-GEMM
+// accuracy, and, unlike the two-term fp16 split of gemm_h3.hip, no row scale (a power-of-two row scale needs the row's
+// maximum over all 49 152 columns BEFORE the first column is quantised: a second pass over HBM).
+//
+// Same decomposition and outputs as gemm_nt_splitk: database rows are the M operand (128-row tiles), the queries the N
+// operand (64 columns, zero-padded), K is cut into S slices (grid.y) so that tiles x S fills the chip; slice s writes its
+// partial scores part[s][row][0..63] and the partial row sums of squares rsq[s][row] (from the fp32 values as staged: the
+// F.normalize / L2 terms of the database come out of the same read).  splitk_combine_kernel (topk.hip) adds the slices.
+//
+// Per 32-k slab and workgroup (4 waves, wave w owns rows 32 w .. 32 w + 31 of the tile and all 64 queries):
+//   database  global -> registers (4 x 16 B per thread, issued one slab ahead) -> LDS as fp32, rows padded to 36 floats
+//             -> fragment reads (8 consecutive k per lane: 2 x ds_read_b128, conflict-free) -> split in registers
+//   queries   global (L2-resident) -> registers -> split ONCE per workgroup -> LDS as three bf16 planes, rows padded to 80 B
+//             -> fragment reads (ds_read_b128, conflict-free)
+//   12 MFMAs per k-step of 16 (6 plane products x 2 query blocks), smallest products first, one accumulator per block.
+#include "common.hpp"
+
+namespace anyloc {
+
+namespace {
+
+typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sx_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SX_BM = 128, SX_BN = 64, SX_BK = 32;
+constexpr int SX_ALD = SX_BK + 4;                        // floats per database row in LDS
+constexpr int SX_BROW = 80;                              // bytes per query row and plane in LDS (64 + 16 of padding)
+constexpr int SX_A_BYTES = SX_BM * SX_ALD * 4;           // 18 432
+constexpr int SX_B_PLANE = SX_BN * SX_BROW;              // 5 120
+constexpr int SX_B_BYTES = 3 * SX_B_PLANE;               // 15 360
+constexpr int SX_STAGE = SX_A_BYTES + SX_B_BYTES;        // 33 792: two stages = 66 KiB, two workgroups per CU
+
+__device__ __forceinline__ f32x4 sx_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+__global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __restrict__ db, int64_t ldd, int64_t rows,
+                                                                const float* __restrict__ qu, int64_t ldq, int nq,
+                                                                int64_t kslice, float* __restrict__ part,
+                                                                float* __restrict__ rsq_part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * SX_BM;
+  const int64_t sl = blockIdx.y;
+  const int kq = tid & 7, r0 = tid >> 3;                 // staging: 8 lanes x 16 B cover one 128-byte row segment
+
+  // ---- staging coordinates (buffer loads: descriptor at the tile origin, constant per-thread offset, slab offset scalar) ----
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(db + m0 * ldd + sl * kslice), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(qu + sl * kslice), 0, 0x7fffffff, 0x00020000);
+  unsigned a_off[4], b_off[2];
+  bool b_ok[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t row = m0 + r0 + 32 * i;
+    row = (row < rows ? row : rows - 1) - m0;            // rows past the end re-read the last row; never stored
+    a_off[i] = (unsigned)((row * ldd + 4 * kq) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = r0 + 32 * i;
+    b_ok[i] = row < nq;
+    b_off[i] = (unsigned)(((int64_t)(b_ok[i] ? row : 0) * ldq + 4 * kq) * 4);
+  }
+  const int nk = (int)(kslice / SX_BK);
+  f32x4 ra[4], rb[2];
+  float rsq[4] = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](int kt) {
+    const unsigned kb = (unsigned)kt * (SX_BK * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = sx_load16(a_rsrc, a_off[i], kb);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[i] = b_ok[i] ? sx_load16(b_rsrc, b_off[i], kb) : zero4;
+  };
+  auto stash = [&](int stage) {
+    unsigned char* st = sx_smem + stage * SX_STAGE;
+    float* ad = reinterpret_cast<float*>(st) + r0 * SX_ALD + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(ad + 32 * i * SX_ALD) = ra[i];
+      rsq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
+    }
+    unsigned char* bd = st + SX_A_BYTES + r0 * SX_BROW + kq * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned p01[3], p23[3];
+      split_pair_x3(rb[i][0], rb[i][1], p01);
+      split_pair_x3(rb[i][2], rb[i][3], p23);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        sx_u32x2 w;
+        w[0] = p01[pl];
+        w[1] = p23[pl];
+        *reinterpret_cast<sx_u32x2*>(bd + pl * SX_B_PLANE + 32 * i * SX_BROW) = w;
+      }
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) fetch(kt + 1);                      // next slab's loads fly over this slab's MFMAs
+    const unsigned char* st = sx_smem + stage * SX_STAGE;
+    const float* ap = reinterpret_cast<const float*>(st) + (wave * 32 + fr) * SX_ALD + 8 * fh;
+    const unsigned char* bp = st + SX_A_BYTES + fr * SX_BROW + fh * 16;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + 16 * s2);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + 16 * s2 + 4);
+      sx_u32x4 bw[2][3];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bw[ni][pl] = *reinterpret_cast<const sx_u32x4*>(bp + pl * SX_B_PLANE + ni * 32 * SX_BROW + s2 * 32);
+      unsigned q0[3], q1[3], q2[3], q3[3];
+      split_pair_x3(a0[0], a0[1], q0);
+      split_pair_x3(a0[2], a0[3], q1);
+      split_pair_x3(a1[0], a1[1], q2);
+      split_pair_x3(a1[2], a1[3], q3);
+      sx_bf16x8 af[3], bf[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        sx_u32x4 w;
+        w[0] = q0[pl]; w[1] = q1[pl]; w[2] = q2[pl]; w[3] = q3[pl];
+        af[pl] = __builtin_bit_cast(sx_bf16x8, w);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[ni][pl] = __builtin_bit_cast(sx_bf16x8, bw[ni][pl]);
+      }
+#define ANYLOC_SX_TERM(pa, pb) \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bf[ni][pb], acc[ni], 0, 0, 0);
+      ANYLOC_SX_TERM(2, 0) ANYLOC_SX_TERM(0, 2) ANYLOC_SX_TERM(1, 1)
+      ANYLOC_SX_TERM(1, 0) ANYLOC_SX_TERM(0, 1) ANYLOC_SX_TERM(0, 0)
+#undef ANYLOC_SX_TERM
+    }
+    if (kt + 1 < nk) stash(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- partial row sums of squares: the 8 staging lanes of a row hold its pieces ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = rsq[i];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    const int64_t row = m0 + r0 + 32 * i;
+    if (kq == 0 && row < rows) rsq_part[sl * rows + row] = v;
+  }
+  // ---- partial scores: C/D layout of the 32 x 32 block -- lane = query column, 16 rows of its half ----
+  float* out = part + sl * rows * 64;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    if (row < rows) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) out[row * 64 + ni * 32 + fr] = acc[ni][r];
+    }
+  }
+}
+
+}  // namespace
+
+int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(db && queries && part && rsq_part, "scores_fewq_x6: null operand");
+  ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % SX_BK == 0 && ksplit >= 1 && ksplit < 65536,
+                   "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
+  ANYLOC_CHECK_ARG(ldd % 4 == 0 && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(db) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(queries) & 15) == 0 && kslice % 4 == 0,
+                   "scores_fewq_x6: operands must be 16-byte aligned with row strides that are multiples of 4");
+  ANYLOC_CHECK_ARG(127 * ldd * 4 + kslice * 4 < (1ll << 31) && 63 * ldq * 4 + kslice * 4 < (1ll << 31),
+                   "scores_fewq_x6: a tile's rows must stay inside 2 GiB of buffer addressing");
+  const int64_t tiles = (rows + SX_BM - 1) / SX_BM;
+  ANYLOC_CHECK_ARG(tiles < (1ll << 31), "scores_fewq_x6: grid too large");
+  ProfScope prof("topk_scores_gemm", stream, 2.0 * rows * 64 * kslice * ksplit, 4.0 * (rows + 64.0) * kslice * ksplit);
+  static bool attr = false;
+  if (!attr) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   2 * SX_STAGE));
+    attr = true;
+  }
+  hipLaunchKernelGGL(scores_fewq_x6_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SX_STAGE, stream, db, ldd, rows,
+                     queries, ldq, (int)nq, kslice, part, rsq_part);
+  return launch_status("scores_fewq_x6_kernel");
+}
+
+}  // namespace anyloc

@@ -398,15 +398,23 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
                            w.dn + c0);
         ANYLOC_TRY(launch_status("dbnorm_kernel"));
       }
+      // A 49 152-long contraction in ONE fp32 accumulator takes ~9 000 rounded additions: 4e-6 on a score of 1.  Cut into
+      // chunks of 8192 k (one launch each, the later ones adding into the panel) the error is that of ~1 500 additions plus
+      // six: 5e-7 -- the chunked summation of the fp32-MFMA path (gemm_f32.hip, ABL bit 5) at the price of re-reading and
+      // re-writing the score panel per chunk (3 % of the GEMM time).
+      const int64_t K16 = dim / 16, KC16 = 512;
       for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
         const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
-        H3Problem h{};
-        h.A2 = w.qimg + c * h2_bytes(w.q_chunk, dim); h.RA = qc; h.a_inv = w.qinv + q0;
-        h.W2 = w.dimg; h.RW = pc; h.w_inv = w.dinv;
-        h.C = w.scores + q0 * pc; h.ldc = pc;
-        h.M = qc; h.N = pc; h.K16 = (int)(dim / 16);
-        h.tag = "topk_scores_gemm";
-        ANYLOC_TRY(gemm_h3(h, EPI_STORE, stream));
+        for (int64_t kb0 = 0; kb0 < K16; kb0 += KC16) {
+          H3Problem h{};
+          h.A2 = w.qimg + c * h2_bytes(w.q_chunk, dim) + kb0 * (2 * qc * 32); h.RA = qc; h.a_inv = w.qinv + q0;
+          h.W2 = w.dimg + kb0 * (2 * pc * 32); h.RW = pc; h.w_inv = w.dinv;
+          h.C = w.scores + q0 * pc; h.ldc = pc;
+          h.M = qc; h.N = pc; h.K16 = (int)std::min<int64_t>(KC16, K16 - kb0);
+          h.accumulate = kb0 > 0;
+          h.tag = "topk_scores_gemm";
+          ANYLOC_TRY(gemm_h3(h, EPI_STORE, stream));
+        }
       }
     } else if (few) {
       // database rows as the M operand, the (<= 64) queries as N, K cut into slices: enough workgroups to stream the
@@ -418,7 +426,10 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
       g.M = pc; g.N = nq; g.K = dim / S;
       g.ksplit = S; g.c_split_stride = pc * 64;
       g.rowsq = w.rsq_part;
-      ANYLOC_TRY(gemm_nt_splitk(g, stream));
+      if (option(OPT_TOPK_FEWQ_X6) != 0)
+        ANYLOC_TRY(scores_fewq_x6(g.A, g.lda, pc, queries, dim, nq, g.K, S, w.part, w.rsq_part, stream));
+      else
+        ANYLOC_TRY(gemm_nt_splitk(g, stream));
       ProfScope prof("topk_combine", stream, (double)S * pc * 64, 4.0 * ((double)S * pc * 65 + (double)nq * pc));
       hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, w.part, w.rsq_part, S,
                          pc, (int)nq, w.scores, (norm_db ? w.dss : w.dn) + c0);

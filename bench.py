@@ -588,13 +588,17 @@ def stage_b1(ext, qu_img):
         state["i"] = (state["i"] + 1) % len(imgs)
         return ext(imgs[state["i"]])
     el, tok, kern = _timed(one, iters=40, warm=5)
-    # the same image inside a batch must give bitwise the same tokens (per-row arithmetic does not depend on the batch)
-    same = bool(torch.equal(ext(imgs[3]), ext(qu_img[:8])[3:4]))
+    # the same image as image 0 of a batch gives bitwise the same tokens (per-row arithmetic does not depend on the batch);
+    # elsewhere in a batch its rows fall into other GLOBAL 32-row groups of attention_h3's per-tile scales: the
+    # same arithmetic on a differently grouped quantisation, equal to ~1e-7
+    batch = ext(qu_img[:8])
+    same = bool(torch.equal(ext(imgs[0]), batch[0:1]))
+    other = float((ext(imgs[3]) - batch[3:4]).abs().max())
     fl = flops_per_image()
     return {"workload": "DinoV2ExtractFeatures.__call__ at B=1, ViT-G/14 L31 value, 322x322 (the reference scripts' calling convention)",
             "ms_per_image": round(el * 1e3, 3), "images_per_s": round(1.0 / el, 1), "bound": "launch latency",
             "achieved": round(fl / el / 1e12, 1), "unit": "TFLOP/s (algorithmic)", "kernels_ms": kern,
-            "oracle_ok": None, "bitwise_equal_to_batched": same}
+            "oracle_ok": None, "bitwise_equal_to_first_image_of_a_batch": same, "max_abs_diff_at_another_batch_position": other}
 
 
 def stage_kmeans(dev, check):

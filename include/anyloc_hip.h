@@ -60,12 +60,12 @@ const char* anyloc_last_error(void);
  *   ln_small_rows (4096)              layernorm_h2: one row per wave below this many rows
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
- *   attn_h3_kbatch (1)                attention_h3: K fragments of a key tile read first, score MFMAs issued back to back
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
  *   h3_fast_silu (1)                  fused SwiGLU epilogue: SiLU on the hardware exp2 / rcp (1 ulp each)
+ *   topk_fewq_x6 (1)                  anyloc_topk with <= 64 queries: database rows split on the fly into bf16 planes (HBM-bound)
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
  * Unknown names are rejected (ANYLOC_ERR_INVALID_ARG).  Not thread-safe against
  * concurrent launches that read the option being changed. */

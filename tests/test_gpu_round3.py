@@ -347,8 +347,8 @@ def test_split_h2_wide_rows():
 
 # ------------------------------------------------------------------- scheduling variants must not change a bit
 def test_scheduling_variants_are_bitwise_equal():
-    """attention_h3 with the K fragments of a key tile read first (option attn_h3_kbatch) and layernorm_h2 with 1 / 2 / 4
-    rows per wave (option ln_rows_per_wave) reorder instructions, not arithmetic: the tokens are the same bits."""
+    """layernorm_h2 with 1 / 2 / 4 rows per wave (option ln_rows_per_wave) reorders instructions, not arithmetic: the
+    tokens are the same bits."""
     import utilities
     from anyloc_amd import ops, weights
     name = "dinov2_vitg14"
@@ -358,9 +358,36 @@ def test_scheduling_variants_are_bitwise_equal():
         img = torch.randn(5, 3, 322, 322, generator=torch.Generator().manual_seed(4)).to("cuda")
         base = ext(img).clone()
         assert torch.isfinite(base).all()
-        for opts in (dict(attn_h3_kbatch=0), dict(attn_h3_kbatch=1), dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2),
-                     dict(ln_rows_per_wave=4)):
+        for opts in (dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2), dict(ln_rows_per_wave=4)):
             with ops.options(**opts):
                 assert torch.equal(ext(img), base), opts
     finally:
         weights.unregister_state_dict(name)
+
+
+@pytest.mark.parametrize("metric,norm", [("ip", True), ("ip", False), ("l2", True), ("l2", False)])
+def test_topk_few_queries_on_the_fly_bf16_split(metric, norm):
+    """Option topk_fewq_x6 = 1: <= 64 queries, the database rows split on the fly into three bf16 planes (six bf16 MFMA
+    products, csrc/scores_x6.hip) -- ragged row tail (10 000 + 37 rows = 79 tiles, the last one 5 rows), 61 and 3 queries
+    (zero-padded query columns), K slices, row norms from the same pass, vs the flat-index restatement and float64."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dim, ndb = 8192, 10037
+    scale = 0.05 + torch.rand(ndb, 1, generator=g) * 20.0
+    scale[12] = 25.0                                                # the planted top hit also wins the raw inner product
+    db = torch.randn(ndb, dim, generator=g) * scale
+    db[5000] = db[12]
+    for nq, k in ((61, 20), (3, 7)):
+        qu = torch.randn(nq, dim, generator=g)
+        pick = torch.arange(min(nq, 30)) * 301 + 12
+        qu[: len(pick)] = db[pick] + 0.3 * scale[pick] * torch.randn(len(pick), dim, generator=g)
+        qd = (torch.nn.functional.normalize(qu) if norm else qu).to("cuda")
+        with ops.options(topk_fewq_x6=1):
+            d, i = ops.topk(qd, db.to("cuda"), k, metric, normalize_db=norm)
+            d1, i1 = ops.topk(qd, db.to("cuda"), k, metric, normalize_db=norm)
+        assert torch.equal(i, i1) and torch.equal(d, d1)
+        _check_topk(d, i, qu, db, k, metric, norm)
+        assert int(i[0, 0]) == 12 and int(i[0, 1]) == 5000          # the duplicated row: lower index first
+        with ops.options(topk_fewq_x6=0):
+            d0, i0 = ops.topk(qd, db.to("cuda"), k, metric, normalize_db=norm)
+        assert float((i0 != i).float().mean()) < 0.003
