@@ -18,11 +18,13 @@
 // F.normalize / L2 terms of the database come out of the same read).  splitk_combine_kernel (topk.hip) adds the slices.
 //
 // Per 32-k slab and workgroup (4 waves, wave w owns rows 32 w .. 32 w + 31 of the tile and all 64 queries):
-//   database  global -> registers (4 x 16 B per thread, issued one slab ahead) -> LDS as fp32, rows padded to 36 floats
+//   database  global -> registers (4 x 16 B per thread, issued TWO slabs ahead) -> LDS as fp32, rows padded to 36 floats
 //             -> fragment reads (8 consecutive k per lane: 2 x ds_read_b128, conflict-free) -> split in registers
 //   queries   global (L2-resident) -> registers -> split ONCE per workgroup -> LDS as three bf16 planes, rows padded to 80 B
 //             -> fragment reads (ds_read_b128, conflict-free)
 //   12 MFMAs per k-step of 16 (6 plane products x 2 query blocks), smallest products first, one accumulator per block.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace anyloc {
@@ -75,31 +77,39 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
     b_off[i] = (unsigned)(((int64_t)(b_ok[i] ? row : 0) * ldq + 4 * kq) * 4);
   }
   const int nk = (int)(kslice / SX_BK);
-  f32x4 ra[4], rb[2];
+  // TWO slabs travel in registers ahead of the one being contracted (sets 0 / 1): with one, a workgroup has 16 KB of HBM
+  // loads in flight -- 32 KB per CU at two workgroups -- and the pass ran at 3.1 TB/s, the latency-bandwidth product of that
+  // much data (profiles/r03_fewq_x6.log); two sets double it
+  f32x4 ra[2][4], rb[2][2];
   float rsq[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
-  auto fetch = [&](int kt) {
+  auto fetch = [&](int kt, auto setc) {
+    constexpr int S = decltype(setc)::value;
     const unsigned kb = (unsigned)kt * (SX_BK * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = sx_load16(a_rsrc, a_off[i], kb);
+    for (int i = 0; i < 4; ++i) ra[S][i] = sx_load16(a_rsrc, a_off[i], kb);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[i] = b_ok[i] ? sx_load16(b_rsrc, b_off[i], kb) : zero4;
+    for (int i = 0; i < 2; ++i) rb[S][i] = sx_load16(b_rsrc, b_off[i], kb);   // (padding rows re-read row 0; zeroed in stash)
   };
-  auto stash = [&](int stage) {
+  auto stash = [&](auto setc, int stage) {               // register set S -> LDS stage
+    constexpr int S = decltype(setc)::value;
     unsigned char* st = sx_smem + stage * SX_STAGE;
     float* ad = reinterpret_cast<float*>(st) + r0 * SX_ALD + 4 * kq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(ad + 32 * i * SX_ALD) = ra[i];
-      rsq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
+      *reinterpret_cast<f32x4*>(ad + 32 * i * SX_ALD) = ra[S][i];
+      rsq[i] += ra[S][i][0] * ra[S][i][0] + ra[S][i][1] * ra[S][i][1] + ra[S][i][2] * ra[S][i][2] + ra[S][i][3] * ra[S][i][3];
     }
     unsigned char* bd = st + SX_A_BYTES + r0 * SX_BROW + kq * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       unsigned p01[3], p23[3];
-      split_pair_x3(rb[i][0], rb[i][1], p01);
-      split_pair_x3(rb[i][2], rb[i][3], p23);
+      const f32x4 q = b_ok[i] ? rb[S][i] : zero4;          // a select, not a branch around the load: the counted waits survive
+      split_pair_x3(q[0], q[1], p01);
+      split_pair_x3(q[2], q[3], p23);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         sx_u32x2 w;
@@ -116,14 +126,8 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
 
-  fetch(0);
-  stash(0);
-  __syncthreads();
-
   const int fr = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nk) fetch(kt + 1);                      // next slab's loads fly over this slab's MFMAs
+  auto contract = [&](int stage) {                       // the 32-k slab sitting in LDS stage `stage`
     const unsigned char* st = sx_smem + stage * SX_STAGE;
     const float* ap = reinterpret_cast<const float*>(st) + (wave * 32 + fr) * SX_ALD + 8 * fh;
     const unsigned char* bp = st + SX_A_BYTES + fr * SX_BROW + fh * 16;
@@ -157,8 +161,32 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
       ANYLOC_SX_TERM(1, 0) ANYLOC_SX_TERM(0, 1) ANYLOC_SX_TERM(0, 0)
 #undef ANYLOC_SX_TERM
     }
-    if (kt + 1 < nk) stash(stage ^ 1);
+  };
+
+  // Every fetch is issued unconditionally (past the last slab it re-reads the last one and the result is dropped): a load
+  // inside a branch makes the compiler's vector-memory wait conservative at the join -- vmcnt(0), i.e. the newest prefetch
+  // is drained with the one that is needed and the second set buys nothing.
+  const int last = nk - 1;
+  fetch(0, S0{});
+  fetch(min(1, last), S1{});
+  stash(S0{}, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // slab kt is in LDS stage 0, slab kt + 1 in register set 1 (loads issued one iteration ago), set 0 is free
+    fetch(min(kt + 2, last), S0{});
+    __builtin_amdgcn_sched_barrier(0);                   // (the loads stay in front of the contraction they fly over)
+    contract(0);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(S1{}, 1);                                      // (kt + 1 == nk: a copy of the last slab nobody contracts)
     __syncthreads();
+    if (kt + 1 < nk) {
+      fetch(min(kt + 3, last), S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      contract(1);
+      __builtin_amdgcn_sched_barrier(0);
+      stash(S0{}, 0);
+      __syncthreads();
+    }
   }
 
   // ---- partial row sums of squares: the 8 staging lanes of a row hold its pieces ----
