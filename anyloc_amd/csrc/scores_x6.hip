@@ -35,44 +35,55 @@ typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sx_u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SX_BM = 128, SX_BN = 64, SX_BK = 32;
-constexpr int SX_ALD = SX_BK + 4;                        // floats per database row in LDS
-constexpr int SX_BROW = 80;                              // bytes per query row and plane in LDS (64 + 16 of padding)
-constexpr int SX_A_BYTES = SX_BM * SX_ALD * 4;           // 18 432
-constexpr int SX_B_PLANE = SX_BN * SX_BROW;              // 5 120
-constexpr int SX_B_BYTES = 3 * SX_B_PLANE;               // 15 360
-constexpr int SX_STAGE = SX_A_BYTES + SX_B_BYTES;        // 33 792: two stages = 66 KiB, two workgroups per CU
+constexpr int SX_BM = 128, SX_BN = 64;
+// BK = k per slab: 32 (128 B per database row and slab, two workgroups per CU) or 64 (256 B per row and slab -- longer runs
+// per DRAM page -- one workgroup per CU)
+template <int BK>
+struct SxCfg {
+  static constexpr int ALD = BK + 4;                     // floats per database row in LDS (BK = 32: 36, BK = 64: 68 -> 16-byte slots 9 r / 17 r mod 16: conflict-free)
+  static constexpr int BROW = 2 * BK + 16;               // bytes per query row and plane in LDS (80 / 144 -> slots 5 r / 9 r mod 16)
+  static constexpr int A_BYTES = SX_BM * ALD * 4;
+  static constexpr int B_PLANE = SX_BN * BROW;
+  static constexpr int STAGE = A_BYTES + 3 * B_PLANE;    // 33 792 / 62 464 bytes
+  static constexpr int LPR = BK / 4;                     // staging lanes per row (16 B each)
+  static constexpr int RPP = 256 / LPR;                  // rows per staging pass
+  static constexpr int A_LD = SX_BM / RPP, B_LD = SX_BN / RPP;
+};
 
 __device__ __forceinline__ f32x4 sx_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
-__global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __restrict__ db, int64_t ldd, int64_t rows,
+template <int BK>
+__global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(const float* __restrict__ db, int64_t ldd, int64_t rows,
                                                                 const float* __restrict__ qu, int64_t ldq, int nq,
                                                                 int64_t kslice, float* __restrict__ part,
                                                                 float* __restrict__ rsq_part) {
+  using Cfg = SxCfg<BK>;
+  constexpr int SX_BK = BK, SX_ALD = Cfg::ALD, SX_BROW = Cfg::BROW, SX_A_BYTES = Cfg::A_BYTES, SX_B_PLANE = Cfg::B_PLANE,
+                SX_STAGE = Cfg::STAGE, LPR = Cfg::LPR, RPP = Cfg::RPP, A_LD = Cfg::A_LD, B_LD = Cfg::B_LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char sx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * SX_BM;
   const int64_t sl = blockIdx.y;
-  const int kq = tid & 7, r0 = tid >> 3;                 // staging: 8 lanes x 16 B cover one 128-byte row segment
+  const int kq = tid % LPR, r0 = tid / LPR;              // staging: LPR lanes x 16 B cover one row segment of the slab
 
   // ---- staging coordinates (buffer loads: descriptor at the tile origin, constant per-thread offset, slab offset scalar) ----
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(db + m0 * ldd + sl * kslice), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(qu + sl * kslice), 0, 0x7fffffff, 0x00020000);
-  unsigned a_off[4], b_off[2];
-  bool b_ok[2];
+  unsigned a_off[A_LD], b_off[B_LD];
+  bool b_ok[B_LD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t row = m0 + r0 + 32 * i;
+  for (int i = 0; i < A_LD; ++i) {
+    int64_t row = m0 + r0 + RPP * i;
     row = (row < rows ? row : rows - 1) - m0;            // rows past the end re-read the last row; never stored
     a_off[i] = (unsigned)((row * ldd + 4 * kq) * 4);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = r0 + 32 * i;
+  for (int i = 0; i < B_LD; ++i) {
+    const int row = r0 + RPP * i;
     b_ok[i] = row < nq;
     b_off[i] = (unsigned)(((int64_t)(b_ok[i] ? row : 0) * ldq + 4 * kq) * 4);
   }
@@ -80,8 +91,10 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
   // TWO slabs travel in registers ahead of the one being contracted (sets 0 / 1): with one, a workgroup has 16 KB of HBM
   // loads in flight -- 32 KB per CU at two workgroups -- and the pass ran at 3.1 TB/s, the latency-bandwidth product of that
   // much data (profiles/r03_fewq_x6.log); two sets double it
-  f32x4 ra[2][4], rb[2][2];
-  float rsq[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[2][A_LD], rb[2][B_LD];
+  float rsq[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) rsq[i] = 0.f;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -90,22 +103,24 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
     constexpr int S = decltype(setc)::value;
     const unsigned kb = (unsigned)kt * (SX_BK * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[S][i] = sx_load16(a_rsrc, a_off[i], kb);
+    for (int i = 0; i < A_LD; ++i) ra[S][i] = sx_load16(a_rsrc, a_off[i], kb);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[S][i] = sx_load16(b_rsrc, b_off[i], kb);   // (padding rows re-read row 0; zeroed in stash)
+    for (int i = 0; i < B_LD; ++i) rb[S][i] = sx_load16(b_rsrc, b_off[i], kb);   // (padding rows re-read row 0; zeroed in stash)
   };
-  auto stash = [&](auto setc, int stage) {               // register set S -> LDS stage
+  // `real` = 1.0f for a slab of the slice, 0.0f for the copy of the last slab the unconditional prefetch brings in past the
+  // end (its squares must not be counted a second time; the LDS image it leaves is never contracted)
+  auto stash = [&](auto setc, int stage, float real) {   // register set S -> LDS stage
     constexpr int S = decltype(setc)::value;
     unsigned char* st = sx_smem + stage * SX_STAGE;
     float* ad = reinterpret_cast<float*>(st) + r0 * SX_ALD + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(ad + 32 * i * SX_ALD) = ra[S][i];
-      rsq[i] += ra[S][i][0] * ra[S][i][0] + ra[S][i][1] * ra[S][i][1] + ra[S][i][2] * ra[S][i][2] + ra[S][i][3] * ra[S][i][3];
+    for (int i = 0; i < A_LD; ++i) {
+      *reinterpret_cast<f32x4*>(ad + RPP * i * SX_ALD) = ra[S][i];
+      rsq[i] += real * (ra[S][i][0] * ra[S][i][0] + ra[S][i][1] * ra[S][i][1] + ra[S][i][2] * ra[S][i][2] + ra[S][i][3] * ra[S][i][3]);
     }
     unsigned char* bd = st + SX_A_BYTES + r0 * SX_BROW + kq * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < B_LD; ++i) {
       unsigned p01[3], p23[3];
       const f32x4 q = b_ok[i] ? rb[S][i] : zero4;          // a select, not a branch around the load: the counted waits survive
       split_pair_x3(q[0], q[1], p01);
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
         sx_u32x2 w;
         w[0] = p01[pl];
         w[1] = p23[pl];
-        *reinterpret_cast<sx_u32x2*>(bd + pl * SX_B_PLANE + 32 * i * SX_BROW) = w;
+        *reinterpret_cast<sx_u32x2*>(bd + pl * SX_B_PLANE + RPP * i * SX_BROW) = w;
       }
     }
   };
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
     const float* ap = reinterpret_cast<const float*>(st) + (wave * 32 + fr) * SX_ALD + 8 * fh;
     const unsigned char* bp = st + SX_A_BYTES + fr * SX_BROW + fh * 16;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < SX_BK / 16; ++s2) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + 16 * s2);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + 16 * s2 + 4);
       sx_u32x4 bw[2][3];
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
   const int last = nk - 1;
   fetch(0, S0{});
   fetch(min(1, last), S1{});
-  stash(S0{}, 0);
+  stash(S0{}, 0, 1.0f);
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     // slab kt is in LDS stage 0, slab kt + 1 in register set 1 (loads issued one iteration ago), set 0 is free
@@ -177,26 +192,25 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
     __builtin_amdgcn_sched_barrier(0);                   // (the loads stay in front of the contraction they fly over)
     contract(0);
     __builtin_amdgcn_sched_barrier(0);
-    stash(S1{}, 1);                                      // (kt + 1 == nk: a copy of the last slab nobody contracts)
+    stash(S1{}, 1, kt + 1 < nk ? 1.0f : 0.0f);           // (kt + 1 == nk: a copy of the last slab nobody contracts)
     __syncthreads();
     if (kt + 1 < nk) {
       fetch(min(kt + 3, last), S1{});
       __builtin_amdgcn_sched_barrier(0);
       contract(1);
       __builtin_amdgcn_sched_barrier(0);
-      stash(S0{}, 0);
+      stash(S0{}, 0, kt + 2 < nk ? 1.0f : 0.0f);
       __syncthreads();
     }
   }
 
   // ---- partial row sums of squares: the 8 staging lanes of a row hold its pieces ----
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < A_LD; ++i) {
     float v = rsq[i];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    const int64_t row = m0 + r0 + 32 * i;
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    const int64_t row = m0 + r0 + RPP * i;
     if (kq == 0 && row < rows) rsq_part[sl * rows + row] = v;
   }
   // ---- partial scores: C/D layout of the 32 x 32 block -- lane = query column, 16 rows of its half ----
@@ -211,30 +225,38 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_x6_kernel(const float* __r
   }
 }
 
+template <int BK>
+int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice, int ksplit,
+                float* part, float* rsq_part, hipStream_t stream) {
+  const int64_t tiles = (rows + SX_BM - 1) / SX_BM;
+  static bool attr = false;
+  if (!attr) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   2 * SxCfg<BK>::STAGE));
+    attr = true;
+  }
+  hipLaunchKernelGGL(scores_fewq_x6_kernel<BK>, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SxCfg<BK>::STAGE, stream, db,
+                     ldd, rows, queries, ldq, (int)nq, kslice, part, rsq_part);
+  return launch_status("scores_fewq_x6_kernel");
+}
+
 }  // namespace
 
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, float* part, float* rsq_part, hipStream_t stream) {
+                   int ksplit, int slab_k, float* part, float* rsq_part, hipStream_t stream) {
   ANYLOC_CHECK_ARG(db && queries && part && rsq_part, "scores_fewq_x6: null operand");
-  ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % SX_BK == 0 && ksplit >= 1 && ksplit < 65536,
-                   "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
+  ANYLOC_CHECK_ARG(slab_k == 32 || slab_k == 64, "scores_fewq_x6: slab_k %d", slab_k);
+  ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % slab_k == 0 && ksplit >= 1 && ksplit < 65536,
+                   "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of the slab and 1 <= ksplit < 65536");
   ANYLOC_CHECK_ARG(ldd % 4 == 0 && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(db) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(queries) & 15) == 0 && kslice % 4 == 0,
                    "scores_fewq_x6: operands must be 16-byte aligned with row strides that are multiples of 4");
   ANYLOC_CHECK_ARG(127 * ldd * 4 + kslice * 4 < (1ll << 31) && 63 * ldq * 4 + kslice * 4 < (1ll << 31),
                    "scores_fewq_x6: a tile's rows must stay inside 2 GiB of buffer addressing");
-  const int64_t tiles = (rows + SX_BM - 1) / SX_BM;
-  ANYLOC_CHECK_ARG(tiles < (1ll << 31), "scores_fewq_x6: grid too large");
+  ANYLOC_CHECK_ARG((rows + SX_BM - 1) / SX_BM < (1ll << 31), "scores_fewq_x6: grid too large");
   ProfScope prof("topk_scores_gemm", stream, 2.0 * rows * 64 * kslice * ksplit, 4.0 * (rows + 64.0) * kslice * ksplit);
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   2 * SX_STAGE));
-    attr = true;
-  }
-  hipLaunchKernelGGL(scores_fewq_x6_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SX_STAGE, stream, db, ldd, rows,
-                     queries, ldq, (int)nq, kslice, part, rsq_part);
-  return launch_status("scores_fewq_x6_kernel");
+  return slab_k == 32 ? launch_fewq<32>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream)
+                      : launch_fewq<64>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
 }
 
 }  // namespace anyloc
