@@ -464,10 +464,7 @@ constexpr int AH_STAGE = 16384;       // K hi | K lo | V hi | V lo, 4 KiB each
 // QG = 32-query groups per wave (1 or 2), NW = waves per workgroup; a workgroup always covers QG * NW = 4 consecutive
 // groups (128 queries) of one (image, head).  QG = 2: a wave's K / V fragments serve 64 queries, i.e. half the LDS reads,
 // DMA issues and barriers per unit of work, at 2 waves per SIMD.
-// VH = 1: the V fragments are read per 32-column half right before that half's MFMAs (16 live registers instead of 32):
-// 126 VGPRs -> four waves per SIMD, four workgroups per CU (4 x 32 KiB of LDS).  VH = 0: all eight V fragments read before
-// the softmax (152 VGPRs, three per SIMD) -- the round-2 kernel, kept for the A/B.
-template <int QG, int NW, int VH>
+template <int QG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
                                                                   const float* __restrict__ inv, int T, int heads, int64_t G,
                                                                   unsigned char* __restrict__ out2, float* __restrict__ out_inv,
@@ -591,18 +588,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
         }
       }
       // V^T fragments: lane (d = db*32 + ql, half h2), k-step s2: the 8 keys register r = 8 s2 + j of the score block holds
-      attn_u32x4 vfa[2][2][2];
-      if constexpr (VH == 0) {
+      attn_u32x4 vf[2][2][2];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+      for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            const int d = db * 32 + ql;
+        for (int db = 0; db < 2; ++db) {
+          const int d = db * 32 + ql;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-              vfa[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
-          }
-      }
+          for (int s2 = 0; s2 < 2; ++s2)
+            vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
+        }
       const bool edge = gk == g_first || gk == g_last;      // wave-uniform: only the image's first / last key group
       // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
       const float vratio = t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv);
@@ -650,26 +645,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
 #pragma unroll
           for (int r = 0; r < 16; ++r) { oacc[qg][0][r] *= resc; oacc[qg][1][r] *= resc; }
         }
-        // V^T fragments: lane (d = db*32 + ql, half h2), k-step s2: the 8 keys register r = 8 s2 + j of the score block holds;
-        // read per 32-column half right before its MFMAs (16 live registers instead of 32)
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int d = db * 32 + ql;
-          attn_u32x4 vf[2][2];
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              if constexpr (VH == 0) vf[pl][s2] = vfa[pl][db][s2];
-              else vf[pl][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
-            }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            oacc[qg][db] = ANYLOC_MFMA_F16(vf[1][s2], pf[0][s2], oacc[qg][db]);
-            oacc[qg][db] = ANYLOC_MFMA_F16(vf[0][s2], pf[1][s2], oacc[qg][db]);
-            oacc[qg][db] = ANYLOC_MFMA_F16(vf[0][s2], pf[0][s2], oacc[qg][db]);
+          for (int db = 0; db < 2; ++db) {
+            oacc[qg][db] = ANYLOC_MFMA_F16(vf[1][db][s2], pf[0][s2], oacc[qg][db]);
+            oacc[qg][db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[1][s2], oacc[qg][db]);
+            oacc[qg][db] = ANYLOC_MFMA_F16(vf[0][db][s2], pf[0][s2], oacc[qg][db]);
           }
-        }
       }
     }
     __syncthreads();                    // everyone is done with this stage; the next tile's DMA has landed
@@ -770,12 +753,11 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   const size_t lds = 2 * AH_STAGE + 64;
   // four waves of 32 queries per workgroup.  Measured and removed: two waves of 64 queries (12.7 vs 13.7 ms per step at
   // B=61), a software-pipelined loop with a 3-stage ring (15.0 ms), and (round 3) all K fragments of a tile read first with
-  // the twelve score MFMAs issued back to back (13.2 vs 13.2 ms: no effect) -- DESIGN.md 4.2b
+  // the twelve score MFMAs issued back to back (13.2 vs 13.2 ms) and the V fragments read per 32-column half (126 instead of
+  // 152 VGPRs: four waves per SIMD; 13.4 vs 13.5 ms): neither the dependent-chain gaps nor the occupancy is what holds this
+  // kernel at 40 % matrix-core utilisation -- DESIGN.md 4.2b
   const dim3 grid((qgroups + 3) / 4, heads, (unsigned)batch);
-  if (option(OPT_ATTN_H3_OCC) >= 4)
-    hipLaunchKernelGGL((attention_h3_kernel<1, 4, 1>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
-  else
-    hipLaunchKernelGGL((attention_h3_kernel<1, 4, 0>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
+  hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
   return launch_status("attention_h3_kernel");
 }
 

@@ -68,7 +68,6 @@ enum Option {
   OPT_H3_MIN_ROWS,       // h3 forward: below this many token rows use the fp32-MFMA kernels
   OPT_X6_MIN_ROWS,       // x6 forward: the same
   OPT_ATTN_CFG,          // fp32-MFMA attention: workgroup shape (micro-benchmarks)
-  OPT_ATTN_H3_OCC,       // attention_h3: waves per SIMD the kernel is compiled for (2 = ~152 VGPRs, 4 = <= 128)
   OPT_ATTN_X6,           // anyloc_attention: 1 = split-bf16 products for every call, 0 = never, -1 = as the caller asks
   OPT_VLAD_PARTS,        // workgroups per image of the fused VLAD kernel (0 = chosen from the image count)
   OPT_VLAD_TWO_PASS,     // 1 = force the general two-pass VLAD path
@@ -166,7 +165,7 @@ int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream);
 // the same pass with both operands split on the fly into three bf16 planes (six bf16 MFMA products, fp32 accumulate):
 // part[s][row][0..63] and rsq_part[s][row] for K slices s < ksplit of length kslice (scores_x6.hip)
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, int slab_k /* 32 or 64 */, float* part, float* rsq_part, hipStream_t stream);
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {

@@ -36,8 +36,8 @@ typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sx_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SX_BM = 128, SX_BN = 64;
-// BK = k per slab: 32 (128 B per database row and slab, two workgroups per CU) or 64 (256 B per row and slab -- longer runs
-// per DRAM page -- one workgroup per CU)
+// BK = k per slab: 32 (128 B per database row and slab, two workgroups per CU).  A 64-k slab (256 B runs, one workgroup per
+// CU) was measured slower: 0.71 vs 0.61 ms at the bench shape (profiles/r03_fewq_x6.log)
 template <int BK>
 struct SxCfg {
   static constexpr int ALD = BK + 4;                     // floats per database row in LDS (BK = 32: 36, BK = 64: 68 -> 16-byte slots 9 r / 17 r mod 16: conflict-free)
@@ -243,11 +243,10 @@ int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries
 }  // namespace
 
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, int slab_k, float* part, float* rsq_part, hipStream_t stream) {
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream) {
   ANYLOC_CHECK_ARG(db && queries && part && rsq_part, "scores_fewq_x6: null operand");
-  ANYLOC_CHECK_ARG(slab_k == 32 || slab_k == 64, "scores_fewq_x6: slab_k %d", slab_k);
-  ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % slab_k == 0 && ksplit >= 1 && ksplit < 65536,
-                   "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of the slab and 1 <= ksplit < 65536");
+  ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % 32 == 0 && ksplit >= 1 && ksplit < 65536,
+                   "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
   ANYLOC_CHECK_ARG(ldd % 4 == 0 && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(db) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(queries) & 15) == 0 && kslice % 4 == 0,
                    "scores_fewq_x6: operands must be 16-byte aligned with row strides that are multiples of 4");
@@ -255,8 +254,7 @@ int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* quer
                    "scores_fewq_x6: a tile's rows must stay inside 2 GiB of buffer addressing");
   ANYLOC_CHECK_ARG((rows + SX_BM - 1) / SX_BM < (1ll << 31), "scores_fewq_x6: grid too large");
   ProfScope prof("topk_scores_gemm", stream, 2.0 * rows * 64 * kslice * ksplit, 4.0 * (rows + 64.0) * kslice * ksplit);
-  return slab_k == 32 ? launch_fewq<32>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream)
-                      : launch_fewq<64>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
+  return launch_fewq<32>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
 }
 
 }  // namespace anyloc

@@ -60,7 +60,6 @@ const char* anyloc_last_error(void);
  *   ln_small_rows (4096)              layernorm_h2: one row per wave below this many rows
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
- *   attn_h3_occ (2)                   attention_h3 compiled for 2 (~152 VGPRs) or 4 (<= 128 VGPRs) waves per SIMD
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call

@@ -347,8 +347,8 @@ def test_split_h2_wide_rows():
 
 # ------------------------------------------------------------------- scheduling variants must not change a bit
 def test_scheduling_variants_are_bitwise_equal():
-    """layernorm_h2 with 1 / 2 / 4 rows per wave (option ln_rows_per_wave) and attention_h3 compiled for 2 or 4 waves per
-    SIMD (option attn_h3_occ) reorder instructions, not arithmetic: the tokens are the same bits."""
+    """layernorm_h2 with 1 / 2 / 4 rows per wave (option ln_rows_per_wave) reorders instructions, not arithmetic: the
+    tokens are the same bits."""
     import utilities
     from anyloc_amd import ops, weights
     name = "dinov2_vitg14"
@@ -358,8 +358,7 @@ def test_scheduling_variants_are_bitwise_equal():
         img = torch.randn(5, 3, 322, 322, generator=torch.Generator().manual_seed(4)).to("cuda")
         base = ext(img).clone()
         assert torch.isfinite(base).all()
-        for opts in (dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2), dict(ln_rows_per_wave=4), dict(attn_h3_occ=4),
-                     dict(attn_h3_occ=2)):
+        for opts in (dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2), dict(ln_rows_per_wave=4)):
             with ops.options(**opts):
                 assert torch.equal(ext(img), base), opts
     finally:
