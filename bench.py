@@ -596,7 +596,8 @@ def stage_b1(ext, qu_img):
     other = float((ext(imgs[3]) - batch[3:4]).abs().max())
     fl = flops_per_image()
     return {"workload": "DinoV2ExtractFeatures.__call__ at B=1, ViT-G/14 L31 value, 322x322 (the reference scripts' calling convention)",
-            "ms_per_image": round(el * 1e3, 3), "images_per_s": round(1.0 / el, 1), "bound": "launch latency",
+            "ms_per_image": round(el * 1e3, 3), "images_per_s": round(1.0 / el, 1),
+            "bound": "latency: ~220 dependent launches of 13-61 us, each a few hundred small tiles (DESIGN.md 8)",
             "achieved": round(fl / el / 1e12, 1), "unit": "TFLOP/s (algorithmic)", "kernels_ms": kern,
             "oracle_ok": None, "bitwise_equal_to_first_image_of_a_batch": same, "max_abs_diff_at_another_batch_position": other}
 
@@ -686,10 +687,11 @@ def stage_config3_shard(dev, check):
     planted = bool((i[:64, 0] == rows).all())
     res = {"workload": "BASELINE.json configs[2], one shard: 10k queries x 125k rows x 49152-d, top-20 (cosine, normalise inside)",
            "ms": round(el * 1e3, 2), "queries_per_s": round(nq / el, 1), "bound": "mfma", "achieved": round(flops / el / 1e12, 2),
-           "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(flops / el / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-           "peak_note": "fp32-MFMA peak; the score panels run on the two-term fp16 GEMM (3 fp16 products per fp32-accurate "
-                        "product: dense 16-bit peak 2500 / 3 = 833.3), frac_of_833 alongside",
-           "frac_of_833": round(flops / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+           "unit": "TFLOP/s (algorithmic, fp32-equivalent)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
+           "frac": round(flops / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+           "peak_note": "the score panels run on the two-term fp16 GEMM: 3 fp16 products per fp32-accurate product, dense 16-bit "
+                        "peak 2500 / 3 = 833.3; `vs_fp32_mfma_peak` = achieved / 157.3 (the roofline of the round-2 fp32-MFMA panels)",
+           "vs_fp32_mfma_peak": round(flops / el / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
            "kernels_ms": kern, "planted_neighbours_found": planted, "oracle_ok": None}
     if check:
         # the many-query panel path on a slice the CPU can score: 96 queries x 3000 rows vs the flat-index restatement
