@@ -165,7 +165,7 @@ int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream);
 // the same pass with both operands split on the fly into three bf16 planes (six bf16 MFMA products, fp32 accumulate):
 // part[s][row][0..63] and rsq_part[s][row] for K slices s < ksplit of length kslice (scores_x6.hip)
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, float* part, float* rsq_part, hipStream_t stream);
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream, int ablation = 0 /* timing-only, see scores_x6.hip */);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {

@@ -22,7 +22,7 @@
 //             -> fragment reads (8 consecutive k per lane: 2 x ds_read_b128, conflict-free) -> split in registers
 //   queries   global (L2-resident) -> registers -> split ONCE per workgroup -> LDS as three bf16 planes, rows padded to 80 B
 //             -> fragment reads (ds_read_b128, conflict-free)
-//   12 MFMAs per k-step of 16 (6 plane products x 2 query blocks), smallest products first, one accumulator per block.
+//   12 MFMAs per k-step of 16 (6 plane products x 2 query blocks); two accumulators per block (leading / 2^-16 products).
 #include <type_traits>
 
 #include "common.hpp"
@@ -54,7 +54,9 @@ __device__ __forceinline__ f32x4 sx_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
-template <int BK>
+// ABL (timing-only ablations for tools/time_topk.py, results are WRONG when != 0): 1 = no contraction (loads, LDS staging and
+// barriers only), 2 = loads only (their values folded into the row sums of squares so that they are not dead)
+template <int BK, int ABL = 0>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(const float* __restrict__ db, int64_t ldd, int64_t rows,
                                                                 const float* __restrict__ qu, int64_t ldq, int nq,
                                                                 int64_t kslice, float* __restrict__ part,
@@ -111,6 +113,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
   // end (its squares must not be counted a second time; the LDS image it leaves is never contracted)
   auto stash = [&](auto setc, int stage, float real) {   // register set S -> LDS stage
     constexpr int S = decltype(setc)::value;
+    if constexpr (ABL == 2) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) rsq[i] += ra[S][i][0] + ra[S][i][3];
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) rsq[0] += rb[S][i][1];
+      return;
+    }
     unsigned char* st = sx_smem + stage * SX_STAGE;
     float* ad = reinterpret_cast<float*>(st) + r0 * SX_ALD + 4 * kq;
 #pragma unroll
@@ -135,14 +144,20 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
     }
   };
 
-  f32x16 acc[2];
+  // Two accumulators per 32 x 32 block: the three leading products (a1 b1, a1 b2, a2 b1) and the three of relative size
+  // 2^-16 (a2 b2, a1 b3, a3 b1).  In ONE accumulator the small ones are below half an ulp of the running sum after a few
+  // hundred k and round away -- harmless when their signs are random, but a query that IS (nearly) a database row makes
+  // a2 b2 = x2^2 >= 0 for every k: a systematic -4e-6 on a cosine of 1 (measured on the 131 072-column ViT-L VLADs).
+  // Summed among themselves they keep their bits; the two sums are added once at the end.
+  f32x16 acc[2], accl[2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[ni][r] = 0.0f; accl[ni][r] = 0.0f; }
 
   const int fr = lane & 31, fh = lane >> 5;
   auto contract = [&](int stage) {                       // the 32-k slab sitting in LDS stage `stage`
+    if constexpr (ABL != 0) return;
     const unsigned char* st = sx_smem + stage * SX_STAGE;
     const float* ap = reinterpret_cast<const float*>(st) + (wave * 32 + fr) * SX_ALD + 8 * fh;
     const unsigned char* bp = st + SX_A_BYTES + fr * SX_BROW + fh * 16;
@@ -170,10 +185,10 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) bf[ni][pl] = __builtin_bit_cast(sx_bf16x8, bw[ni][pl]);
       }
-#define ANYLOC_SX_TERM(pa, pb) \
-  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bf[ni][pb], acc[ni], 0, 0, 0);
-      ANYLOC_SX_TERM(2, 0) ANYLOC_SX_TERM(0, 2) ANYLOC_SX_TERM(1, 1)
-      ANYLOC_SX_TERM(1, 0) ANYLOC_SX_TERM(0, 1) ANYLOC_SX_TERM(0, 0)
+#define ANYLOC_SX_TERM(A, pa, pb) \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) A[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bf[ni][pb], A[ni], 0, 0, 0);
+      ANYLOC_SX_TERM(accl, 2, 0) ANYLOC_SX_TERM(accl, 0, 2) ANYLOC_SX_TERM(accl, 1, 1)
+      ANYLOC_SX_TERM(acc, 1, 0) ANYLOC_SX_TERM(acc, 0, 1) ANYLOC_SX_TERM(acc, 0, 0)
 #undef ANYLOC_SX_TERM
     }
   };
@@ -193,14 +208,14 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
     contract(0);
     __builtin_amdgcn_sched_barrier(0);
     stash(S1{}, 1, kt + 1 < nk ? 1.0f : 0.0f);           // (kt + 1 == nk: a copy of the last slab nobody contracts)
-    __syncthreads();
+    if constexpr (ABL != 2) __syncthreads();
     if (kt + 1 < nk) {
       fetch(min(kt + 3, last), S1{});
       __builtin_amdgcn_sched_barrier(0);
       contract(1);
       __builtin_amdgcn_sched_barrier(0);
       stash(S0{}, 0, kt + 2 < nk ? 1.0f : 0.0f);
-      __syncthreads();
+      if constexpr (ABL != 2) __syncthreads();
     }
   }
 
@@ -220,22 +235,22 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
     const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
     if (row < rows) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) out[row * 64 + ni * 32 + fr] = acc[ni][r];
+      for (int ni = 0; ni < 2; ++ni) out[row * 64 + ni * 32 + fr] = acc[ni][r] + accl[ni][r];
     }
   }
 }
 
-template <int BK>
+template <int BK, int ABL = 0>
 int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice, int ksplit,
                 float* part, float* rsq_part, hipStream_t stream) {
   const int64_t tiles = (rows + SX_BM - 1) / SX_BM;
   static bool attr = false;
   if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   2 * SxCfg<BK>::STAGE));
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK, ABL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SxCfg<BK>::STAGE));
     attr = true;
   }
-  hipLaunchKernelGGL(scores_fewq_x6_kernel<BK>, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SxCfg<BK>::STAGE, stream, db,
+  hipLaunchKernelGGL((scores_fewq_x6_kernel<BK, ABL>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SxCfg<BK>::STAGE, stream, db,
                      ldd, rows, queries, ldq, (int)nq, kslice, part, rsq_part);
   return launch_status("scores_fewq_x6_kernel");
 }
@@ -243,7 +258,7 @@ int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries
 }  // namespace
 
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, float* part, float* rsq_part, hipStream_t stream) {
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream, int ablation) {
   ANYLOC_CHECK_ARG(db && queries && part && rsq_part, "scores_fewq_x6: null operand");
   ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % 32 == 0 && ksplit >= 1 && ksplit < 65536,
                    "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
@@ -254,6 +269,8 @@ int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* quer
                    "scores_fewq_x6: a tile's rows must stay inside 2 GiB of buffer addressing");
   ANYLOC_CHECK_ARG((rows + SX_BM - 1) / SX_BM < (1ll << 31), "scores_fewq_x6: grid too large");
   ProfScope prof("topk_scores_gemm", stream, 2.0 * rows * 64 * kslice * ksplit, 4.0 * (rows + 64.0) * kslice * ksplit);
+  if (ablation == 1) return launch_fewq<32, 1>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
+  if (ablation == 2) return launch_fewq<32, 2>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
   return launch_fewq<32>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
 }
 

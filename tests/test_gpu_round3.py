@@ -391,3 +391,23 @@ def test_topk_few_queries_on_the_fly_bf16_split(metric, norm):
         with ops.options(topk_fewq_x6=0):
             d0, i0 = ops.topk(qd, db.to("cuda"), k, metric, normalize_db=norm)
         assert float((i0 != i).float().mean()) < 0.003
+
+
+@pytest.mark.parametrize("nq", [8, 200])
+def test_topk_self_match_keeps_the_small_products(nq):
+    """A query that IS a database row (cosine 1): every term of the contraction is a square, so products that are dropped or
+    absorbed add up instead of averaging out -- the few-query bf16 split keeps its 2^-16-sized plane products in their own
+    accumulator, the fp16 panels cut K into chunks.  131 072 columns (the ViT-L two-tap VLAD), vs float64."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    dim, ndb = 131072, 260
+    db = torch.nn.functional.normalize(torch.randn(ndb, dim, generator=g).abs() + 0.5, dim=1) * 2.5     # all-positive rows
+    qu = db[:nq].clone()
+    with ops.options(topk_h3=1):
+        d, i = ops.topk(torch.nn.functional.normalize(qu).to("cuda"), db.to("cuda"), 5, "ip", normalize_db=True)
+    assert torch.equal(i[:, 0].cpu(), torch.arange(nq))
+    _check_topk(d, i, qu, db, 5, "ip", True)
+    q64 = torch.nn.functional.normalize(qu.double())
+    d64 = torch.nn.functional.normalize(db.double())
+    exact = (q64 @ d64.t()).topk(5, dim=1)[0]
+    assert float((d.cpu().double() - exact).abs().max()) <= 2e-6
