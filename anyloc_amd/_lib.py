@@ -47,7 +47,8 @@ H2_FIELDS = ("qkv_w2", "qkv_inv", "proj_w2", "proj_inv", "fc1_w2", "fc1_inv", "f
 
 
 class VitBlockH2(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in H2_FIELDS] + [("fc1_bound", C.c_float * 4)]
+    _fields_ = [(n, C.c_void_p) for n in H2_FIELDS] + [("fc1_bound", C.c_float * 4), ("fc1_b2", C.c_void_p),
+                                                       ("fc1_layout", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); also the list the symbol-export test checks

@@ -74,6 +74,7 @@ enum Option {
   OPT_VLAD_FUSED_V,      // fused VLAD kernel: 0 = default choice, 1 = exact-score kernel, 3 / 4 = screening kernel with 4 / 8 waves
   OPT_KMEANS_FUSED_V,    // the same for the k-means step
   OPT_KMEANS_MAX_CHUNKS, // k-means: upper limit of row chunks (partial sums); 0 = two per CU
+  OPT_H3_SWIGLU_T,       // Python host: build the SwiGLU fc1 image in the 16-channel block layout (transposed-accumulator epilogue)
   OPT_H3_FAST_SILU,      // fused SwiGLU epilogue of the h3 w12 GEMM: SiLU on v_exp_f32 + v_rcp_f32 instead of expf + IEEE division
   OPT_TOPK_FEWQ_X6,      // few-query retrieval scores: 1 = database split on the fly into bf16 planes (scores_x6.hip), 0 = fp32 MFMA
   OPT_TOPK_H3,           // retrieval score panels on the two-term fp16 GEMM: -1 = where it pays, 0 = never, 1 = wherever possible
@@ -139,7 +140,11 @@ enum GemmEpilogue {
   // gemm_h3 only: the result leaves the kernel already quantised for its consumer (no fp32 round trip)
   EPI_QKV_PLANES = 5, // q | k | v written as per-head two-plane fp16 tiles + one 2^-e per (32-row group, head): attention_h3
   EPI_GELU_H2 = 6,    // gelu(acc + bias) written as the h2 image of the next GEMM, rows scaled by the caller's c_inv
-  EPI_SWIGLU_H2 = 7   // silu(gate) * value, the same
+  EPI_SWIGLU_H2 = 7,  // silu(gate) * value, the same
+  // gemm_h3 only, weights in the 16-channel block layout (anyloc_vit_block_h2.fc1_layout = 1): the product is formed
+  // transposed (weights as the MFMA A operand), a lane holds one token and 8 consecutive gate / value channels
+  EPI_SWIGLU_T = 8,   // C[:, n/2] = silu(gate) * value as fp32
+  EPI_SWIGLU_T_H2 = 9 // ... as the h2 image of the next GEMM, 16-byte chunks straight from the accumulators
 };
 
 struct GemmProblem {

@@ -81,6 +81,7 @@ __device__ __forceinline__ float h3_silu_fast(float v) {
 template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p, int tiles_m, int tiles_n) {
   using Cfg = H3Cfg<MI, NI, WM, WN, STAGES, KB>;
+  constexpr bool TR = EPI == EPI_SWIGLU_T || EPI == EPI_SWIGLU_T_H2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -149,9 +150,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
         for (int ni = 0; ni < NI; ++ni) b[ni][pl] = *reinterpret_cast<const f16x8*>(sw + pl * Cfg::W_PLANE + ni * 1024);
       }
       if (kb == 0) issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
+      // TR (EPI_SWIGLU_T*): the weight fragment is the MFMA's A operand, so acc[mi][ni] holds the TRANSPOSED 32 x 32 block --
+      // lane = token, registers = 16 weight rows -- same products, same sums, other owner of each element
 #define ANYLOC_H3_TERM(pa, pb)                                                                       \
   _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
+      acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][pb], a[mi][pa], acc[mi][ni], 0, 0, 0) \
+                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
       ANYLOC_H3_TERM(1, 0) ANYLOC_H3_TERM(0, 1) ANYLOC_H3_TERM(0, 0)
 #undef ANYLOC_H3_TERM
     }
@@ -173,6 +177,60 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if constexpr (TR) {
+    // SwiGLU on transposed accumulators (weights in the 16-channel block layout, include/anyloc_hip.h): lane (token n =
+    // lane & 31, half hl) holds, of the 32-row weight block ni, rows 4 hl + {0..3}, 8 + 4 hl + {0..3} = the GATES of hidden
+    // channels c .. c+7 (c = 16 * block + 8 hl) in registers 0..7 and rows 16 + ..., 24 + ... = their VALUES in registers
+    // 8..15.  silu(g) * v of one token and 8 consecutive channels is exactly one 16-byte chunk per plane of the fc2 operand
+    // image: no LDS transposition, two 16-byte stores per block and lane, 32 rows x 32 B = whole 1-KiB runs per instruction.
+    const int hl = lane >> 5;
+    const int64_t wr0 = n0 + wn * 32 * NI;               // first weight row of this wave (N % (32 NI) == 0: all-in or all-out)
+    if (wr0 >= p.N) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int64_t row = m0 + wm * 32 * MI + mi * 32 + (lane & 31);
+      const bool rok = row < p.M;
+      const float ai = rok ? p.a_inv[row] : 0.0f;
+      float cs = 1.0f;
+      if constexpr (EPI == EPI_SWIGLU_T_H2) cs = rok ? h2_scale_of_inv(p.c_inv[row]) : 0.0f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int64_t wr = wr0 + ni * 32 + 4 * hl;
+        f32x4 sc[4], bi[4];                              // [gate rows 0..3, gate rows 4..7, value rows 0..3, value rows 4..7]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sc[q] = *reinterpret_cast<const f32x4*>(p.w_inv + wr + 8 * q);
+          bi[q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wr + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = acc[mi][ni][j] * (ai * sc[j >> 2][j & 3]) + bi[j >> 2][j & 3];
+          const float v = acc[mi][ni][8 + j] * (ai * sc[2 + (j >> 2)][j & 3]) + bi[2 + (j >> 2)][j & 3];
+          o[j] = (p.fast_silu ? h3_silu_fast(g) : h3_silu(g)) * v;
+        }
+        const int64_t blk = (wr0 + ni * 32) >> 5;         // 16 hidden channels per weight block: channels 16 blk + 8 hl + j
+        if (rok) {
+          if constexpr (EPI == EPI_SWIGLU_T_H2) {
+            unsigned qh[4], ql[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h2_pack2(o[2 * j] * cs, o[2 * j + 1] * cs, qh[j], ql[j]);
+            hu32x4 ph, plo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ph[j] = qh[j]; plo[j] = ql[j]; }
+            unsigned char* dst = p.C2 + ((blk * 2) * p.RC + row) * 32 + ((hl ^ (int)((row >> 3) & 1)) << 4);
+            *reinterpret_cast<hu32x4*>(dst) = ph;
+            *reinterpret_cast<hu32x4*>(dst + p.RC * 32) = plo;
+          } else {
+            float* dst = p.C + row * p.ldc + 16 * blk + 8 * hl;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: acc * 2^-(e_row + e_col), then the same fused forms as gemm_x6.hip / gemm_f32.hip ----
   const int64_t wrow0 = m0 + wm * 32 * MI + 4 * (lane >> 5);
   const int64_t wcol0 = n0 + wn * 32 * NI + (lane & 31);
@@ -909,6 +967,17 @@ int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
       ANYLOC_CHECK_ARG(p.C2 && p.c_inv && p.RC >= p.M && p.N % 128 == 0, "gemm_h3: SWIGLU_H2 needs an output image, c_inv and N %% 128 == 0");
       p.fast_silu = option(OPT_H3_FAST_SILU) != 0;
       return dispatch_h3<EPI_SWIGLU_H2>(p, stream);
+    case EPI_SWIGLU_T:
+    case EPI_SWIGLU_T_H2:
+      ANYLOC_CHECK_ARG(p.N % 128 == 0 && (reinterpret_cast<uintptr_t>(p.w_inv) & 15) == 0 &&
+                           (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0),
+                       "gemm_h3: SWIGLU_T needs N %% 128 == 0 and 16-byte aligned w_inv / bias");
+      if (epilogue == EPI_SWIGLU_T_H2)
+        ANYLOC_CHECK_ARG(p.C2 && p.c_inv && p.RC >= p.M, "gemm_h3: SWIGLU_T_H2 needs an output image and c_inv");
+      else
+        ANYLOC_CHECK_ARG(p.C && p.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0, "gemm_h3: SWIGLU_T needs an aligned fp32 output");
+      p.fast_silu = option(OPT_H3_FAST_SILU) != 0;
+      return epilogue == EPI_SWIGLU_T ? dispatch_h3<EPI_SWIGLU_T>(p, stream) : dispatch_h3<EPI_SWIGLU_T_H2>(p, stream);
     default: set_error("gemm_h3: unsupported epilogue %d", epilogue); return ANYLOC_ERR_INVALID_ARG;
   }
 }

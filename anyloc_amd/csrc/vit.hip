@@ -223,6 +223,9 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
     const anyloc_vit_block_h2& b = blocks[i];
     ANYLOC_CHECK_ARG(b.qkv_w2 && b.qkv_inv && b.proj_w2 && b.proj_inv && b.fc1_w2 && b.fc1_inv && b.fc2_w2 && b.fc2_inv,
                      "vit_attach_h2: block %d has a null image or scale array", i);
+    ANYLOC_CHECK_ARG(b.fc1_layout == 0 || (b.fc1_layout == 1 && h->cfg.ffn_kind == 1 && b.fc1_b2 && h->cfg.ffn_hidden % 64 == 0),
+                     "vit_attach_h2: block %d: fc1_layout %d (1 needs a SwiGLU model, fc1_b2 and ffn_hidden %% 64 == 0)", i,
+                     b.fc1_layout);
   }
   h->h2.assign(blocks, blocks + h->cfg.depth);
   return ANYLOC_OK;
@@ -361,8 +364,10 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, nullptr, Hh, M, Hh,
                              EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv));
       else
-        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0, b.fc1_b, nullptr, Hh, M,
-                             2 * Hh, EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3, w.hinv));
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0,
+                             h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, nullptr, Hh, M, 2 * Hh,
+                             h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
+                             w.hinv));
       ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
     } else if (h3m) {
@@ -370,8 +375,9 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, w.h, Hh, M, Hh,
                              EPI_GELU, nullptr, "vit_fc1_gemm", stream));
       else
-        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0, b.fc1_b, w.h, Hh, M,
-                             2 * Hh, EPI_SWIGLU, nullptr, "vit_w12_gemm", stream));
+        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0,
+                             h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, w.h, Hh, M, 2 * Hh,
+                             h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T : EPI_SWIGLU, nullptr, "vit_w12_gemm", stream));
       ANYLOC_TRY(linear_h3(w.h, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
     } else if (x6) {

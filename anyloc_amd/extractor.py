@@ -32,6 +32,16 @@ def _on_device(device):
     return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
+def swiglu_t_rows(hidden):
+    """Row order of the fused w12 matrix ([gates; values], 2 * hidden rows) in the 16-channel block layout: position
+    32 B + 16 v + 8 q + 4 h + i  <-  row v * hidden + 16 B + 8 h + 4 q + i."""
+    t = torch.arange(2 * hidden)
+    blk, r = t // 32, t % 32
+    v, u = r // 16, r % 16
+    q, h, i = u // 8, (u // 4) % 2, u % 4
+    return v * hidden + 16 * blk + 8 * h + 4 * q + i
+
+
 def interpolate_pos_embed(pos_embed, h_img, w_img):
     """Positional table for an ``h_img x w_img`` input: [1, 1+37*37, D] ->
     [1 + (h/14)*(w/14), D].  Input-independent, computed once per resolution on
@@ -118,8 +128,20 @@ class HipDinoV2:
                     self._keep.append(img3)
                     setattr(x3[i], f3, img3.data_ptr())
             if self.gemm == "h3":
+                # SwiGLU, option h3_swiglu_t (read here, once per model): the fc1 image in the 16-channel block layout of
+                # include/anyloc_hip.h (anyloc_vit_block_h2.fc1_layout = 1) -- block row t = 16 v + 8 q + 4 h + i holds
+                # channel 16 B + 8 h + 4 q + i of the gates (v = 0) / values (v = 1), the order in which the transposed
+                # MFMA accumulators of gemm_h3's SwiGLU epilogue hold them
+                swiglu_t = self.ffn_kind == 1 and hidden % 64 == 0 and ops.get_option("h3_swiglu_t") != 0
                 for f in ("qkv", "proj", "fc1", "fc2"):
-                    img2, inv = ops.split_h2(dev(vals[f + "_w"]))
+                    mat = dev(vals[f + "_w"])
+                    if f == "fc1" and swiglu_t:
+                        src = swiglu_t_rows(hidden).to(mat.device)
+                        mat = dev(w12)[src]
+                        b2 = keep(dev(b12)[src])
+                        h2[i].fc1_b2 = b2.data_ptr()
+                        h2[i].fc1_layout = 1
+                    img2, inv = ops.split_h2(mat.contiguous())
                     self._keep += [img2, inv]
                     setattr(h2[i], f + "_w2", img2.data_ptr())
                     setattr(h2[i], f + "_inv", inv.data_ptr())

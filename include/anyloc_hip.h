@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 3
+#define ANYLOC_ABI_VERSION 4
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -64,6 +64,8 @@ const char* anyloc_last_error(void);
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
+ *   h3_swiglu_t (1)                   read by the Python host when a model is built: SwiGLU fc1 image in the 16-channel block
+ *                                     layout (anyloc_vit_block_h2.fc1_layout = 1: epilogue straight from transposed accumulators)
  *   h3_fast_silu (1)                  fused SwiGLU epilogue: SiLU on the hardware exp2 / rcp (1 ulp each)
  *   topk_fewq_x6 (1)                  anyloc_topk with <= 64 queries: database rows split on the fly into bf16 planes (HBM-bound)
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
@@ -341,6 +343,15 @@ typedef struct anyloc_vit_block_h2 {
    * max value-row L2 norm, max |value bias|}; the value pair is 0 for the GELU mlp.  All zero = not provided: the
    * activation is then written as fp32 and quantised by a separate pass. */
   float fc1_bound[4];
+  /* SwiGLU only (ABI 4).  fc1_layout = 0: the rows of fc1_w2 are interleaved 32 gate / 32 value (the layout of
+   * anyloc_vit_block_weights.fc1_w; fc1_b2 may be NULL = use fc1_b).  fc1_layout = 1: every 32-row block of fc1_w2
+   * holds 16 consecutive hidden channels c .. c+15 so that the MFMA accumulators of the TRANSPOSED product (weights as
+   * the A operand) give one lane a token row and 8 consecutive gate / value channels: block row t = 16 v + 8 q + 4 h + i
+   * (v = 0 gate / 1 value, q, h in {0, 1}, i < 4) is channel c + 8 h + 4 q + i -- the SwiGLU epilogue then writes its
+   * 16-byte image chunks straight from registers.  fc1_b2: the fc1 bias in the row order of fc1_w2 (device, [2 hidden]). */
+  const float* fc1_b2;
+  int32_t fc1_layout;
+  int32_t reserved;
 } anyloc_vit_block_h2;
 int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*host array [depth]*/);
 #define ANYLOC_VIT_SPLIT_FP16 16u    /* block GEMMs as three fp16 products, fp32-level accuracy */

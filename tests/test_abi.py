@@ -33,7 +33,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.anyloc_version() == 3      # ANYLOC_ABI_VERSION of include/anyloc_hip.h
+    assert lib.anyloc_version() == 4      # ANYLOC_ABI_VERSION of include/anyloc_hip.h
     assert isinstance(lib.anyloc_last_error(), bytes)
 
 

@@ -411,3 +411,33 @@ def test_topk_self_match_keeps_the_small_products(nq):
     d64 = torch.nn.functional.normalize(db.double())
     exact = (q64 @ d64.t()).topk(5, dim=1)[0]
     assert float((d.cpu().double() - exact).abs().max()) <= 2e-6
+
+
+def test_swiglu_transposed_epilogue_agrees_with_the_lds_one():
+    """Option h3_swiglu_t (read when the model is built): the w12 weights in the 16-channel block layout, the product
+    formed transposed (weights as the MFMA's A operand), SiLU(gate) * value written as 16-byte image chunks straight from
+    the accumulators -- against the 32 / 32 interleave whose epilogue goes through LDS: the same products and epilogue
+    formula (the matrix cores sum a transposed block in another order: not the same bits), fused and unfused, at the
+    bench tile configuration and at the small-tile ones.  The full-depth oracle parity suite runs with either layout."""
+    import utilities
+    from anyloc_amd import ops, weights
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device="cuda", depth=3))
+    try:
+        img = torch.randn(5, 3, 322, 322, generator=torch.Generator().manual_seed(4)).to("cuda")
+        out = {}
+        for t in (0, 1):
+            with ops.options(h3_swiglu_t=t):
+                ext = utilities.DinoV2ExtractFeatures(name, 2, "token", use_cls=True, norm_descs=False, device="cuda")
+            out[t, 1] = ext(img).clone()
+            with ops.options(h3_fuse=0):
+                out[t, 0] = ext(img).clone()
+            one = ext(img[:1]).clone()                                   # the small-tile configurations (one image)
+            assert torch.equal(one, ext(img[:1])) and float((one - out[t, 1][:1]).abs().max()) < 2e-6 * float(one.abs().max())
+        assert torch.isfinite(out[0, 1]).all()
+        scale = float(out[0, 1].abs().max())
+        assert float((out[0, 1] - out[1, 1]).abs().max()) <= 2e-6 * scale
+        assert float((out[0, 0] - out[1, 0]).abs().max()) <= 2e-6 * scale
+        assert float((out[1, 1] - out[1, 0]).abs().max()) <= 2e-6 * scale
+    finally:
+        weights.unregister_state_dict(name)
