@@ -74,6 +74,7 @@ enum Option {
   OPT_VLAD_FUSED_V,      // fused VLAD kernel: 0 = default choice, 1 = exact-score kernel, 3 / 4 = screening kernel with 4 / 8 waves
   OPT_KMEANS_FUSED_V,    // the same for the k-means step
   OPT_KMEANS_MAX_CHUNKS, // k-means: upper limit of row chunks (partial sums); 0 = two per CU
+  OPT_H3_MFMA16,         // gemm_h3: 1 = large GEMMs on the 16x16x32 MFMA kernel (gemm_h3m.hip) where it has the epilogue
   OPT_H3_SWIGLU_T,       // Python host: build the SwiGLU fc1 image in the 16-channel block layout (transposed-accumulator epilogue)
   OPT_H3_FAST_SILU,      // fused SwiGLU epilogue of the h3 w12 GEMM: SiLU on v_exp_f32 + v_rcp_f32 instead of expf + IEEE division
   OPT_TOPK_FEWQ_X6,      // few-query retrieval scores: 1 = database split on the fly into bf16 planes (scores_x6.hip), 0 = fp32 MFMA
@@ -241,6 +242,8 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
 int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsigned char* planes, float* inv,
                         hipStream_t stream);
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
+// the same GEMM on v_mfma_f32_16x16x32_f16 (gemm_h3m.hip); ANYLOC_ERR_UNSUPPORTED for epilogues it does not have
+int gemm_h3m(const H3Problem& p, int epilogue, hipStream_t stream);
 
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
                 int64_t dim, float eps, hipStream_t stream);

@@ -941,6 +941,13 @@ int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
   // tile-rows per scheduling group (co-resident workgroups of an XCD share A / W panels through its L2): option
   // h3_group_m, default 8
   p.group_m = (int)std::max<int64_t>(1, option(OPT_H3_GROUP_M));
+  // plain-store GEMMs of >= 256 tiles of 256 x 256 run on the 16 x 16 x 32 MFMA kernel (gemm_h3m.hip; option h3_mfma16: -1 =
+  // when the contraction is >= 4096 long -- the retrieval panels, +3.6 % -- 0 never, 1 whatever the length)
+  const int64_t m16 = option(OPT_H3_MFMA16);
+  if (epilogue == EPI_STORE && m16 != 0 && (m16 > 0 || p.K16 >= 256) && ((p.M + 255) / 256) * ((p.N + 255) / 256) >= 256) {
+    const int rc = gemm_h3m(p, epilogue, stream);
+    if (rc != ANYLOC_ERR_UNSUPPORTED) return rc;
+  }
   switch (epilogue) {
     case EPI_STORE: return dispatch_h3<EPI_STORE>(p, stream);
     case EPI_GELU: return dispatch_h3<EPI_GELU>(p, stream);

@@ -64,6 +64,8 @@ const char* anyloc_last_error(void);
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
+ *   h3_mfma16 (-1)                    plain-store two-term fp16 GEMMs of >= 256 tiles of 256 x 256 on the 16 x 16 x 32 MFMA kernel
+ *                                     (csrc/gemm_h3m.hip): -1 when the contraction is >= 4096 long (retrieval panels), 0 never, 1 always
  *   h3_swiglu_t (1)                   read by the Python host when a model is built: SwiGLU fc1 image in the 16-channel block
  *                                     layout (anyloc_vit_block_h2.fc1_layout = 1: epilogue straight from transposed accumulators)
  *   h3_fast_silu (1)                  fused SwiGLU epilogue: SiLU on the hardware exp2 / rcp (1 ulp each)

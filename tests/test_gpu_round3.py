@@ -325,6 +325,26 @@ def test_topk_fp16_score_panels_vlad_width():
     _check_topk(d, i, qu, db, 20, "ip", True)
 
 
+def test_topk_fp16_score_panels_on_the_16x16x32_kernel():
+    """>= 2048 queries against a full 8192-row panel of >= 4096 columns: the panel GEMM is gemm_h3m_kernel (256 x 256 tiles,
+    v_mfma_f32_16x16x32_f16), first K chunk plain, second chunk accumulating (here on gemm_h3_kernel: 512 columns), the
+    600-row tail panel on gemm_h3_kernel -- checked like every other panel path, and against the lists gemm_h3_kernel gives."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dim, ndb, nq, k = 8192 + 512, 8192 + 600, 2100, 20
+    db = torch.randn(ndb, dim, generator=g) * (0.05 + torch.rand(ndb, 1, generator=g) * 20.0)
+    qu = torch.randn(nq, dim, generator=g)
+    qu[:64] = db[torch.arange(64) * 131 + 5] + 0.3 * torch.randn(64, dim, generator=g)
+    qu[-64:] = db[torch.arange(64) * 7 + 8200 - 448] + 0.3 * torch.randn(64, dim, generator=g)   # (rows of both panels)
+    qg, dg = torch.nn.functional.normalize(qu).to("cuda"), db.to("cuda")
+    d, i = ops.topk(qg, dg, k, "ip", normalize_db=True)
+    with ops.options(h3_mfma16=0):
+        d0, i0 = ops.topk(qg, dg, k, "ip", normalize_db=True)
+    assert float((i0 != i).float().mean()) < 0.002 and float((d0 - d).abs().max()) <= 3e-6
+    sel = torch.cat([torch.arange(0, 128), torch.arange(nq - 128, nq)])
+    _check_topk(d[sel.to("cuda")], i[sel.to("cuda")], qu[sel], db, k, "ip", True)
+
+
 def test_split_h2_wide_rows():
     """anyloc_split_h2 above 4096 columns (retrieval rows): 22 bits relative to the row maximum, rows of any magnitude,
     a zero row, a ragged last row group."""
@@ -441,3 +461,25 @@ def test_swiglu_transposed_epilogue_agrees_with_the_lds_one():
         assert float((out[1, 1] - out[1, 0]).abs().max()) <= 2e-6 * scale
     finally:
         weights.unregister_state_dict(name)
+
+
+def test_gemm_h3_on_the_16x16x32_mfma():
+    """csrc/gemm_h3m.hip (option h3_mfma16; by default the retrieval panels' kernel): the two-term fp16 GEMM on
+    v_mfma_f32_16x16x32_f16 with 256 x 256 tiles -- same operand images, same three products per k, against float64 at the
+    bar of gemm_h3_kernel; ragged rows / columns, an odd number of 16-k blocks (the last ring stage half empty)."""
+    from anyloc_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, K = 4500, 4200, 1552
+    a = torch.randn(M, K, generator=g, device="cuda") * (0.5 + torch.rand(M, 1, generator=g, device="cuda"))
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.02
+    bias = torch.randn(N, generator=g, device="cuda")
+    a2, w2 = ops.split_h2(a), ops.split_h2(w)
+    with ops.options(h3_mfma16=0):
+        base = ops.gemm_nt_h3(a2, w2, M, N, K, bias)
+    with ops.options(h3_mfma16=1):
+        c = ops.gemm_nt_h3(a2, w2, M, N, K, bias)
+    rows = torch.cat([torch.arange(0, 300, device="cuda"), torch.arange(M - 300, M, device="cuda")])
+    ref = a[rows].double() @ w.double().t() + bias.double()
+    mag = a[rows].double().abs() @ w.double().abs().t() + bias.double().abs()
+    assert float(((c[rows].double() - ref).abs() / mag).max()) <= 6e-7
+    assert float(((base[rows].double() - ref).abs() / mag).max()) <= 6e-7

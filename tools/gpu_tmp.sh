@@ -1,7 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out
-mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_round3.py -m gpu -q -k "swiglu or scheduling" < /dev/null > $O/g_pytest.log 2>&1; echo "exit: $?" >> $O/g_pytest.log; tail -8 $O/g_pytest.log | cut -c1-240
-ANYLOC_OPTIONS=h3_swiglu_t=1 timeout 900 python -m pytest tests/test_gpu_fullsize_parity.py tests/test_gpu_vit.py tests/test_gpu_x6.py -m gpu -q < /dev/null > $O/g_pytest_t.log 2>&1; echo "exit: $?" >> $O/g_pytest_t.log; tail -6 $O/g_pytest_t.log | cut -c1-240
-REPS=2 bash tools/gpu_ab.sh "h3_swiglu_t=0" "h3_swiglu_t=1"
+for opt in "h3_mfma16=0" "h3_mfma16=1" "h3_mfma16=0" "h3_mfma16=1"; do
+  ANYLOC_OPTIONS=$opt timeout 300 python tools/run_stage.py config3_shard --check 2>&1 | grep -E "config3|rror" | cut -c1-400
+done | tee gpurun_out/h3m_config3.log
