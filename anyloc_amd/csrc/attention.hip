@@ -13,6 +13,8 @@
 // the probabilities are already in B-operand layout for O^T += V^T * P^T.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "tile_order.hpp"
 
@@ -468,18 +470,21 @@ template <int QG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
                                                                   const float* __restrict__ inv, int T, int heads, int64_t G,
                                                                   unsigned char* __restrict__ out2, float* __restrict__ out_inv,
-                                                                  int64_t R) {
+                                                                  int64_t R, int QB) {
   static_assert(QG * NW == 4 && (QG == 1 || QG == 2), "a workgroup covers four 32-query groups");
   constexpr int NT = 64 * NW;
   constexpr int PIECES = 16 / NW;       // 1-KiB DMA pieces per wave and key tile
   extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];   // 2 stages + 16 bytes for the block reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y;
-  const int64_t b = blockIdx.z;
+  // 1-D grid, XCD-aware: the QB workgroups of one (image, head) -- which stream the same K / V tiles, 271 KB at T = 530 -- get
+  // consecutive ids on ONE XCD, so the tiles come from HBM / the fabric into that XCD's L2 once instead of once per XCD
+  const int logical = xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x);
+  const int qb = logical % QB, h = (logical / QB) % heads;
+  const int64_t b = logical / (QB * heads);
   const int64_t r0 = b * T, r1 = r0 + T;
   const int64_t g_first = r0 >> 5, g_last = (r1 - 1) >> 5;
   const int ng = (int)(g_last - g_first + 1);
-  const int64_t gq0 = g_first + blockIdx.x * 4 + wave * QG;
+  const int64_t gq0 = g_first + qb * 4 + wave * QG;
   const bool wave_active = gq0 <= g_last;
   const int ql = lane & 31, h2 = lane >> 5;
   const int64_t tile_bytes = 8192;
@@ -553,8 +558,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   issue(0, 0);
   __syncthreads();                      // drains the DMA counter (fence) and publishes stage 0
 
-  for (int t = 0; t < ng; ++t) {
-    const int stage = t & 1;
+  // fragment addresses: lane-dependent part once (the swizzled 16-byte slot of each k-step), the stage / plane / d-block part
+  // as the ds_read's immediate offset -- the tile body is instantiated per stage so that the stage is a compile-time constant
+  unsigned k_lane[4], v_lane[2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) k_lane[s] = (unsigned)(ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) v_lane[s2] = (unsigned)(ql * 64 + (((h2 * 2 + s2) ^ ((ql >> 2) & 3)) << 4));
+
+  auto tile = [&](const int t, auto stagec) {
+    constexpr int stage = decltype(stagec)::value;
     if (t + 1 < ng) issue(t + 1, stage ^ 1);
     if (wave_active) {
       const int64_t gk = g_first + t;
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
         attn_u32x4 kf[2];
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
-          kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
+          kf[pl] = *reinterpret_cast<const attn_u32x4*>(Ks + pl * 4096 + k_lane[s]);
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
           sacc[qg] = ANYLOC_MFMA_F16(kf[1], qf[qg][0][s], sacc[qg]);
@@ -593,10 +606,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const int d = db * 32 + ql;
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-            vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + d * 64 + (((h2 * 2 + s2) ^ ((d >> 2) & 3)) << 4));
+          for (int s2 = 0; s2 < 2; ++s2)                    // d = 32 db + ql: (d >> 2) & 3 does not depend on db
+            vf[pl][db][s2] = *reinterpret_cast<const attn_u32x4*>(Vs + pl * 4096 + db * 2048 + v_lane[s2]);
         }
       const bool edge = gk == g_first || gk == g_last;      // wave-uniform: only the image's first / last key group
       // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
@@ -623,6 +635,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
         const float m_new = fmaxf(m_run[qg], mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
         const float moff = 14.0f - m_new;                  // P * 2^14: hi + lo in fp16, the factor cancels against l
+        // (measured and dropped, profiles/r03_attn_experiments.log: the same arithmetic on v_pk_fma_f32 / v_pk_add_f32 and the
+        // hi / lo split on v_fma_mixlo_f16 / v_fma_mixhi_f16 -- 97 instead of 130 vector instructions per tile, same bits for
+        // P -- ran 3 % SLOWER: this loop is not short of vector issue slots)
         float lsum = 0.f;
         attn_u32x4 pf[2][2];
 #pragma unroll
@@ -656,6 +671,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
       }
     }
     __syncthreads();                    // everyone is done with this stage; the next tile's DMA has landed
+  };
+  for (int t = 0; t < ng; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ng) tile(t + 1, std::integral_constant<int, 1>{});
   }
 
   // oacc[db][r] = O[q][db*32 + (r&3) + 8*(r>>2) + 4*h2] * l_run / fv_run (in P * 2^14 units, which cancel against l_run)
@@ -756,8 +775,10 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   // the twelve score MFMAs issued back to back (13.2 vs 13.2 ms) and the V fragments read per 32-column half (126 instead of
   // 152 VGPRs: four waves per SIMD; 13.4 vs 13.5 ms): neither the dependent-chain gaps nor the occupancy is what holds this
   // kernel at 40 % matrix-core utilisation -- DESIGN.md 4.2b
-  const dim3 grid((qgroups + 3) / 4, heads, (unsigned)batch);
-  hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R);
+  const int QB = (qgroups + 3) / 4;                         // workgroups (of four 32-query groups) per image and head
+  ANYLOC_CHECK_ARG((int64_t)QB * heads * batch < (1ll << 31), "attention_h3: grid too large");
+  const dim3 grid((unsigned)((int64_t)QB * heads * batch));
+  hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R, QB);
   return launch_status("attention_h3_kernel");
 }
 

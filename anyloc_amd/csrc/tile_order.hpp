@@ -22,6 +22,13 @@ __device__ __forceinline__ void xcd_grouped_tile(int bid, int tiles_m, int tiles
   tn = within / gm;
 }
 
+// The first step alone: ids of one XCD made contiguous -- consecutive logical ids run on the SAME XCD at about the same time
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 // 16 bytes per lane straight from global memory into LDS (wave-uniform LDS base + lane * 16); out-of-range lanes of the
 // buffer descriptor write zeros
 __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, unsigned voff, unsigned soff) {
