@@ -560,7 +560,7 @@ PEAK_HBM_TBPS = 8.0                # MI355X_MICROARCH.md: HBM3E spec peak (6.3 T
 
 def _timed(fn, iters, warm=1):
     """Wall time per call of ``fn`` (device drained on both sides, per-kernel profiler OFF: its event pairs cost
-    launch-bound calls real time) and, from one more profiled call, the per-kernel HIP-event durations."""
+    launch-bound calls real time) and, from two more profiled calls, the per-kernel HIP-event durations."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -569,13 +569,16 @@ def _timed(fn, iters, warm=1):
         r = fn()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / iters
-    ops.profile_enable(True)
-    ops.profile_reset()
-    fn()
-    torch.cuda.synchronize()
-    ops.profile_enable(False)
-    prof = ops.profile_dump()
-    return el, r, {k: round(v["ms"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    best = {}
+    for _ in range(2):                      # two profiled calls, per kernel the shorter one (a single call now and then catches a hiccup)
+        ops.profile_enable(True)
+        ops.profile_reset()
+        fn()
+        torch.cuda.synchronize()
+        ops.profile_enable(False)
+        for k, v in ops.profile_dump().items():
+            best[k] = min(best.get(k, float("inf")), v["ms"])
+    return el, r, {k: round(v, 4) for k, v in sorted(best.items(), key=lambda kv: -kv[1])}
 
 
 def stage_b1(ext, qu_img):
