@@ -20,7 +20,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 128 matrix-pipe cycles per call: 4 MFMAs of 32 x 32 x 16 (8 passes each) or 8 of 16 x 16 x 32 (4 passes each)
 template <int SHAPE>
 __device__ __forceinline__ void mfma_body(f32x16 (&acc)[4], const f16x8& a, const f16x8& b) {
-  if constexpr (SHAPE == 32) {
+  if constexpr (SHAPE == 1) {           // ONE dependent chain: every MFMA accumulates into the result of the one before
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b));
+  } else if constexpr (SHAPE == 32) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   } else {
@@ -110,16 +113,19 @@ int main() {
   const char* what[6] = {"all waves MFMA", "all waves v_fma", "4 waves MFMA + 4 waves v_fma (2 per SIMD, one each)",
                          "all waves MFMA and v_fma interleaved", "all waves v_exp", "4 waves MFMA + 4 waves v_exp"};
   for (int rep = 0; rep < 2; ++rep) {
-    for (int shape = 32; shape >= 16; shape -= 16) {
+    for (int shape = 32; shape >= 0; shape -= 16) {
       float t[6];
-      if (shape == 32) {
+      if (shape == 0) {
+        const float u[6] = {run<0, 1>(out, iters), run<1, 1>(out, iters), run<2, 1>(out, iters), run<3, 1>(out, iters), run<4, 1>(out, iters), run<5, 1>(out, iters)};
+        for (int m = 0; m < 6; ++m) t[m] = u[m];
+      } else if (shape == 32) {
         const float u[6] = {run<0, 32>(out, iters), run<1, 32>(out, iters), run<2, 32>(out, iters), run<3, 32>(out, iters), run<4, 32>(out, iters), run<5, 32>(out, iters)};
         for (int m = 0; m < 6; ++m) t[m] = u[m];
       } else {
         const float u[6] = {run<0, 16>(out, iters), run<1, 16>(out, iters), run<2, 16>(out, iters), run<3, 16>(out, iters), run<4, 16>(out, iters), run<5, 16>(out, iters)};
         for (int m = 0; m < 6; ++m) t[m] = u[m];
       }
-      printf("---- MFMA shape %s (mode 3 always interleaves the 32 x 32 x 16 one)\n", shape == 32 ? "32 x 32 x 16, 8 passes" : "16 x 16 x 32, 4 passes");
+      printf("---- MFMA shape %s (mode 3 always interleaves the 32 x 32 x 16 one)\n", shape == 32 ? "32 x 32 x 16, 8 passes, 4 independent accumulators" : shape == 16 ? "16 x 16 x 32, 4 passes, 8 independent accumulators" : "32 x 32 x 16, ONE dependent chain");
       for (int m = 0; m < 6; ++m)
         printf("mode %d  %-52s %8.3f ms  %7.1f cycles per iteration (2.4 GHz)\n", m, what[m], t[m], t[m] * 1e-3 * 2.4e9 / iters);
       printf("  MFMA + v_fma on one SIMD from two waves: perfect overlap %.3f, no overlap %.3f, measured %.3f ms\n",
