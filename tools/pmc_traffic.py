@@ -50,7 +50,7 @@ def main():
         tags = None
         if epi in (0, 5):
             tags = ["vit_qkv_gemm"] if int(grid) > 1_000_000 else None
-        elif epi in (3, 7):
+        elif epi in (3, 7, 8, 9):                   # SwiGLU epilogues (8 / 9: from transposed accumulators)
             tags = ["vit_w12_gemm"]
         elif epi == 2:          # proj and fc2 share template and grid: the shorter launches are proj (K = 1536 vs 4096)
             cut = sorted(v[1] for v in vals)[len(vals) // 2 - 1] * 1.4
