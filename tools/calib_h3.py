@@ -18,8 +18,8 @@ g.manual_seed(0)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 61 * 530
 
 
-def timed(fn, n=10):
-    for _ in range(3):
+def timed(fn, n=20):
+    for _ in range(10):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,6 +31,10 @@ def timed(fn, n=10):
     return s.elapsed_time(e) / n
 
 
+_wa = torch.randn(8192, 4096, device=dev).half()
+for _ in range(60):                          # ~100 ms of load: the clocks settle before the first measurement (the first
+    torch.matmul(_wa, _wa.t())               # shape of a cold run measures 15 % low, profiles/r03_h3_n_sweep.log)
+torch.cuda.synchronize()
 for (N, K) in ((8192, 1536), (4608, 1536), (1536, 4096), (1536, 1536)):
     a = torch.randn(M, K, generator=g, device=dev) * (0.5 + torch.rand(M, 1, generator=g, device=dev))
     w = torch.randn(N, K, generator=g, device=dev) * 0.02
