@@ -164,3 +164,32 @@ def test_gemm_h3_random_shapes(seed, heavy):
     # (rows with outlier channels: 22 bits relative to the row MAXIMUM -- the exact-fp32 kernel measures 8-9e-7 on such rows,
     # DESIGN 4.1b)
     assert float(((c.double() - ref).abs() / mag).max()) <= (1e-6 if heavy else 6e-7), (seed, m, n, K, heavy)
+
+
+@settings(max_examples=24, **SETTINGS)
+@given(seed=st.integers(0, 2 ** 20), facet=st.sampled_from(["value", "key", "query", "token"]), use_cls=st.booleans())
+def test_extractor_random_image_sizes(seed, facet, use_cls):
+    """DinoV2ExtractFeatures on random batch sizes and image sizes (multiples of 14, non-square, down to 2 x 2 patches): the
+    position-embedding interpolation, token counts that are not multiples of the kernels' 32-row groups (so image
+    boundaries fall inside the attention tiles and the GEMM row tiles), every facet -- against the CPU restatement of the
+    hub model (ViT-S/14 geometry, 4 blocks of synthetic weights) at the token bar of the fixed-shape tests."""
+    import utilities
+    from anyloc_amd import synth, weights
+    from oracle import dinov2_ref
+    g = torch.Generator().manual_seed(seed)
+    name, depth = "dinov2_vits14", 4
+    sd = synth.synthetic_state_dict(name, 7, depth=depth)
+    weights.register_state_dict(name, sd)
+    try:
+        b, gh, gw, layer = _int(g, 1, 6), _int(g, 2, 18), _int(g, 2, 18), _int(g, 0, depth - 1)
+        img = torch.randn(b, 3, 14 * gh, 14 * gw, generator=g)
+        ext = utilities.DinoV2ExtractFeatures(name, layer, facet, use_cls=use_cls, norm_descs=True, device=DEV)
+        out = ext(img.to(DEV)).cpu()
+        model = dinov2_ref.DinoVisionTransformer(name)
+        model.blocks = model.blocks[:depth]
+        model.load_state_dict(sd, strict=True)
+        ref = dinov2_ref.extract_facet(model.eval(), img, layer, facet, use_cls=use_cls, norm_descs=True)
+        assert out.shape == ref.shape == (b, gh * gw + (1 if use_cls else 0), 384)
+        assert float((out - ref).abs().max()) < 2e-5, (seed, b, gh, gw, layer, facet, use_cls)
+    finally:
+        weights.unregister_state_dict(name)
