@@ -78,6 +78,13 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
                        "(profiles/r02_calib_h3_hipblaslt_zero_data.log): the same h3 kernel runs 39 % faster on all-zero operands, "
                        "and hipBLASLt's fp16 GEMM sustains 1.04-1.43 PFLOP/s on these shapes on random data (this kernel: 1.15-1.24 "
                        "PFLOP/s of fp16 MFMA work = 3 x achieved)") if split else None,
+        # what the matrix cores SUSTAIN inside the chip's power limit on random operands, from registers, with no LDS or HBM
+        # traffic at all (tools/micro/mfma_power.hip, profiles/r03_mfma_shape_power.log: 1 700-1 718 TFLOP/s for the 32x32x16
+        # fp16 instruction this kernel uses; 2 424 on all-zero operands) -- `peak` above stays the guide's nominal figure
+        "power_limited": ({"sustained_mfma_tflops": 1700.0, "peak": round(1700.0 / products, 1),
+                           "frac": round(achieved / (1700.0 / products), 4),
+                           "note": "register-resident fp16 MFMA loop on random operands, one MI355X; this kernel adds LDS, L2 and "
+                                   "HBM traffic inside the same power budget"} if split and products == 3 else None),
         "avg_launch_ms": round(avg_ms, 4), "launches": dom["calls"],
         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
         "all_gemms": {"achieved": round(all_gemm, 2), "frac": round(all_gemm / peak, 4),
