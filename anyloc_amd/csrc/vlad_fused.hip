@@ -635,7 +635,9 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       const unsigned long long cm = __ballot(kin && (wild || s >= best - tau));
       const unsigned mask = (unsigned)(cm >> sh);
       const bool live = row < valid;
-      const bool close = live && __builtin_popcount(mask) > 1;
+      // (an all-zero row has EXACT screening scores -- its matrix-core part is 0, the bias is fp32 -- so its 32-way tie needs
+      // no resolution: first index, as the exact kernels give; without this rule zero rows cost 13x a normal row)
+      const bool close = live && !(xn == 0.f) && __builtin_popcount(mask) > 1;
       if (close && ((mask >> k) & 1u)) pairs[atomicAdd(npairs, 1)] = (row << 5) | k;   // LDS atomic; order is irrelevant
       if (k == 0) {
         if (bi == 0x7fffffff) bi = 0;
