@@ -107,6 +107,8 @@ SIGNATURES = {
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),
 }
 
+ABI_VERSION = 5          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
+
 _lib = None
 
 
@@ -124,6 +126,12 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
         fn.restype = res
         fn.argtypes = args
+    have = lib.anyloc_version()
+    if have != ABI_VERSION:
+        # the .so is git-ignored and built separately: a stale one still exports every symbol but lays the structs out
+        # differently (anyloc_vit_block_h2 grew in ABI 4) -- refuse it instead of handing the GPU garbage pointers
+        raise AnylocHipError(f"{LIB_PATH} has ABI version {have}, this package expects {ABI_VERSION}: "
+                             "rebuild it (`python -m anyloc_amd.build --force`)")
     _lib = lib
     return lib
 

@@ -79,6 +79,12 @@ enum Option {
   OPT_H3_FAST_SILU,      // fused SwiGLU epilogue of the h3 w12 GEMM: SiLU on v_exp_f32 + v_rcp_f32 instead of expf + IEEE division
   OPT_TOPK_FEWQ_X6,      // few-query retrieval scores: 1 = database split on the fly into bf16 planes (scores_x6.hip), 0 = fp32 MFMA
   OPT_TOPK_H3,           // retrieval score panels on the two-term fp16 GEMM: -1 = where it pays, 0 = never, 1 = wherever possible
+  // small-M plans of the two-term fp16 GEMM (gemm_h3s.hip): overrides of the built-in plan table for sweeps / A-B runs
+  OPT_H3S_CFG,           // tile configuration id (-1 = the plan table)
+  OPT_H3S_KSPLIT,        // split-K factor (0 = the plan table)
+  OPT_H3S_KB,            // k-blocks per ring stage: 1, 2 or 4 (0 = the plan table)
+  OPT_H3S_MASK,          // which GEMMs the three overrides apply to: bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 others
+  OPT_H3S_ENABLE,        // 1 = small-M plans (default), 0 = the round-3 small-batch kernels (64x64 two-wave tiles, no split-K)
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -171,7 +177,7 @@ int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream);
 // the same pass with both operands split on the fly into three bf16 planes (six bf16 MFMA products, fp32 accumulate):
 // part[s][row][0..63] and rsq_part[s][row] for K slices s < ksplit of length kslice (scores_x6.hip)
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, float* part, float* rsq_part, hipStream_t stream, int ablation = 0 /* timing-only, see scores_x6.hip */);
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {
@@ -208,6 +214,12 @@ struct H3Problem {
   int fast_silu;                            // EPI_SWIGLU_H2: SiLU on v_exp_f32 / v_rcp_f32 (set by gemm_h3 from option h3_fast_silu)
   int epi_lds;                              // EPI_LS_RESID: transposed 16-byte epilogue through LDS (set by gemm_h3)
   int group_m;                              // tile-rows per XCD scheduling group (set by gemm_h3)
+  // split-K (small-M plans, gemm_h3s.hip): ksplit > 1 cuts the contraction into ksplit ranges of kper k-blocks, one
+  // workgroup each; partial accumulators meet in sk_part, the last arrival of a tile (sk_tickets, zero between launches)
+  // sums them in split order and runs the epilogue.  Both buffers: h3_split_workspace().
+  int ksplit, kper;
+  float* sk_part; unsigned* sk_tickets;
+  int kind;                                 // which block GEMM this is (H3_KIND_*: plan table / option h3s_mask); 0 = other
   // EPI_QKV_PLANES: N = 3 * heads * 64; see QkvPlanes below
   unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
   // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])
@@ -242,6 +254,13 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
 int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsigned char* planes, float* inv,
                         hipStream_t stream);
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
+// small-M plans (gemm_h3s.hip): GEMMs of fewer than ~2 workgroups of 128 x 256 per CU -- one or a few images per call
+enum { H3_KIND_OTHER = 0, H3_KIND_QKV = 1, H3_KIND_PROJ = 2, H3_KIND_FC1 = 3, H3_KIND_FC2 = 4 };
+constexpr size_t H3_SPLIT_PART_BYTES = 48u << 20;      // partial accumulators of one split-K launch (<= 1024 workgroups x 32 KiB + slack)
+constexpr size_t H3_SPLIT_TICKETS = 4096;               // tiles of one split-K launch
+inline size_t h3_split_workspace_bytes() { return H3_SPLIT_PART_BYTES + H3_SPLIT_TICKETS * sizeof(unsigned) + 512; }
+bool h3_small_supported(int epilogue);
+int gemm_h3_small(const H3Problem& p, int epilogue, hipStream_t stream);
 // the same GEMM on v_mfma_f32_16x16x32_f16 (gemm_h3m.hip); ANYLOC_ERR_UNSUPPORTED for epilogues it does not have
 int gemm_h3m(const H3Problem& p, int epilogue, hipStream_t stream);
 

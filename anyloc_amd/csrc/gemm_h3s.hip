@@ -1,0 +1,147 @@
+// Small-M plans of the row-scaled two-term fp16 GEMM (kernel: gemm_h3_kernel.hpp; arithmetic: gemm_h3.hip).
+//
+// The reference's scripts call the extractor with ONE image (scripts/dino_v2_vlad.py:164-188, demo/anyloc_vlad_generate.py
+// :163-186): 530 token rows at 322 x 322.  A block GEMM then has a handful of row tiles and the 128 x 256 tiling of the
+// batched forward leaves most of the 256 CUs idle.  What bounds such a GEMM is not the matrix cores but (i) how many
+// waves exist at all -- proj / fc2 of ViT-g on 64 x 64 tiles are 216 two-wave workgroups = 432 waves for 1024 SIMDs --
+// and (ii) the dependent chain of a lone wave per SIMD: counted wait -> barrier -> fragment reads -> 6 MFMAs per k-block.
+// A plan = (tile shape, k-blocks per ring stage, split-K factor) picked per GEMM from its shape:
+//   * split-K: the contraction is cut into `ksplit` ranges, one workgroup each, so a K = 4096 GEMM of 216 tiles becomes 864
+//     workgroups of 64 k-blocks; partial accumulators meet in a workspace and the LAST arrival of a tile (ticket) sums them
+//     in split order -- deterministic -- and runs the fused epilogue (LayerScale-residual, q|k|v planes, SwiGLU + quantise);
+//   * wider tiles (64 x 128, 64 x 256) where N is large (qkv, w12): twice the flops per staged byte of a 64 x 64 tile.
+// A one-image forward is therefore no longer bitwise the same image inside a batch (other summation order over k); both
+// meet the oracle bar, and they agree to ~1e-7 (tests/test_gpu_vit.py).
+#include "gemm_h3_kernel.hpp"
+
+namespace anyloc {
+
+namespace {
+
+struct Plan {
+  int cfg, kb, ksplit;
+};
+
+// tile configurations: id -> (MI, NI, WM, WN); BM = 32 MI WM, BN = 32 NI WN
+constexpr int NCFG = 7;
+const int kCfgBM[NCFG] = {64, 64, 64, 64, 128, 64, 64};
+const int kCfgBN[NCFG] = {64, 128, 128, 128, 128, 256, 256};
+
+template <int EPI, int MI, int NI, int WM, int WN, int KB>
+int launch_small(const H3Problem& p, hipStream_t stream) {
+  using Cfg = H3Cfg<MI, NI, WM, WN, 3, KB>;
+  const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, 3, 2, EPI, KB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, 3, 2, EPI, KB>), dim3((unsigned)(tiles_m * tiles_n * std::max(1, p.ksplit))),
+                     dim3(64 * WM * WN), Cfg::LDS, stream, p, tiles_m, tiles_n);
+  return launch_status("gemm_h3_kernel (small-M plan)");
+}
+
+template <int EPI, int MI, int NI, int WM, int WN>
+int launch_kb(const H3Problem& p, int kb, hipStream_t stream) {
+  if (kb >= 4) {
+    if constexpr (H3Cfg<MI, NI, WM, WN, 3, 4>::LDS <= 160 * 1024) return launch_small<EPI, MI, NI, WM, WN, 4>(p, stream);
+    kb = 2;
+  }
+  if (kb == 2) return launch_small<EPI, MI, NI, WM, WN, 2>(p, stream);
+  return launch_small<EPI, MI, NI, WM, WN, 1>(p, stream);
+}
+
+template <int EPI>
+int launch_cfg(const H3Problem& p, const Plan& pl, hipStream_t stream) {
+  switch (pl.cfg) {
+    case 0: return launch_kb<EPI, 1, 2, 2, 1>(p, pl.kb, stream);    // 64 x 64, two waves of 32 x 64
+    case 1: return launch_kb<EPI, 2, 2, 1, 2>(p, pl.kb, stream);    // 64 x 128, two waves of 64 x 64
+    case 2: return launch_kb<EPI, 1, 2, 2, 2>(p, pl.kb, stream);    // 64 x 128, four waves of 32 x 64
+    case 3: return launch_kb<EPI, 1, 4, 2, 1>(p, pl.kb, stream);    // 64 x 128, two waves of 32 x 128
+    case 4: return launch_kb<EPI, 2, 2, 2, 2>(p, pl.kb, stream);    // 128 x 128, four waves of 64 x 64
+    case 5: return launch_kb<EPI, 2, 2, 1, 4>(p, pl.kb, stream);    // 64 x 256, four waves of 64 x 64
+    default: return launch_kb<EPI, 1, 4, 2, 2>(p, pl.kb, stream);   // 64 x 256, four waves of 32 x 128
+  }
+}
+
+int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// the plan table (measured on one MI355X: profiles/r04_b1_plan_sweep.log) + the option overrides
+Plan choose(const H3Problem& p, int epilogue) {
+  Plan pl{0, 1, 1};
+  const int64_t t64 = cdiv(p.M, 64) * cdiv(p.N, 64);
+  if (option(OPT_H3S_ENABLE) == 0) {
+    // the round-3 small-batch kernels: 64 x 64 two-wave tiles (four / two k-blocks per ring stage when a workgroup is alone
+    // on its CU), 128 x 128 from 256 such tiles up; no split-K
+    if (cdiv(p.M, 128) * cdiv(p.N, 128) >= option(OPT_H3_TINY_MAX)) return Plan{4, 1, 1};
+    return Plan{0, t64 < option(OPT_H3_DEEP_MAX) ? 4 : t64 < option(OPT_H3_DEEP2_MAX) ? 2 : 1, 1};
+  }
+  // default plans: aim at >= ~3 waves per SIMD in total, >= 16 k-blocks per split
+  const int64_t t128 = cdiv(p.M, 64) * cdiv(p.N, 128);
+  if (p.N >= 4096 && t128 >= 256) {
+    pl.cfg = 1;                                            // wide outputs (qkv, w12): 64 x 128 tiles
+    pl.ksplit = t128 < 512 && p.K16 >= 64 ? 2 : 1;
+    pl.kb = 1;
+  } else if (cdiv(p.M, 128) * cdiv(p.N, 128) >= 256) {
+    pl = Plan{4, 1, 1};
+  } else {
+    pl.cfg = 0;
+    int ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, 1024 / std::max<int64_t>(1, t64)));
+    while (ks > 1 && p.K16 / ks < 16) --ks;
+    pl.ksplit = ks;
+    pl.kb = 2;
+  }
+  const int64_t mask = option(OPT_H3S_MASK);
+  const int bit = p.kind == H3_KIND_QKV ? 1 : p.kind == H3_KIND_PROJ ? 2 : p.kind == H3_KIND_FC1 ? 4 : p.kind == H3_KIND_FC2 ? 8 : 16;
+  if (mask & bit) {
+    const int64_t c = option(OPT_H3S_CFG), s = option(OPT_H3S_KSPLIT), k = option(OPT_H3S_KB);
+    if (c >= 0 && c < NCFG) pl.cfg = (int)c;
+    if (s > 0) pl.ksplit = (int)s;
+    if (k == 1 || k == 2 || k == 4) pl.kb = (int)k;
+  }
+  return pl;
+}
+
+}  // namespace
+
+bool h3_small_supported(int epilogue) {
+  switch (epilogue) {
+    case EPI_STORE: case EPI_LS_RESID: case EPI_QKV_PLANES: case EPI_GELU_H2: case EPI_SWIGLU_H2: case EPI_SWIGLU_T_H2: return true;
+    default: return false;
+  }
+}
+
+int gemm_h3_small(const H3Problem& p_in, int epilogue, hipStream_t stream) {
+  H3Problem p = p_in;
+  Plan pl = choose(p, epilogue);
+  // the epilogues that write q|k|v tiles need whole heads per wave column block: NI even (all configurations have it)
+  // split-K needs the workspace, a plain (non-accumulating) epilogue input and enough k-blocks
+  const int64_t tiles = cdiv(p.M, kCfgBM[pl.cfg]) * cdiv(p.N, kCfgBN[pl.cfg]);
+  if (!p.sk_part || !p.sk_tickets || p.accumulate) pl.ksplit = 1;
+  pl.ksplit = (int)std::min<int64_t>(pl.ksplit, p.K16);
+  while (pl.ksplit > 1 && ((size_t)pl.ksplit * tiles * kCfgBM[pl.cfg] * kCfgBN[pl.cfg] * sizeof(float) > H3_SPLIT_PART_BYTES ||
+                           tiles > (int64_t)H3_SPLIT_TICKETS))
+    --pl.ksplit;
+  p.ksplit = pl.ksplit;
+  // k-blocks per split: a multiple of the ring stage's k-blocks, so that only the LAST split can end inside a stage
+  // (its missing k-blocks lie beyond the buffer descriptors and read as zeros)
+  if (pl.ksplit > 1) {
+    p.kper = (int)(cdiv(cdiv(p.K16, pl.ksplit), pl.kb) * pl.kb);
+    p.ksplit = (int)cdiv(p.K16, p.kper);                   // no empty split
+    if (p.ksplit <= 1) { p.ksplit = 1; p.kper = p.K16; }
+  } else {
+    p.kper = p.K16;
+  }
+  switch (epilogue) {
+    case EPI_STORE: return launch_cfg<EPI_STORE>(p, pl, stream);
+    case EPI_LS_RESID: return launch_cfg<EPI_LS_RESID>(p, pl, stream);
+    case EPI_QKV_PLANES: return launch_cfg<EPI_QKV_PLANES>(p, pl, stream);
+    case EPI_GELU_H2: return launch_cfg<EPI_GELU_H2>(p, pl, stream);
+    case EPI_SWIGLU_H2: return launch_cfg<EPI_SWIGLU_H2>(p, pl, stream);
+    case EPI_SWIGLU_T_H2: return launch_cfg<EPI_SWIGLU_T_H2>(p, pl, stream);
+    default: set_error("gemm_h3_small: epilogue %d has no small-M plan", epilogue); return ANYLOC_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace anyloc

@@ -54,9 +54,7 @@ __device__ __forceinline__ f32x4 sx_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
-// ABL (timing-only ablations for tools/time_topk.py, results are WRONG when != 0): 1 = no contraction (loads, LDS staging and
-// barriers only), 2 = loads only (their values folded into the row sums of squares so that they are not dead)
-template <int BK, int ABL = 0>
+template <int BK>
 __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(const float* __restrict__ db, int64_t ldd, int64_t rows,
                                                                 const float* __restrict__ qu, int64_t ldq, int nq,
                                                                 int64_t kslice, float* __restrict__ part,
@@ -113,13 +111,6 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
   // end (its squares must not be counted a second time; the LDS image it leaves is never contracted)
   auto stash = [&](auto setc, int stage, float real) {   // register set S -> LDS stage
     constexpr int S = decltype(setc)::value;
-    if constexpr (ABL == 2) {
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) rsq[i] += ra[S][i][0] + ra[S][i][3];
-#pragma unroll
-      for (int i = 0; i < B_LD; ++i) rsq[0] += rb[S][i][1];
-      return;
-    }
     unsigned char* st = sx_smem + stage * SX_STAGE;
     float* ad = reinterpret_cast<float*>(st) + r0 * SX_ALD + 4 * kq;
 #pragma unroll
@@ -157,7 +148,6 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
 
   const int fr = lane & 31, fh = lane >> 5;
   auto contract = [&](int stage) {                       // the 32-k slab sitting in LDS stage `stage`
-    if constexpr (ABL != 0) return;
     const unsigned char* st = sx_smem + stage * SX_STAGE;
     const float* ap = reinterpret_cast<const float*>(st) + (wave * 32 + fr) * SX_ALD + 8 * fh;
     const unsigned char* bp = st + SX_A_BYTES + fr * SX_BROW + fh * 16;
@@ -208,14 +198,14 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
     contract(0);
     __builtin_amdgcn_sched_barrier(0);
     stash(S1{}, 1, kt + 1 < nk ? 1.0f : 0.0f);           // (kt + 1 == nk: a copy of the last slab nobody contracts)
-    if constexpr (ABL != 2) __syncthreads();
+    __syncthreads();
     if (kt + 1 < nk) {
       fetch(min(kt + 3, last), S1{});
       __builtin_amdgcn_sched_barrier(0);
       contract(1);
       __builtin_amdgcn_sched_barrier(0);
       stash(S0{}, 0, kt + 2 < nk ? 1.0f : 0.0f);
-      if constexpr (ABL != 2) __syncthreads();
+      __syncthreads();
     }
   }
 
@@ -240,17 +230,17 @@ __global__ __launch_bounds__(256, BK == 32 ? 2 : 1) void scores_fewq_x6_kernel(c
   }
 }
 
-template <int BK, int ABL = 0>
+template <int BK>
 int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice, int ksplit,
                 float* part, float* rsq_part, hipStream_t stream) {
   const int64_t tiles = (rows + SX_BM - 1) / SX_BM;
   static bool attr = false;
   if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK, ABL>),
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SxCfg<BK>::STAGE));
     attr = true;
   }
-  hipLaunchKernelGGL((scores_fewq_x6_kernel<BK, ABL>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SxCfg<BK>::STAGE, stream, db,
+  hipLaunchKernelGGL((scores_fewq_x6_kernel<BK>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SxCfg<BK>::STAGE, stream, db,
                      ldd, rows, queries, ldq, (int)nq, kslice, part, rsq_part);
   return launch_status("scores_fewq_x6_kernel");
 }
@@ -258,7 +248,7 @@ int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries
 }  // namespace
 
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
-                   int ksplit, float* part, float* rsq_part, hipStream_t stream, int ablation) {
+                   int ksplit, float* part, float* rsq_part, hipStream_t stream) {
   ANYLOC_CHECK_ARG(db && queries && part && rsq_part, "scores_fewq_x6: null operand");
   ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % 32 == 0 && ksplit >= 1 && ksplit < 65536,
                    "scores_fewq_x6: needs <= 64 queries, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
@@ -269,8 +259,6 @@ int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* quer
                    "scores_fewq_x6: a tile's rows must stay inside 2 GiB of buffer addressing");
   ANYLOC_CHECK_ARG((rows + SX_BM - 1) / SX_BM < (1ll << 31), "scores_fewq_x6: grid too large");
   ProfScope prof("topk_scores_gemm", stream, 2.0 * rows * 64 * kslice * ksplit, 4.0 * (rows + 64.0) * kslice * ksplit);
-  if (ablation == 1) return launch_fewq<32, 1>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
-  if (ablation == 2) return launch_fewq<32, 2>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
   return launch_fewq<32>(db, ldd, rows, queries, ldq, nq, kslice, ksplit, part, rsq_part, stream);
 }
 

@@ -427,8 +427,7 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
       g.ksplit = S; g.c_split_stride = pc * 64;
       g.rowsq = w.rsq_part;
       if (option(OPT_TOPK_FEWQ_X6) != 0)
-        ANYLOC_TRY(scores_fewq_x6(g.A, g.lda, pc, queries, dim, nq, g.K, S, w.part, w.rsq_part, stream,
-                                  (int)option(OPT_TOPK_FEWQ_X6) - 1 /* 2, 3 = timing-only ablations */));
+        ANYLOC_TRY(scores_fewq_x6(g.A, g.lda, pc, queries, dim, nq, g.K, S, w.part, w.rsq_part, stream));
       else
         ANYLOC_TRY(gemm_nt_splitk(g, stream));
       ProfScope prof("topk_combine", stream, (double)S * pc * 64, 4.0 * ((double)S * pc * 65 + (double)nq * pc));

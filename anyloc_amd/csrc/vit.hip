@@ -42,6 +42,8 @@ struct VitWs {
   unsigned char* h3;        //                  plane image of the FFN hidden activation
   float *ainv, *hinv;       // fp16 mode: 2^-e per row of the images in a3 / h3
   float* qinv;              // fp16 mode, fused attention: 2^-e per (part, head, 32-row group) tile of q | k | v (in qkv)
+  float* sk_part;           // fp16 mode, small-M plans: partial accumulators of a split-K launch (gemm_h3s.hip)
+  unsigned* sk_tickets;     //                           arrival counters per tile, zero between launches
   size_t bytes;
 };
 
@@ -60,6 +62,8 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   w.ainv = a.take<float>(M);
   w.hinv = a.take<float>(M);
   w.qinv = a.take<float>(qkv_inv_count(M, c.heads));
+  w.sk_part = a.take<float>(H3_SPLIT_PART_BYTES / sizeof(float));
+  w.sk_tickets = a.take<unsigned>(H3_SPLIT_TICKETS);
   w.bytes = a.off;
   return w;
 }
@@ -109,9 +113,12 @@ int linear_x6(const float* A, int64_t K, unsigned char* a3, const void* w3, int6
 int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const void* w2, const float* winv, int64_t w_rows,
               int64_t w_row0, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
               const char* tag, hipStream_t stream, unsigned char* c2 = nullptr, const float* c_inv = nullptr,
-              unsigned char* qkv_planes = nullptr, float* qkv_inv = nullptr, int heads = 0) {
+              unsigned char* qkv_planes = nullptr, float* qkv_inv = nullptr, int heads = 0, const VitWs* ws = nullptr,
+              int kind = H3_KIND_OTHER) {
   if (A) ANYLOC_TRY(split_h2(A, K, M, K, a2, ainv, stream));
   H3Problem g{};
+  if (ws) { g.sk_part = ws->sk_part; g.sk_tickets = ws->sk_tickets; }
+  g.kind = kind;
   g.C2 = c2; g.RC = M; g.c_inv = c_inv;
   g.qkv_planes = qkv_planes; g.qkv_inv = qkv_inv; g.heads = heads; g.groups = (M + 31) / 32;
   g.A2 = a2; g.RA = M; g.a_inv = ainv;
@@ -266,6 +273,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   const int64_t ldo = (int64_t)n_taps * D;
   const int norm_taps = (flags & ANYLOC_VIT_NORM_TAPS) ? 1 : 0;
   const int last_layer = tap_layers[n_taps - 1];
+  if (h3m) ANYLOC_HIP(hipMemsetAsync(w.sk_tickets, 0, H3_SPLIT_TICKETS * sizeof(unsigned), stream));   // split-K arrival counters
   // does any tap need the block OUTPUT of the last executed layer?
   bool last_needs_full = false;
   for (int t = 0; t < n_taps; ++t)
@@ -304,7 +312,8 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
         const int f = tap_facets[t];
         if (h3m)
           ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, (int64_t)f * D,
-                               b.qkv_b + (int64_t)f * D, w.qkv, D, M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream));
+                               b.qkv_b + (int64_t)f * D, w.qkv, D, M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream, nullptr,
+                               nullptr, nullptr, nullptr, 0, &w, H3_KIND_PROJ));
         else if (x6)
           ANYLOC_TRY(linear_x6(y_in, D, w.a3, h->x3[l].qkv_w3, 3 * D, (int64_t)f * D, b.qkv_b + (int64_t)f * D, w.qkv, D,
                                M, D, EPI_STORE, nullptr, "vit_facet_gemm", stream));
@@ -325,10 +334,10 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       // the image of the projection GEMM -- q, k, v and the attention output never exist in fp32
       ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, nullptr, 3 * D, M,
                            3 * D, EPI_QKV_PLANES, nullptr, "vit_qkv_gemm", stream, nullptr, nullptr,
-                           reinterpret_cast<unsigned char*>(w.qkv), w.qinv, c.heads));
+                           reinterpret_cast<unsigned char*>(w.qkv), w.qinv, c.heads, &w, H3_KIND_QKV));
       ANYLOC_TRY(attention_h3(reinterpret_cast<const unsigned char*>(w.qkv), w.qinv, batch, T, D, c.heads, w.a3, w.ainv, stream));
       ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
-                           EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
+                           EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_PROJ));
     } else {
       if (h3m)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M,
@@ -362,14 +371,14 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       // the hidden activation is quantised in the epilogue against the row bound LayerNorm 2 left in w.hinv
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, nullptr, Hh, M, Hh,
-                             EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv));
+                             EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1));
       else
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0,
                              h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, nullptr, Hh, M, 2 * Hh,
                              h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
-                             w.hinv));
+                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1));
       ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
-                           EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
+                           EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
     } else if (h3m) {
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, w.h, Hh, M, Hh,

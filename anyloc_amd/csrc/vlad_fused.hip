@@ -592,6 +592,22 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       }
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
+      if (rs == 0.f) {
+        // rare: the token's slice is all zero -- or its squares underflowed (|x| < ~1e-19).  The zero-row rule of the assign
+        // phase (no exact resolution for a row whose norm is 0) must only fire for rows that are bitwise zero, so a slice
+        // with any non-zero bit reports the smallest positive float instead of 0 (absorbed by any normal sum of squares)
+        unsigned ob = 0;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob |= __float_as_uint(x0[e]) | __float_as_uint(x1[e]);
+        }
+        ob |= (unsigned)__shfl_xor((int)ob, 16, 64);
+        ob |= (unsigned)__shfl_xor((int)ob, 32, 64);
+        if (ob & 0x7fffffffu) rs = __uint_as_float(1u);
+      }
       if (fq == 0) rsqp[wave * TT + fr] = rs;
     }
     lds_barrier();
@@ -635,8 +651,9 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       const unsigned long long cm = __ballot(kin && (wild || s >= best - tau));
       const unsigned mask = (unsigned)(cm >> sh);
       const bool live = row < valid;
-      // (an all-zero row has EXACT screening scores -- its matrix-core part is 0, the bias is fp32 -- so its 32-way tie needs
-      // no resolution: first index, as the exact kernels give; without this rule zero rows cost 13x a normal row)
+      // (a row that is BITWISE all zero has EXACT screening scores -- its matrix-core part is 0, the bias is fp32 -- so its
+      // 32-way tie needs no resolution: first index, as the exact kernels give; without this rule zero rows cost 13x a
+      // normal row.  xn == 0 means exactly that: a slice with a non-zero bit contributes at least 2^-149 to q, see above)
       const bool close = live && !(xn == 0.f) && __builtin_popcount(mask) > 1;
       if (close && ((mask >> k) & 1u)) pairs[atomicAdd(npairs, 1)] = (row << 5) | k;   // LDS atomic; order is irrelevant
       if (k == 0) {

@@ -192,9 +192,10 @@ class HipDinoV2:
         if self._final_norm is None or self.depth != self.full_depth:
             raise RuntimeError(f"{self.name}: the model forward needs all {self.full_depth} blocks and the final "
                                f"norm.weight / norm.bias (loaded: {self.depth} blocks)")
-        tok = self.forward_taps(img, [(self.depth - 1, "token")], use_cls=True, norm_taps=False)
-        res = ops.layernorm(tok[:, 0].contiguous(), self._final_norm[0], self._final_norm[1], 1e-6)
-        return res if img.is_cuda else res.to(img.device)
+        with _on_device(self.device):          # every launch of the call on the model's device, whatever the current one is
+            tok = self._forward_taps(img, [(self.depth - 1, "token")], True, False, False)
+            res = ops.layernorm(tok[:, 0].contiguous(), self._final_norm[0], self._final_norm[1], 1e-6)
+        return res if img.is_cuda else ops.to_home(res, img.device)
 
     def pos_table(self, H, W):
         key = (H, W)
@@ -310,7 +311,7 @@ class DinoV2ExtractFeatures:
         """
         res = self.dino_model.forward_taps(img, [(self.layer, self.facet)], use_cls=self.use_cls,
                                            norm_taps=self.norm_descs)
-        return res if img.is_cuda else res.to(img.device)
+        return res if img.is_cuda else ops.to_home(res, img.device)
 
     def extract_multi(self, img: torch.Tensor, layers, facet=None, norm_concat=True) -> torch.Tensor:
         """Additive API (one forward, several taps): per-layer facets, each L2-normalised when
@@ -320,7 +321,7 @@ class DinoV2ExtractFeatures:
         facet = facet or self.facet
         res = self.dino_model.forward_taps(img, [(l, facet) for l in layers], use_cls=self.use_cls,
                                            norm_taps=self.norm_descs, norm_concat=norm_concat)
-        return res if img.is_cuda else res.to(img.device)
+        return res if img.is_cuda else ops.to_home(res, img.device)
 
     def __del__(self):
         fh = getattr(self, "fh_handle", None)

@@ -8,7 +8,7 @@ import json
 
 import torch
 
-from . import _lib
+from . import _lib, staging
 
 VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
@@ -18,11 +18,24 @@ VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1,
 
 
 def _f32c(t, device=None):
+    """-> contiguous fp32 tensor (on ``device`` when given).  CPU sources are staged through pinned buffers with
+    asynchronous copies (staging.py); a dtype conversion happens on the device, after the copy."""
     if device is not None and t.device != device:
-        t = t.to(device, non_blocking=True)
+        t = staging.to_device(t, device)
     if t.dtype != torch.float32:
         t = t.to(torch.float32)
     return t.contiguous()
+
+
+def to_home(t, home):
+    """Result tensor back to where the caller's inputs live: device tensors stay, CPU callers get a CPU tensor through
+    the pinned staging path (complete on return)."""
+    home = torch.device(home)
+    if t.device == home:
+        return t
+    if home.type == "cpu":
+        return staging.to_host(t)
+    return t.to(home)
 
 
 def _need_cuda(*ts):

@@ -65,8 +65,9 @@ def get_top_k_recall(top_k: List[int], db: torch.Tensor, qu: torch.Tensor, gt_po
         raise NotImplementedError(f"Method: {method}")
     home = qu.device
     distances, indices = search(db, qu, max(top_k), method, norm_descs)
-    distances, indices = distances.to(home), indices.to(home)
-    recalls = recalls_from_indices(top_k, indices.cpu().numpy(), gt_pos, use_percentage,
+    distances, indices = ops.to_home(distances, home), ops.to_home(indices, home)
+    idx_host = indices if indices.device.type == "cpu" else ops.to_home(indices, "cpu")
+    recalls = recalls_from_indices(top_k, idx_host.numpy(), gt_pos, use_percentage,
                                    sub_sample_db, sub_sample_qu)
     return distances, indices, recalls
 

@@ -246,6 +246,10 @@ class VLAD:
             torch.save({"format": LAZY_FORMAT, "tokens": xh.cpu(), "num_clusters": self.num_clusters},
                        f"{self.cache_dir}/{cache_id}_t.pt")
 
+    # images per launch when the descriptors arrive as one CPU tensor (scripts/dino_v2_vlad.py:236-260 hands over
+    # [n_img, 529, 1536]: 3.25 MB per image): bounds the device copy to ~6.6 GB while the pinned staging ring streams it
+    HOST_CHUNK_IMGS = 2048
+
     def _generate_batch(self, multi_query):
         """[n_img,N,D] tensor or list of [N_i,D] -> [n_img, K*D] on the inputs' device."""
         first = multi_query[0] if not isinstance(multi_query, torch.Tensor) else multi_query
@@ -253,10 +257,16 @@ class VLAD:
         home = first.device
         if not isinstance(multi_query, torch.Tensor):
             multi_query = [_as_tensor(q) for q in multi_query]
-        out = ops.vlad(multi_query, self._centers_dev(), mode=self.vlad_mode,
-                       norm_descs=self.norm_descs, intra_norm=self.intra_norm,
-                       soft_temp=self.soft_temp, dist_mode=self.mode)
-        return out if home.type == "cuda" else out.to(home)
+        kw = dict(mode=self.vlad_mode, norm_descs=self.norm_descs, intra_norm=self.intra_norm,
+                  soft_temp=self.soft_temp, dist_mode=self.mode)
+        c = self._centers_dev()
+        n = len(multi_query)
+        if home.type == "cpu" and n > self.HOST_CHUNK_IMGS:
+            out = torch.cat([ops.vlad(multi_query[s:s + self.HOST_CHUNK_IMGS], c, **kw)
+                             for s in range(0, n, self.HOST_CHUNK_IMGS)])
+        else:
+            out = ops.vlad(multi_query, c, **kw)
+        return ops.to_home(out, home)
 
     def generate(self, query_descs: Union[np.ndarray, torch.Tensor],
                  cache_id: Union[str, None] = None) -> torch.Tensor:
@@ -312,7 +322,7 @@ class VLAD:
         home = query_descs.device
         x = ops._f32c(query_descs, _lib.require_gpu())
         residuals = ops.vlad_residuals(x, self._centers_dev(), self.norm_descs)
-        residuals = residuals if home.type == "cuda" else residuals.to(home)
+        residuals = ops.to_home(residuals, home)
         if cache_id is not None and self.can_use_cache_vlad():
             cid_dir = f"{self.cache_dir}/" f"{os.path.split(cache_id)[0]}"
             if not os.path.isdir(cid_dir):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 4
+#define ANYLOC_ABI_VERSION 5
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -69,8 +69,13 @@ const char* anyloc_last_error(void);
  *   h3_swiglu_t (1)                   read by the Python host when a model is built: SwiGLU fc1 image in the 16-channel block
  *                                     layout (anyloc_vit_block_h2.fc1_layout = 1: epilogue straight from transposed accumulators)
  *   h3_fast_silu (1)                  fused SwiGLU epilogue: SiLU on the hardware exp2 / rcp (1 ulp each)
- *   topk_fewq_x6 (1)                  anyloc_topk with <= 64 queries: database rows split on the fly into bf16 planes (HBM-bound)
+ *   topk_fewq_x6 (1)                  anyloc_topk with <= 64 queries: database rows split on the fly into bf16 planes (HBM-bound); 0 = fp32 MFMA
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
+ *   h3s_enable (1)                    small-M plans of the two-term fp16 GEMM (csrc/gemm_h3s.hip: tile shape, ring depth and split-K
+ *                                     factor per GEMM shape when a call has one or a few images); 0 = the round-3 small-batch kernels
+ *   h3s_cfg (-1) h3s_ksplit (0) h3s_kb (0) h3s_mask (31)
+ *                                     overrides of that plan table for sweeps: tile configuration id, split-K factor, k-blocks per
+ *                                     ring stage; mask bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 other GEMMs
  * Unknown names are rejected (ANYLOC_ERR_INVALID_ARG).  Not thread-safe against
  * concurrent launches that read the option being changed. */
 int anyloc_set_option(const char* name, int64_t value);

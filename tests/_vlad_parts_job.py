@@ -60,6 +60,7 @@ def kmeans_close_calls():
         x[6] *= 1e-7                                      # below the fp16 range of the screening pass
         x[7] *= 3e4                                       # beyond it
         x[8] = c[3] + 1e-4 * torch.randn(D, generator=g)  # a clear winner
+        x[9] *= 1e-25 / float(x[9].abs().max())           # non-zero, but every square underflows: NOT an all-zero row
         for mode in ("cosine", "euclidean"):
             sums, counts, lab = ops.kmeans_step(x.to(DEV), c.to(DEV), mode, True)
             lab = lab.cpu()
@@ -79,6 +80,8 @@ def kmeans_close_calls():
                 assert not (gap == 0.0 and int(lab[i]) > int(ref[i])), (D, K, mode, i, "tie must go to the lower index")
             assert int(lab[5]) == 0 or mode == "euclidean"
             assert int(lab[8]) == 3
+            if mode == "cosine":                          # the tiny row still orders its (tiny) scores: exact resolution, not the zero-row rule
+                assert int(lab[9]) == int(ref[9]), (D, K, int(lab[9]), int(ref[9]))
             assert len(bad) <= 8, (D, K, mode, len(bad))
             onehot = (lab[None] == torch.arange(K)[:, None]).double()
             assert torch.equal(counts.cpu(), onehot.sum(-1).float())

@@ -33,7 +33,10 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.anyloc_version() == 4      # ANYLOC_ABI_VERSION of include/anyloc_hip.h
+    from anyloc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "anyloc_hip.h")).read()
+    declared = int(re.search(r"#define ANYLOC_ABI_VERSION (\d+)", header).group(1))
+    assert lib.anyloc_version() == declared == _lib.ABI_VERSION     # header, library and binding agree
     assert isinstance(lib.anyloc_last_error(), bytes)
 
 
