@@ -98,6 +98,8 @@ SIGNATURES = {
     "anyloc_vit_destroy": (None, [C.c_void_p]),
     "anyloc_vit_attach_x3": (C.c_int, [C.c_void_p, C.POINTER(VitBlockX3)]),
     "anyloc_vit_attach_h2": (C.c_int, [C.c_void_p, C.POINTER(VitBlockH2)]),
+    "anyloc_vit_set_telemetry": (C.c_int, [C.c_void_p, c_f32p]),
+    "anyloc_vit_block_ffn_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "anyloc_vit_workspace_bytes": (c_sz, [C.c_void_p, c_i64, c_i64, c_i64]),
     "anyloc_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_f32p, C.c_int32,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint, c_f32p,

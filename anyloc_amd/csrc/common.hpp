@@ -253,6 +253,8 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
 // test / fallback producer of the same tiles from an fp32 [rows, 3D] buffer
 int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsigned char* planes, float* inv,
                         hipStream_t stream);
+// telemetry: *out = max(*out, max over rows < M of 2^15 / (largest |hi-plane value| of the row)) for an h2 image of R rows
+int h2_row_looseness(const void* h2, int64_t M, int64_t R, int64_t K, float* out, hipStream_t stream);
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
 // small-M plans (gemm_h3s.hip): GEMMs of fewer than ~2 workgroups of 128 x 256 per CU -- one or a few images per call
 enum { H3_KIND_OTHER = 0, H3_KIND_QKV = 1, H3_KIND_PROJ = 2, H3_KIND_FC1 = 3, H3_KIND_FC2 = 4 };

@@ -308,7 +308,42 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
   h2_store_rows<NV, RPW>(v, scale, tile, dim, row0, rows, out, R);
 }
 
+
+// FFN-bound telemetry (anyloc_vit_set_telemetry): largest scaled magnitude of every row of an h2 image (the leading plane
+// carries it) -> looseness of the bound the row was quantised against, 2^15 / max; the launch's maximum lands in *out.
+// One thread per row, k-blocks walked in order: adjacent rows are adjacent 32-byte pieces, so a wave reads 2-KiB runs.
+__global__ __launch_bounds__(256) void h2_row_looseness_kernel(const unsigned char* __restrict__ img, int64_t M, int64_t R, int K16,
+                                                               float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float amax = 0.f;
+  if (row < M) {
+    const unsigned char* p = img + row * 32;
+    for (int kb = 0; kb < K16; ++kb) {
+      const hu32x4 a = *reinterpret_cast<const hu32x4*>(p + (int64_t)kb * 2 * R * 32);
+      const hu32x4 b = *reinterpret_cast<const hu32x4*>(p + (int64_t)kb * 2 * R * 32 + 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x2 x = __builtin_bit_cast(f16x2, a[j]), y = __builtin_bit_cast(f16x2, b[j]);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf((float)x[0]), fabsf((float)x[1])), fmaxf(fabsf((float)y[0]), fabsf((float)y[1]))));
+      }
+    }
+  }
+  // a row whose leading plane is all zero lies more than 2^39 below its bound (or is exactly zero: then nothing was lost,
+  // but a token row of an FFN activation is never that) -- report it as 2^40
+  float loose = row < M ? (amax > 0.f ? 32768.0f / amax : 1.099511627776e12f) : 0.f;
+  loose = wave_max(loose);
+  if ((threadIdx.x & 63) == 0 && loose > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(loose));   // positive floats order as their bits
+}
+
 }  // namespace
+
+int h2_row_looseness(const void* h2, int64_t M, int64_t R, int64_t K, float* out, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(h2 && out && M > 0 && R >= M && K > 0 && K % 16 == 0, "h2_row_looseness: bad arguments");
+  ProfScope prof("ffn_telemetry", stream, 0.0, 2.0 * M * K);
+  hipLaunchKernelGGL(h2_row_looseness_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<const unsigned char*>(h2), M, R, (int)(K / 16), out);
+  return launch_status("h2_row_looseness_kernel");
+}
 
 size_t h2_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 2 * (size_t)rows * 32; }
 

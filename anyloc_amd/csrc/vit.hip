@@ -31,6 +31,8 @@ struct anyloc_vit {
   std::vector<anyloc_vit_block_weights> blocks;
   std::vector<anyloc_vit_block_x3> x3;      // optional: three-plane bf16 images of the four weight matrices
   std::vector<anyloc_vit_block_h2> h2;      // optional: two-plane fp16 images + row scales of the same matrices
+  std::vector<char> ffn_exact;              // per block: 1 = quantise the FFN activation against the exact row maximum
+  float* ffn_looseness = nullptr;           // telemetry target (device [depth]) or null
 };
 
 namespace anyloc {
@@ -238,6 +240,19 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
   return ANYLOC_OK;
 }
 
+int anyloc_vit_set_telemetry(anyloc_vit_t* h, float* ffn_looseness) {
+  ANYLOC_CHECK_ARG(h, "vit_set_telemetry: null handle");
+  h->ffn_looseness = ffn_looseness;
+  return ANYLOC_OK;
+}
+
+int anyloc_vit_block_ffn_exact(anyloc_vit_t* h, int32_t layer, int32_t exact) {
+  ANYLOC_CHECK_ARG(h && layer >= 0 && layer < h->cfg.depth, "vit_block_ffn_exact: bad handle / layer");
+  if (h->ffn_exact.size() != (size_t)h->cfg.depth) h->ffn_exact.assign(h->cfg.depth, 0);
+  h->ffn_exact[layer] = exact ? 1 : 0;
+  return ANYLOC_OK;
+}
+
 void anyloc_vit_destroy(anyloc_vit_t* h) { delete h; }
 
 size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch, int64_t img_h, int64_t img_w) {
@@ -362,7 +377,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
         ANYLOC_TRY(linear(w.y, D, b.proj_w, D, b.proj_b, w.x, D, M, D, EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream));
     }
     const float* fb = h3f ? h->h2[l].fc1_bound : nullptr;
-    const bool fuse_ffn = fb && (fb[0] > 0.f || fb[1] > 0.f);
+    const bool fuse_ffn = fb && (fb[0] > 0.f || fb[1] > 0.f) && !(l < (int)h->ffn_exact.size() && h->ffn_exact[l]);
     if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, fuse_ffn ? fb : nullptr, w.hinv));
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
@@ -377,6 +392,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
                              h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, nullptr, Hh, M, 2 * Hh,
                              h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
                              w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1));
+      if (h->ffn_looseness) ANYLOC_TRY(h2_row_looseness(w.h3, M, M, Hh, h->ffn_looseness + l, stream));
       ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
     } else if (h3m) {

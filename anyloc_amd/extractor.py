@@ -22,6 +22,12 @@ from . import _lib, ops, weights
 from .synth import ARCH, PATCH, POS_GRID
 
 DEFAULT_GEMM = "h3"      # block-GEMM arithmetic when neither the constructor nor ANYLOC_GEMM says otherwise
+# FFN-bound telemetry of the h3 forward (include/anyloc_hip.h, anyloc_vit_set_telemetry): the first forward of a model and
+# every FFN_CHECK_EVERY-th after it also measure how far the Cauchy-Schwarz bound of each block's hidden activation lies
+# above the rows' real maxima; a block beyond FFN_LOOSENESS_MAX is switched to the exact row-maximum quantiser (and the
+# forward that found it is repeated).  Within 2^16 of the bound every element keeps its 22 bits; 2^14 leaves a margin of 4.
+FFN_CHECK_EVERY = 64
+FFN_LOOSENESS_MAX = 2.0 ** 14
 _DINO_V2_MODELS = ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14", "dinov2_vitg14")
 _DINO_FACETS = ("query", "key", "value", "token")
 INTERP_OFFSET = 0.1
@@ -168,6 +174,12 @@ class HipDinoV2:
             _lib.check(lib.anyloc_vit_attach_h2(self._handle, h2), "anyloc_vit_attach_h2")
         # the plane image of one activation operand must stay inside 2 GiB of buffer addressing
         self.max_rows = (2 ** 31 - 1) // (6 * max(dim, hidden)) - 512
+        # FFN-bound telemetry (h3 mode): per-block looseness of the last checked forward, blocks switched to the exact quantiser
+        self.ffn_check_every = FFN_CHECK_EVERY
+        self.ffn_looseness = None
+        self.ffn_exact_blocks = set()
+        self._forwards = 0
+        self._telemetry = torch.zeros(depth, dtype=torch.float32, device=device) if self.gemm == "h3" else None
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -249,9 +261,30 @@ class HipDinoV2:
         flags = (ops.VIT_USE_CLS if use_cls else 0) | (ops.VIT_NORM_TAPS if norm_taps else 0) | \
             (ops.VIT_NORM_CONCAT if norm_concat else 0) | (ops.VIT_SPLIT_BF16 if self.gemm == "x6" else 0) | \
             (ops.VIT_SPLIT_FP16 if self.gemm == "h3" else 0)
-        _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
-                                          n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
-                                          ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")
+        def forward():
+            _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
+                                              n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
+                                              ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")
+        check = self._telemetry is not None and self.ffn_check_every > 0 and self._forwards % self.ffn_check_every == 0
+        self._forwards += 1
+        if not check:
+            forward()
+            return out
+        # a checked forward: measure the looseness of every executed block's FFN bound; blocks beyond the limit move to the
+        # exact row-maximum quantiser and the forward is repeated with them (one host sync per checked forward)
+        self._telemetry.zero_()
+        _lib.check(lib.anyloc_vit_set_telemetry(self._handle, _lib.ptr(self._telemetry)), "anyloc_vit_set_telemetry")
+        try:
+            forward()
+        finally:
+            _lib.check(lib.anyloc_vit_set_telemetry(self._handle, None), "anyloc_vit_set_telemetry")
+        self.ffn_looseness = self._telemetry.cpu().numpy().copy()
+        tripped = [i for i, v in enumerate(self.ffn_looseness) if v > FFN_LOOSENESS_MAX and i not in self.ffn_exact_blocks]
+        if tripped:
+            for i in tripped:
+                _lib.check(lib.anyloc_vit_block_ffn_exact(self._handle, i, 1), "anyloc_vit_block_ffn_exact")
+            self.ffn_exact_blocks.update(tripped)
+            forward()
         return out
 
 

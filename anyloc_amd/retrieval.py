@@ -121,7 +121,7 @@ def gather_rows(local, counts, rank, group, comm):
 
 
 def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_descs=True,
-                   group=None, search_fn=None):
+                   group=None, search_fn=None, counts=None):
     """Database-sharded retrieval, one process per GPU.
 
     Every rank owns ``db_shard`` (rows ``shard_base ...`` of the global database)
@@ -130,15 +130,20 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
     top-k on the shard with global indices; step 3: gather the [nq,k] lists on
     rank 0 and merge on the host.  Returns (dist, idx) numpy arrays on rank 0,
     (None, None) elsewhere.  ``search_fn`` is injectable for CPU tests of the
-    collective / merge logic."""
+    collective / merge logic.  ``counts`` (optional): the query rows of every rank when the caller knows them (static
+    shares, as in bench.py) -- saves the per-call all-gather of the counts and its host sync."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     # RCCL moves device tensors over xGMI; a gloo group (CPU tests, single-GPU tests) is staged through the host
     comm = comm_device(group, qu_local.device)
-    counts = torch.zeros(world, dtype=torch.int64, device=comm)
-    dist.all_gather_into_tensor(counts, torch.tensor([qu_local.shape[0]], dtype=torch.int64, device=comm), group=group)
-    counts = [int(c) for c in counts.cpu()]
+    if counts is None:
+        cnt = torch.zeros(world, dtype=torch.int64, device=comm)
+        dist.all_gather_into_tensor(cnt, torch.tensor([qu_local.shape[0]], dtype=torch.int64, device=comm), group=group)
+        counts = [int(c) for c in cnt.cpu()]
+    else:
+        counts = [int(c) for c in counts]
+        assert len(counts) == world and counts[rank] == qu_local.shape[0], "counts must list every rank's query rows"
     qu_all = gather_rows(qu_local, counts, rank, group, comm)
     if qu_all.device != qu_local.device:
         qu_all = qu_all.to(qu_local.device)
@@ -147,13 +152,14 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
         i = torch.where(i >= 0, i + shard_base, i)
     else:
         d, i = search_fn(db_shard, qu_all, k, method, norm_descs, shard_base)
-    d, i = d.to(comm), i.to(comm)
-    out_d = [torch.empty_like(d) for _ in range(world)] if rank == 0 else None
-    out_i = [torch.empty_like(i) for _ in range(world)] if rank == 0 else None
+    # ONE gather for both lists: the fp32 distances ride as their bit patterns next to the int64 indices
+    packed = torch.cat([d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64), i.to(torch.int64)], dim=1).to(comm)
+    out_p = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
     dst = 0 if group is None or group is dist.group.WORLD else dist.get_global_rank(group, 0)
-    dist.gather(d, out_d, dst=dst, group=group)
-    dist.gather(i, out_i, dst=dst, group=group)
+    dist.gather(packed, out_p, dst=dst, group=group)
     if rank != 0:
         return None, None
-    return merge_shard_topk([x.cpu().numpy() for x in out_d], [x.cpu().numpy() for x in out_i], k,
-                            "ip" if method == "cosine" else "l2")
+    kk = d.shape[1]
+    host = [x.cpu() for x in out_p]
+    return merge_shard_topk([x[:, :kk].to(torch.int32).view(torch.float32).numpy() for x in host],
+                            [x[:, kk:].numpy() for x in host], k, "ip" if method == "cosine" else "l2")

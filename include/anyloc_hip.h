@@ -361,6 +361,16 @@ typedef struct anyloc_vit_block_h2 {
   int32_t reserved;
 } anyloc_vit_block_h2;
 int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*host array [depth]*/);
+
+/* FFN-bound telemetry of the two-term fp16 forward (ABI 5).  The fused fc1 epilogue quantises the hidden activation
+ * against an UPPER BOUND of its row (fc1_bound above); a bound that is more than ~2^16 above the row's real maximum costs
+ * low bits.  With a device array ffn_looseness [depth] (zeroed by the caller) set here, every later forward also measures,
+ * per executed block, max over token rows of 2^15 / (largest scaled magnitude the row actually holds in the fc2 operand
+ * image) -- i.e. how loose the bound was -- with one extra read of that image per block.  NULL switches it off (default).
+ * anyloc_vit_block_ffn_exact(h, layer, 1) makes that block write its activation as fp32 and quantise it against the exact
+ * row maximum instead (the data flow of fc1_bound = 0); the Python host flips it for blocks whose looseness exceeds 2^14. */
+int anyloc_vit_set_telemetry(anyloc_vit_t* h, float* ffn_looseness /*device [depth] or NULL*/);
+int anyloc_vit_block_ffn_exact(anyloc_vit_t* h, int32_t layer, int32_t exact);
 #define ANYLOC_VIT_SPLIT_FP16 16u    /* block GEMMs as three fp16 products, fp32-level accuracy */
 
 #define ANYLOC_VIT_USE_CLS 1u        /* keep the CLS row (utilities.py:270-273) */

@@ -1,0 +1,155 @@
+"""Round-4 GPU tests: retrieval index identity at the full BASELINE.json configs[1] size and on one configs[2] panel
+against an exact float64 search, the pinned host staging path, the reference scripts' CPU-tensor call pattern through
+``VLAD.generate_multi`` / ``get_top_k_recall``, and an 8-rank run of ``bench.py --workload config3`` on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def _vlad_like(n, k, d, seed):
+    """Rows shaped like VLADs: per-cluster unit blocks, globally normalised (bench.py's synthetic database recipe)."""
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    out = torch.empty(n, k * d, dtype=torch.float32, device=DEV)
+    for s in range(0, n, 1000):
+        e = min(n, s + 1000)
+        blk = torch.nn.functional.normalize(torch.randn(e - s, k, d, generator=g, device=DEV), dim=-1) / (k ** 0.5)
+        out[s:e] = blk.reshape(e - s, k * d)
+    return out
+
+
+def _float64_flat(qu, db, k, chunk=128):
+    """Exact flat inner-product search of the L2-normalised operands in float64 on the device (the checker): indices with
+    faiss' tie rule (lower index first) and the float64 score matrix chunks for tie-aware comparison."""
+    dbn = torch.nn.functional.normalize(db.double(), dim=1)
+    for s0 in range(0, qu.shape[0], chunk):
+        sc = torch.nn.functional.normalize(qu[s0:s0 + chunk].double(), dim=1) @ dbn.T
+        yield s0, sc, torch.sort(-sc, dim=1, stable=True)[1][:, :k]
+
+
+def _assert_identity(qu, db, dist, idx, k, tol=3e-6):
+    mism = swaps = 0
+    for s0, sc, order in _float64_flat(qu, db, k):
+        ours = idx[s0:s0 + order.shape[0]]
+        got, want = torch.gather(sc, 1, ours), torch.gather(sc, 1, order)
+        diff = ours != order
+        near = (got - want).abs() <= tol
+        swaps += int((diff & near).sum())
+        mism += int((diff & ~near).sum())
+        assert float((dist[s0:s0 + order.shape[0]].double() - got).abs().max()) <= tol
+        # a swap only ever exchanges near-tied neighbours: as SETS the lists differ at most at the k-th rank
+    assert mism == 0, f"{mism} indices differ from the float64 search outside {tol} ties ({swaps} near-tie swaps)"
+    return swaps
+
+
+def test_topk_index_identity_at_the_full_config2_size():
+    """1 000 queries x 10 000 rows x 49 152 columns (BASELINE.json configs[1], the reference's utilities.py:433-450 at its
+    headline size): every index of the top-20 equals the exact float64 flat search (ties -> lower index), distances within
+    3e-6, and a 48-query slice equals the faiss restatement of the oracle on the CPU."""
+    from anyloc_amd import retrieval
+    from oracle import faiss_flat
+    db = _vlad_like(10000, 32, 1536, 1)
+    qu = _vlad_like(1000, 32, 1536, 2)
+    src = torch.arange(1000, device=DEV) * 7 + 3
+    qu[:600] = 0.6 * db[src[:600]] + 0.4 * qu[:600]              # neighbours at every similarity level
+    qu[600:700] = db[src[600:700]]                               # exact copies (cosine 1)
+    qu[700:720] = 0.5 * (db[src[700:720]] + db[src[700:720] + 1])  # two near-equal neighbours
+    db[9000:9010] = db[8000:8010]                                # duplicated rows: exact ties, the lower index first
+    for lo, hi in ((0, 1000), (0, 61), (100, 356)):             # many-query panels, the few-query kernel, a mid-size call
+        d, i = retrieval.search(db, qu[lo:hi], 20)
+        swaps = _assert_identity(qu[lo:hi], db, d, i, 20)
+        assert swaps <= (hi - lo) // 10
+    d, i = retrieval.search(db, qu[640:688], 20)
+    dr, ir = faiss_flat.flat_search(torch.nn.functional.normalize(qu[640:688].cpu()), torch.nn.functional.normalize(db.cpu()), 20)
+    assert torch.equal(i[:, 0].cpu(), ir[:, 0])
+    assert float((d.cpu() - dr).abs().max()) <= 3e-6
+    both = (i.cpu() == ir)
+    assert float(both.float().mean()) > 0.98                     # fp32 CPU search vs fp32-accurate GPU search: near-ties may swap
+
+
+def test_topk_index_identity_on_a_config3_panel():
+    """2 048 queries against one 8 192-row panel of 49 152 columns (the unit of work of the many-query path at configs[2]:
+    two-term fp16 score panels on the 16x16x32 MFMA kernel, K-chunked accumulation): identical to the float64 search."""
+    from anyloc_amd import retrieval
+    db = _vlad_like(8192, 32, 1536, 3)
+    qu = _vlad_like(2048, 32, 1536, 4)
+    src = torch.arange(1024, device=DEV) * 5 + 1
+    qu[:1024] = 0.7 * db[src] + 0.3 * qu[:1024]
+    d, i = retrieval.search(db, qu, 20)
+    assert torch.equal(i[:1024, 0], src)
+    _assert_identity(qu, db, d, i, 20)
+
+
+def test_pinned_staging_round_trips():
+    """staging.to_device / to_host move bytes unchanged: below and above the 32 MiB ring chunk, above the pinned-result
+    limit, non-contiguous sources, other dtypes, already-pinned sources."""
+    from anyloc_amd import staging
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(0)
+    for shape, dtype in (((7, 13), torch.float32), ((3, 322, 322), torch.float32), ((40, 529, 1536), torch.float32),
+                         ((9_000_001,), torch.int64), ((5, 3), torch.float64), ((0, 4), torch.float32)):
+        t = (torch.randn(shape, generator=g) * 100).to(dtype)
+        on = staging.to_device(t, dev)
+        assert on.is_cuda and on.dtype == dtype and torch.equal(on.cpu(), t)
+        back = staging.to_host(on)
+        assert back.device.type == "cpu" and torch.equal(back, t)
+    t = torch.randn(300, 400, generator=g)
+    nc = t.t()[5:200:3]                                          # non-contiguous view
+    assert torch.equal(staging.to_device(nc, dev).cpu(), nc)
+    pinned = torch.randn(1000, 100, generator=g).pin_memory()
+    assert torch.equal(staging.to_device(pinned, dev).cpu(), pinned)
+    big = torch.randn(20_000_000, generator=g)                   # 80 MB: ring path both ways
+    assert torch.equal(staging.to_host(staging.to_device(big, dev)), big)
+
+
+def test_cpu_tensor_call_pattern_equals_the_device_path():
+    """What scripts/dino_v2_vlad.py does (:236-260, :372): CPU patch descriptors -> VLAD.generate_multi -> CPU VLADs ->
+    get_top_k_recall with a CPU database.  Bitwise the results of the same calls on device tensors."""
+    import utilities
+    g = torch.Generator().manual_seed(3)
+    tok = torch.nn.functional.normalize(torch.randn(37, 529, 1536, generator=g), dim=-1)
+    vlad = utilities.VLAD(32, 1536, cache_dir=None)
+    np.random.seed(1)
+    vlad.fit(tok[:8].reshape(-1, 1536))
+    v_cpu = vlad.generate_multi(tok)
+    v_dev = vlad.generate_multi(tok.to(DEV))
+    assert v_cpu.device.type == "cpu" and v_dev.is_cuda and torch.equal(v_cpu, v_dev.cpu())
+    vlad.HOST_CHUNK_IMGS = 10                                    # the chunked host path
+    assert torch.equal(vlad.generate_multi(tok), v_cpu)
+    db = _vlad_like(3000, 32, 1536, 9).cpu()
+    db[5:42] = v_cpu
+    gt = np.empty(37, dtype=object)
+    for j in range(37):
+        gt[j] = np.array([5 + j])
+    d1, i1, r1 = utilities.get_top_k_recall([1, 5], db, v_cpu, gt)
+    d2, i2, r2 = utilities.get_top_k_recall([1, 5], db.to(DEV), v_dev, gt)
+    assert i1.device.type == "cpu" and torch.equal(i1, i2.cpu()) and torch.equal(d1, d2.cpu())
+    assert r1 == r2 and r1[1] == 1.0
+
+
+def test_bench_config3_eight_ranks_on_one_gpu():
+    """``bench.py --workload config3 --gpus 8`` at a reduced shard (8 x 2 048 rows, 512 queries) with the ranks sharing the one
+    GPU over gloo: the query all-gather with static counts, eight per-shard searches with global indices, the single packed
+    gather and the host merge -- the planted neighbour of every rank-0 query is found in ITS shard."""
+    env = dict(os.environ, ANYLOC_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config3", "--gpus", "8", "--steps", "1",
+                          "--warmup", "0", "--queries", "512", "--shard-rows", "2048"], env=env, capture_output=True, text=True,
+                         timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["unit"] == "queries/s" and out["value"] > 0
+    assert out["planted_neighbours_found"] is True
+    assert out["config"]["db_rows_total"] == 8 * 2048 and out["config"]["queries"] == 512

@@ -155,19 +155,91 @@ def test_config1_pipeline_through_reference_surface(g1, c1, capsys):
 
 @pytest.mark.parametrize("batch", [1, 2])
 def test_small_batch_kernels_are_bitwise_the_plain_ones(batch, monkeypatch):
-    """One or two images run 64x64 GEMM tiles with four / two k-blocks per ring stage (proj, fc2) and a LayerNorm with one
-    row per wave (csrc/gemm_h3.hip): scheduling changes only -- the tokens must equal, bit for bit, those of the kernels
-    with one k-block per stage and four rows per wave (options h3_deep_max = h3_deep2_max = ln_small_rows = 0)."""
+    """Round-3 small-batch kernels (option h3s_enable = 0): one or two images run 64x64 GEMM tiles with four / two k-blocks
+    per ring stage (proj, fc2) and a LayerNorm with one row per wave: scheduling changes only -- the tokens must equal, bit
+    for bit, those of the kernels with one k-block per stage and four rows per wave (options h3_deep_max = h3_deep2_max =
+    ln_small_rows = 0)."""
     import utilities
     name = "dinov2_vitg14"
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device=DEV, depth=3))
     try:
         ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
         img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(batch)).to(DEV)
-        got = ext(img).clone()
         from anyloc_amd import ops
-        with ops.options(h3_deep_max=0, h3_deep2_max=0, ln_small_rows=0):
-            want = ext(img).clone()
+        with ops.options(h3s_enable=0):
+            got = ext(img).clone()
+            with ops.options(h3_deep_max=0, h3_deep2_max=0, ln_small_rows=0):
+                want = ext(img).clone()
         assert torch.isfinite(got).all() and torch.equal(got, want)
+    finally:
+        weights.unregister_state_dict(name)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 5])
+def test_small_m_plans_agree_with_the_plain_kernels(batch):
+    """The small-M plans of csrc/gemm_h3s.hip (other tile shapes, several k-blocks per ring stage, split-K with a
+    deterministic split-order reduction) change the summation order over k, nothing else: every plan -- the table's choice
+    and each forced (tile configuration, ring depth, split factor) -- gives tokens within 2e-6 of the round-3 kernels, the
+    same bits run to run, on a 3-block ViT-g (all four block GEMMs + the facet GEMM go through the plans)."""
+    import utilities
+    from anyloc_amd import ops
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device=DEV, depth=3))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
+        ext.dino_model.ffn_check_every = 0
+        img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(10 + batch)).to(DEV)
+        with ops.options(h3s_enable=0):
+            want = ext(img).clone()
+        got = ext(img).clone()
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= 2e-6
+        assert torch.equal(got, ext(img))
+        plans = [(c, kb, ks) for c in range(7) for kb, ks in ((1, 1), (2, 3), (4, 2), (1, 8), (2, 5))]
+        for cfg, kb, ks in plans:
+            with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks):
+                a = ext(img).clone()
+                b = ext(img)
+            assert float((a - want).abs().max()) <= 2e-6, (cfg, kb, ks, float((a - want).abs().max()))
+            assert torch.equal(a, b), (cfg, kb, ks, "not reproducible")
+    finally:
+        weights.unregister_state_dict(name)
+
+
+def test_ffn_bound_telemetry_switches_a_loose_block_to_the_exact_quantiser():
+    """h3 forward: the fused fc1 epilogue quantises the hidden activation against a Cauchy-Schwarz bound.  A weight set
+    whose bound is far above the real activations (one fc1 row of huge norm along the direction LayerNorm's output never
+    moves in) trips the telemetry: the block is switched to the exact row-maximum quantiser and the tokens still meet the
+    oracle bar; ordinary blocks stay fused."""
+    import utilities
+    from anyloc_amd import extractor as ex
+    from oracle import dinov2_ref
+    name = "dinov2_vits14"
+    sd = synth.synthetic_state_dict(name, 5, device="cpu", depth=4)
+    # block 2, hidden unit 7: weight row c * d with d . (LN2 output - LN2 bias) = 0 for every token (d ~ 1 / norm2.weight, the
+    # one direction a LayerNorm output cannot move along) and bias -c * (d . LN2 bias): a huge row norm -- the bound of every
+    # token row grows ~3000 x -- whose pre-activation is ~0 for every token, so the real activations do not change
+    w, b = sd["blocks.2.norm2.weight"].double(), sd["blocks.2.norm2.bias"].double()
+    d = (1.0 / w) / (1.0 / w).norm()
+    f1 = sd["blocks.2.mlp.fc1.weight"].double()
+    c = 3000.0 * float(f1.norm(dim=1).max())
+    f1[7] = c * d
+    sd["blocks.2.mlp.fc1.weight"] = f1.float()
+    sd["blocks.2.mlp.fc1.bias"][7] = float(-c * (d * b).sum())
+    weights.register_state_dict(name, {k: v.to(DEV) for k, v in sd.items()})
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 3, "token", device=DEV)
+        assert ext.dino_model.gemm == "h3"
+        img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+        got = ext(img.to(DEV)).cpu()
+        m = ext.dino_model
+        assert m.ffn_looseness is not None and m.ffn_looseness[2] > ex.FFN_LOOSENESS_MAX, m.ffn_looseness
+        assert m.ffn_exact_blocks == {2}, (m.ffn_exact_blocks, m.ffn_looseness)
+        assert all(0 < m.ffn_looseness[i] <= ex.FFN_LOOSENESS_MAX for i in (0, 1, 3)), m.ffn_looseness
+        ref = dinov2_ref.extract_facet(dinov2_ref.build(name, sd), img, 3, "token")
+        assert float((got - ref).abs().max()) <= 2e-5
+        # the switch is sticky and later forwards need no repeat
+        again = ext(img.to(DEV)).cpu()
+        assert torch.equal(again, got)
     finally:
         weights.unregister_state_dict(name)
