@@ -180,42 +180,58 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (p.ksplit > 1) {
-    // partial accumulators -> workspace in register order (16 bytes per lane, whole 1-KiB runs per instruction); ticket
-    // between an agent-scope release and acquire (the per-XCD L2s are not coherent with each other), as vlad_fused.hip
+    // Partial accumulators -> workspace in register order, 16 bytes per lane (whole 1-KiB runs per instruction), as
+    // WRITE-THROUGH (sc1) stores: they reach the device-coherent level themselves, so no release fence -- an agent-scope
+    // release is an L2 write-back, and one per workgroup made a split GEMM 3-4 x SLOWER than the unsplit one
+    // (profiles/r04_b1_plan_sweep_fences.log).  Every wave drains its stores, the workgroup meets, ONE lane takes the tile's
+    // ticket (relaxed, agent scope), and the last arrival reads all slabs back with sc1 loads (the per-XCD L2s are not
+    // coherent with each other) IN SPLIT ORDER -- deterministic whichever workgroup arrives last.  The hand-off recipe of
+    // cdna_hip_programming.md section 6 (counter form).  The flag travels through the (now idle) LDS ring: a second
+    // __shared__ object would cost every k-step of the pipeline a full vmcnt drain.
     constexpr int NT = 64 * Cfg::NW;
+    constexpr int SC1 = 16;                                  // aux bit of the buffer instructions: sc1
     const int tile = tm * tiles_n + tn;
-    f32x4* part = reinterpret_cast<f32x4*>(p.sk_part) + ((int64_t)split * ntiles + tile) * (MI * NI * 4 * NT) + tid;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          part[((mi * NI + ni) * 4 + q) * NT] =
-              f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-    __shared__ int sk_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(p.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sk_last = ticket == (unsigned)(p.ksplit - 1);
-      if (sk_last) p.sk_tickets[tile] = 0;                // the array is clean again for the next launch on this stream
-    }
-    __syncthreads();
-    if (!sk_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.sk_part) + (int64_t)tile * (MI * NI * 4 * NT) + tid;
-    const int64_t sstride = (int64_t)ntiles * (MI * NI * 4 * NT);
+    const int64_t slab = (int64_t)(MI * NI * 4 * NT) * 16;   // bytes of one tile's partial
+    const __amdgpu_buffer_rsrc_t sk_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(p.sk_part), 0, (int)((int64_t)p.ksplit * ntiles * slab), 0x00020000);
+    const unsigned own = (unsigned)(((int64_t)split * ntiles + tile) * slab) + (unsigned)tid * 16u;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 t = src[((mi * NI + ni) * 4 + q) * NT];
+          const hu32x4 v = {__float_as_uint(acc[mi][ni][4 * q]), __float_as_uint(acc[mi][ni][4 * q + 1]),
+                            __float_as_uint(acc[mi][ni][4 * q + 2]), __float_as_uint(acc[mi][ni][4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, sk_rsrc, own + (unsigned)(((mi * NI + ni) * 4 + q) * NT * 16), 0, SC1);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                         // (also: nobody reads fragments from the ring any more)
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(p.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(p.ksplit - 1);
+      if (last) __hip_atomic_store(p.sk_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+      *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();                                         // (the epilogues reuse the ring)
+    if (!last) return;
+    const unsigned base = (unsigned)((int64_t)tile * slab) + (unsigned)tid * 16u;
+    const unsigned sstride = (unsigned)((int64_t)ntiles * slab);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned off = base + (unsigned)(((mi * NI + ni) * 4 + q) * NT * 16);
+          hu32x4 u = __builtin_amdgcn_raw_buffer_load_b128(sk_rsrc, off, 0, SC1);
+          f32x4 t = {__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
           for (int sp = 1; sp < p.ksplit; ++sp) {
-            const f32x4 u = src[sp * sstride + ((mi * NI + ni) * 4 + q) * NT];
-            t[0] += u[0]; t[1] += u[1]; t[2] += u[2]; t[3] += u[3];
+            u = __builtin_amdgcn_raw_buffer_load_b128(sk_rsrc, off, (unsigned)sp * sstride, SC1);
+            t[0] += __uint_as_float(u[0]); t[1] += __uint_as_float(u[1]); t[2] += __uint_as_float(u[2]); t[3] += __uint_as_float(u[3]);
           }
           acc[mi][ni][4 * q] = t[0]; acc[mi][ni][4 * q + 1] = t[1]; acc[mi][ni][4 * q + 2] = t[2]; acc[mi][ni][4 * q + 3] = t[3];
         }

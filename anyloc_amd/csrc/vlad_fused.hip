@@ -412,6 +412,40 @@ constexpr int f3_cw(int slice) {
 }
 constexpr int f3_gcd(int x, int y) { return y == 0 ? x : f3_gcd(y, x % y); }
 
+// CW consecutive fp32 columns of a lane as ONE memory instruction (CW = 3: buffer_load_dwordx3 -- a lane's columns start at a
+// multiple of 12 bytes, dword alignment is all a buffer access needs); other widths fall back to dwords
+typedef unsigned f3_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned f3_u32x3 __attribute__((ext_vector_type(3)));
+template <int CW>
+__device__ __forceinline__ void f3_load_cols(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float (&c)[CW]) {
+  if constexpr (CW == 2) {
+    const f3_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+    c[0] = __uint_as_float(r[0]); c[1] = __uint_as_float(r[1]);
+  } else if constexpr (CW == 3) {
+    const f3_u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, soff, 0);
+    c[0] = __uint_as_float(r[0]); c[1] = __uint_as_float(r[1]); c[2] = __uint_as_float(r[2]);
+  } else if constexpr (CW == 4) {
+    const u32x4s r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    c[0] = __uint_as_float(r[0]); c[1] = __uint_as_float(r[1]); c[2] = __uint_as_float(r[2]); c[3] = __uint_as_float(r[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < CW; ++j) c[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4 * j, soff, 0));
+  }
+}
+template <int CW>
+__device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, const float (&c)[CW]) {
+  if constexpr (CW == 2) {
+    __builtin_amdgcn_raw_buffer_store_b64(f3_u32x2{__float_as_uint(c[0]), __float_as_uint(c[1])}, rsrc, voff, soff, 0);
+  } else if constexpr (CW == 3) {
+    __builtin_amdgcn_raw_buffer_store_b96(f3_u32x3{__float_as_uint(c[0]), __float_as_uint(c[1]), __float_as_uint(c[2])}, rsrc, voff, soff, 0);
+  } else if constexpr (CW == 4) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4s{__float_as_uint(c[0]), __float_as_uint(c[1]), __float_as_uint(c[2]), __float_as_uint(c[3])}, rsrc, voff, soff, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < CW; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c[j]), rsrc, voff + 4 * j, soff, 0);
+  }
+}
+
 template <int NV, int SW, bool KMEANS>
 __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   constexpr int D = NV * 128;
@@ -592,22 +626,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       }
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
-      if (rs == 0.f) {
-        // rare: the token's slice is all zero -- or its squares underflowed (|x| < ~1e-19).  The zero-row rule of the assign
-        // phase (no exact resolution for a row whose norm is 0) must only fire for rows that are bitwise zero, so a slice
-        // with any non-zero bit reports the smallest positive float instead of 0 (absorbed by any normal sum of squares)
-        unsigned ob = 0;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb);
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(a_frag + 32 * kb + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ob |= __float_as_uint(x0[e]) | __float_as_uint(x1[e]);
-        }
-        ob |= (unsigned)__shfl_xor((int)ob, 16, 64);
-        ob |= (unsigned)__shfl_xor((int)ob, 32, 64);
-        if (ob & 0x7fffffffu) rs = __uint_as_float(1u);
-      }
       if (fq == 0) rsqp[wave * TT + fr] = rs;
     }
     lds_barrier();
@@ -653,8 +671,21 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       const bool live = row < valid;
       // (a row that is BITWISE all zero has EXACT screening scores -- its matrix-core part is 0, the bias is fp32 -- so its
       // 32-way tie needs no resolution: first index, as the exact kernels give; without this rule zero rows cost 13x a
-      // normal row.  xn == 0 means exactly that: a slice with a non-zero bit contributes at least 2^-149 to q, see above)
-      const bool close = live && !(xn == 0.f) && __builtin_popcount(mask) > 1;
+      // normal row.  A zero sum of squares alone does not say that: the squares of |x| < ~1e-19 underflow, and such a row
+      // still orders its tiny scores -- so on xn == 0 (rare) the row's 32 lanes OR its bits from the LDS tile)
+      bool zero_row = false;
+      if (xn == 0.f) {
+        int tl2 = tl;
+        asm volatile("" : "+v"(tl2));
+        const float* xr = tile + ((tl2 >> 5) + 2 * SW * it) * LD + (tl2 & 31);
+        unsigned ob = 0;
+#pragma unroll 4
+        for (int i = 0; i < D / 32; ++i) ob |= __float_as_uint(xr[32 * i]);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) ob |= (unsigned)__shfl_xor((int)ob, o, 64);
+        zero_row = (ob & 0x7fffffffu) == 0u;
+      }
+      const bool close = live && !zero_row && __builtin_popcount(mask) > 1;
       if (close && ((mask >> k) & 1u)) pairs[atomicAdd(npairs, 1)] = (row << 5) | k;   // LDS atomic; order is irrelevant
       if (k == 0) {
         if (bi == 0x7fffffff) bi = 0;
@@ -747,19 +778,19 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
           static_for<CW>([&](auto j) { acc[j][(int)k] += v[j]; });
         }
       };
-      // four tokens per round: one LDS round trip for their labels and columns, then the register-indexed adds
+      if constexpr (KMEANS) {
+        // four tokens per round: one LDS round trip for their labels and columns, then the register-indexed adds
 #pragma unroll 1
-      for (int n4 = 0; n4 < TT; n4 += 4) {
-        const i32x4_t lq = *reinterpret_cast<const i32x4_t*>(lab + n4);
-        float v[4][CW];
+        for (int n4 = 0; n4 < TT; n4 += 4) {
+          const i32x4_t lq = *reinterpret_cast<const i32x4_t*>(lab + n4);
+          float v[4][CW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < CW; ++j) v[e][j] = tp[(n4 + e) * LD + j];
-        int kk[4];
+            for (int j = 0; j < CW; ++j) v[e][j] = tp[(n4 + e) * LD + j];
+          int kk[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
-        if (KMEANS) {
+          for (int e = 0; e < 4; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // rows past the unit carry label -1 and are all zero (the loads were out of the descriptor's range): adding
@@ -767,23 +798,41 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             add_token(kk[e] < 0 ? 0 : kk[e], v[e]);
             if (wave == 0) my_count += (lane == kk[e]) ? 1u : 0u;
           }
-        } else {
-          // x / ||x|| - c_k: the centre's CW columns come from L2
-          float c[4][CW];
+        }
+      } else {
+        // x / ||x|| - c_k.  The centres' CW columns of TG tokens are requested at once -- one CW-wide load per token, TT / TG
+        // L2 round trips per tile (round 3: four rounds of four tokens, CW dword loads each, every round waiting for its
+        // own round trip) -- and the tokens are then added in order while their columns come from the LDS tile.  The
+        // order of additions per (cluster, column) is the token order, as before: bitwise the same sums.
+        // TG tokens per round (option of the build: 16 = the whole tile needs 16 CW registers more than this kernel has at
+        // D = 1536; 8 = two round trips per tile instead of four)
+        constexpr int TG = 8;
+#pragma unroll 1
+        for (int g0 = 0; g0 < TT; g0 += TG) {
+          int kk[TG];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned so = (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4);
+          for (int n4 = 0; n4 < TG; n4 += 4) {
+            const i32x4_t lq = *reinterpret_cast<const i32x4_t*>(lab + g0 + n4);
 #pragma unroll
-            for (int j = 0; j < CW; ++j)
-              c[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cen_rsrc, (unsigned)((gcol + j) * 4), so, 0));
+            for (int e = 0; e < 4; ++e) kk[n4 + e] = __builtin_amdgcn_readfirstlane(lq[e]);
           }
-          const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + n4);
+          float c[TG][CW];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float inv = 1.0f / nq[e];
+          for (int e = 0; e < TG; ++e)
+            f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
 #pragma unroll
-            for (int j = 0; j < CW; ++j) v[e][j] = v[e][j] * inv - c[e][j];
-            add_token(kk[e], v[e]);
+          for (int n4 = 0; n4 < TG; n4 += 4) {
+            const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + g0 + n4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v[CW];
+#pragma unroll
+              for (int j = 0; j < CW; ++j) v[j] = tp[(g0 + n4 + e) * LD + j];
+              const float inv = 1.0f / nq[e];
+#pragma unroll
+              for (int j = 0; j < CW; ++j) v[j] = v[j] * inv - c[n4 + e][j];
+              add_token(kk[n4 + e], v);
+            }
           }
         }
       }
@@ -794,21 +843,34 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   }
 
   const bool g_live = lane < GL;
+  // a lane's CW columns of cluster k travel as one CW-wide buffer access (idle lanes of a 48-lane slice point past the
+  // descriptor: their stores are dropped, their loads return zeros)
+  const int64_t kd = (int64_t)a.K * D;
+  const unsigned col_off = g_live ? (unsigned)(gcol * 4) : 0x7fffff00u;
+  auto cols_of = [&](auto kc, float (&v)[CW]) { static_for<CW>([&](auto j) { v[(int)j] = acc[j][(int)kc]; }); };
   if (KMEANS) {
-    float* o = a.out + unit * a.K * (int64_t)D + gcol;
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out + unit * kd), 0, (int)(kd * 4), 0x00020000);
     static_for<32>([&](auto k) {
-      if (k < a.K && g_live) static_for<CW>([&](auto j) { o[(int64_t)k * D + j] = acc[j][(int)k]; });
+      if (k < a.K) {
+        float v[CW];
+        cols_of(k, v);
+        f3_store_cols<CW>(o_rsrc, col_off, (unsigned)((int)k * D * 4), v);
+      }
     });
     if (wave == 0 && lane < a.K) a.cnt_part[unit * a.K + lane] = my_count;
     return;
   }
   if (a.parts > 1) {
     // (the hand-off of vlad_fused_kernel: partial sums -> workspace, last ticket reduces in part order)
-    const int64_t kd = (int64_t)a.K * D;
     {
-      float* pb = a.part_buf + (unit * a.parts + part_id) * kd + gcol;
+      const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.part_buf + (unit * a.parts + part_id) * kd), 0, (int)(kd * 4), 0x00020000);
       static_for<32>([&](auto k) {
-        if (k < a.K && g_live) static_for<CW>([&](auto j) { pb[(int64_t)k * D + j] = acc[j][(int)k]; });
+        if (k < a.K) {
+          float v[CW];
+          cols_of(k, v);
+          f3_store_cols<CW>(p_rsrc, col_off, (unsigned)((int)k * D * 4), v);
+        }
       });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -823,15 +885,29 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     }
     __syncthreads();
     if (!lab[0]) return;
-    static_for<CW>([&](auto j) {
-      static_for<32>([&](auto k) { acc[j][(int)k] = 0.f; });
+    // the parts' sums of a cluster, added in part order; all parts' loads of a cluster are in flight together (<= 8 parts:
+    // 8 CW registers) and CW-wide -- round 3 issued parts x 32 x CW dword loads one behind the other: 39 us for the 784 KB of
+    // 61 images x 4 parts
+    const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.part_buf + unit * a.parts * kd), 0, (int)imin64((int64_t)a.parts * kd * 4, 0x7fffffff), 0x00020000);
+    static_for<32>([&](auto k) {
+      if (k < a.K) {
+        float sum[CW];
+        static_for<CW>([&](auto j) { sum[(int)j] = 0.f; });
+        for (int q0 = 0; q0 < a.parts; q0 += 8) {
+          float pv[8][CW];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q0 + q < a.parts) f3_load_cols<CW>(q_rsrc, col_off, (unsigned)(((q0 + q) * kd + (int)k * D) * 4), pv[q]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q0 + q < a.parts) static_for<CW>([&](auto j) { sum[(int)j] += pv[q][(int)j]; });
+        }
+        static_for<CW>([&](auto j) { acc[j][(int)k] = sum[(int)j]; });
+      } else {
+        static_for<CW>([&](auto j) { acc[j][(int)k] = 0.f; });
+      }
     });
-    const float* pb = a.part_buf + unit * a.parts * kd + gcol;
-    for (int q = 0; q < a.parts; ++q) {
-      static_for<32>([&](auto k) {
-        if (k < a.K && g_live) static_for<CW>([&](auto j) { acc[j][(int)k] += pb[q * kd + (int64_t)k * D + j]; });
-      });
-    }
   }
   // intra-norm of each cluster block (its columns are spread over the SW waves), then the global norm
   if (a.intra) {
@@ -862,9 +938,13 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
 #pragma unroll
   for (int w2 = 0; w2 < SW; ++w2) tot += red[w2];
   const float gn = fmaxf(sqrtf(tot), 1e-12f);
-  float* o = a.out + unit * a.K * (int64_t)D + gcol;
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out + unit * kd), 0, (int)(kd * 4), 0x00020000);
   static_for<32>([&](auto k) {
-    if (k < a.K && g_live) static_for<CW>([&](auto j) { o[(int64_t)k * D + j] = acc[j][(int)k] / gn; });
+    if (k < a.K) {
+      float v[CW];
+      static_for<CW>([&](auto j) { v[(int)j] = acc[j][(int)k] / gn; });
+      f3_store_cols<CW>(o_rsrc, col_off, (unsigned)((int)k * D * 4), v);
+    }
   });
 }
 

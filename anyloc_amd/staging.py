@@ -6,21 +6,41 @@ rows) and read CPU tensors back.  A ``tensor.to(device)`` from pageable memory i
 through its own small bounce buffer; here the host side of every transfer is a page-locked buffer and the DMA is
 asynchronous:
 
-* ``to_device``: the source is copied chunk by chunk (32 MiB) into a ring of pinned buffers by the host's cores
-  (``Tensor.copy_`` between CPU tensors is a multi-threaded memcpy) while the previous chunk's DMA is in flight;
+* ``to_device``: the source is copied chunk by chunk (32 MiB) into a ring of pinned buffers by several host threads
+  while the previous chunk's DMA is in flight;
 * ``to_host``: results up to 64 MiB are written by ONE asynchronous DMA straight into a pinned result tensor (torch's
   caching host allocator recycles the pages); larger ones go through the ring into an ordinary tensor, the host memcpy of
   chunk i running under the DMA of chunk i + 1.
 
 No arithmetic happens here; the module only moves bytes.
 """
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 
 CHUNK_BYTES = 32 << 20
 RING = 3
 PINNED_RESULT_MAX = 64 << 20
 
+COPY_THREADS = 8               # host cores that fill / drain a pinned chunk together
 _rings = {}
+_pool = None
+
+
+def _host_copy(dst, src):
+    """dst[:] = src for two flat uint8 CPU tensors.  One ``Tensor.copy_`` is a single-threaded memcpy (~8 GB/s from pageable
+    memory, measured on the MI355X host: profiles/r04_staging.log); COPY_THREADS slices run concurrently instead (``copy_``
+    releases the GIL), which is what lets the PCIe DMA -- not the host -- bound a large transfer."""
+    global _pool
+    n = dst.numel()
+    if n < (4 << 20):
+        dst.copy_(src)
+        return
+    if _pool is None:
+        _pool = ThreadPoolExecutor(max_workers=COPY_THREADS, thread_name_prefix="anyloc-staging")
+    step = -(-n // COPY_THREADS)
+    step = (step + 4095) // 4096 * 4096
+    list(_pool.map(lambda o: dst[o:o + step].copy_(src[o:o + step]), range(0, n, step)))
 
 
 class _Ring:
@@ -77,7 +97,7 @@ def to_device(t, device):
     for off in range(0, nbytes, CHUNK_BYTES):
         n = min(CHUNK_BYTES, nbytes - off)
         i, buf = ring.next()
-        buf[:n].copy_(src[off:off + n])
+        _host_copy(buf[:n], src[off:off + n])
         dst[off:off + n].copy_(buf[:n], non_blocking=True)
         ring.mark(i)
     return out
@@ -104,7 +124,7 @@ def to_host(t):
         while len(pending) > limit:
             i, off, n = pending.pop(0)
             ring.events[i].synchronize()
-            dst[off:off + n].copy_(ring.bufs[i][:n])
+            _host_copy(dst[off:off + n], ring.bufs[i][:n])
             ring.events[i] = None                       # the buffer is free as soon as the host copy is done
     for off in range(0, nbytes, CHUNK_BYTES):
         n = min(CHUNK_BYTES, nbytes - off)
