@@ -63,6 +63,7 @@ enum Option {
   OPT_H3_EPI_LDS,        // gemm_h3 LayerScale-residual epilogue: 1 = 16-byte accesses through LDS, 0 = dword read-modify-write
   OPT_LN_ROWS_PER_WAVE,  // layernorm_h2: 0 = by ln_small_rows; 1 / 2 / 4 = rows per wave at every size (A/B)
   OPT_LN_SMALL_ROWS,     // layernorm_h2: below this many rows one row per wave
+  OPT_LN_DIRECT_ROWS,    // layernorm_h2: below this many rows one single-wave workgroup per row, no LDS tile (0 = never)
   OPT_H3_FUSE,           // h3 forward: 1 = q|k|v, attention output and FFN activation stay in fp16 planes; 0 = fp32 + quantiser passes
   OPT_X6_FUSE,           // x6 forward: the same for the bf16 plane images
   OPT_H3_MIN_ROWS,       // h3 forward: below this many token rows use the fp32-MFMA kernels
@@ -83,6 +84,7 @@ enum Option {
   OPT_H3S_CFG,           // tile configuration id (-1 = the plan table)
   OPT_H3S_KSPLIT,        // split-K factor (0 = the plan table)
   OPT_H3S_KB,            // k-blocks per ring stage: 1, 2 or 4 (0 = the plan table)
+  OPT_H3S_STAGES,        // ring depth: 3 or 6 (0 = the plan table)
   OPT_H3S_MASK,          // which GEMMs the three overrides apply to: bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 others
   OPT_H3S_ENABLE,        // 1 = small-M plans (default), 0 = the round-3 small-batch kernels (64x64 two-wave tiles, no split-K)
   OPT_COUNT

@@ -309,6 +309,79 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
 }
 
 
+// The same LayerNorm for FEW rows (one or two images): one wave per row, one row per workgroup, and every lane stores its own
+// four-column groups straight into the image (8 bytes per plane and group) -- no LDS tile, no barriers.  A 530-row launch
+// is 530 single-wave workgroups on 256 CUs and is bound by one wave's load -> two reductions -> store chain instead of the
+// 12 barriers of the tiled kernel (13 -> 7 us per launch, profiles/r04_b1_kernels.log).  Per-row arithmetic as above: same bits.
+template <int NV>
+__global__ __launch_bounds__(64) void layernorm_h2_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, int dim, int64_t rows, float eps,
+                                                                 unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
+                                                                 const f32x4 bound4, float* __restrict__ bound_inv) {
+  const int lane = threadIdx.x;
+  const int n4 = dim >> 2;
+  const int64_t row = blockIdx.x;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      v[i] = xr[idx];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)dim;
+  float qs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < n4) {
+      const float d0 = v[i][0] - mean, d1 = v[i][1] - mean, d2 = v[i][2] - mean, d3 = v[i][3] - mean;
+      qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
+  float amax = 0.f, ysq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+        amax = fmaxf(amax, fabsf(v[i][j]));
+        ysq += v[i][j] * v[i][j];
+      }
+    }
+  }
+  float iv;
+  const float scale = h2_row_scale(wave_max(amax), iv);
+  if (lane == 0) inv[row] = iv;
+  if (bound_inv) {
+    const float yn = sqrtf(wave_sum(ysq)) * 1.001f;
+    const float bg = yn * bound4[0] + bound4[1];
+    const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
+    float biv;
+    h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
+    if (lane == 0) bound_inv[row] = biv;
+  }
+  const int swap = (int)((row >> 3) & 1);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;                        // columns 4 idx .. 4 idx + 3: k-block idx / 4, quarter idx % 4
+    if (idx < n4) {
+      unsigned h0, l0, h1, l1;
+      h2_pack2(v[i][0] * scale, v[i][1] * scale, h0, l0);
+      h2_pack2(v[i][2] * scale, v[i][3] * scale, h1, l1);
+      const int q = idx & 3;
+      unsigned char* dst = out + (((int64_t)(idx >> 2) * 2) * R + row) * 32 + (((q >> 1) ^ swap) << 4) + ((q & 1) << 3);
+      *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+      *reinterpret_cast<uint2*>(dst + R * 32) = uint2{l0, l1};
+    }
+  }
+}
+
 // FFN-bound telemetry (anyloc_vit_set_telemetry): largest scaled magnitude of every row of an h2 image (the leading plane
 // carries it) -> looseness of the bound the row was quantised against, 2^15 / max; the launch's maximum lands in *out.
 // One thread per row, k-blocks walked in order: adjacent rows are adjacent 32-byte pieces, so a wave reads 2-KiB runs.
@@ -396,6 +469,21 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   // was the round-2 kernel, one row per wave at this size 11.4 ms -- profiles/r03_ab_attn_kbatch_ln_rpw.log).  Option
   // ln_rows_per_wave (0 = that rule) forces 1, 2 or 4 at every size (A/B; same per-row arithmetic, same bits)
   const int64_t forced = option(OPT_LN_ROWS_PER_WAVE);
+  if (forced == 0 && rows < option(OPT_LN_DIRECT_ROWS)) {
+    // a few hundred rows: one single-wave workgroup per row, image written straight from registers
+    const dim3 grid((unsigned)rows);
+#define ANYLOC_LN_H2_D(NVV)                                                                                              \
+  hipLaunchKernelGGL((layernorm_h2_direct_kernel<NVV>), grid, dim3(64), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
+                     rows, b4, bound ? bound_inv : nullptr)
+    if (nv <= 1) ANYLOC_LN_H2_D(1);
+    else if (nv <= 2) ANYLOC_LN_H2_D(2);
+    else if (nv <= 3) ANYLOC_LN_H2_D(3);
+    else if (nv <= 4) ANYLOC_LN_H2_D(4);
+    else if (nv <= 6) ANYLOC_LN_H2_D(6);
+    else ANYLOC_LN_H2_D(8);
+#undef ANYLOC_LN_H2_D
+    return launch_status("layernorm_h2_direct_kernel");
+  }
   const int rpw = (forced == 1 || forced == 2 || forced == 4) ? (int)forced : (rows < option(OPT_LN_SMALL_ROWS) ? 1 : 2);
   const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
 #define ANYLOC_LN_H2_R(NVV, RPWV)                                                                                        \

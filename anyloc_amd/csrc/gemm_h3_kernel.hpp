@@ -173,9 +173,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   };
   for (int kt = 0; kt < nk; kt += STAGES) {
     slab(kt, 0);
-    if (kt + 1 < nk) slab(kt + 1, 1);
-    if (STAGES > 2 && kt + 2 < nk) slab(kt + 2, 2);
-    if (STAGES > 3 && kt + 3 < nk) slab(kt + 3, 3);
+#pragma unroll
+    for (int st = 1; st < STAGES; ++st)
+      if (kt + st < nk) slab(kt + st, st);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

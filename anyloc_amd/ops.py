@@ -18,8 +18,8 @@ VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1,
 
 
 def _f32c(t, device=None):
-    """-> contiguous fp32 tensor (on ``device`` when given).  CPU sources are staged through pinned buffers with
-    asynchronous copies (staging.py); a dtype conversion happens on the device, after the copy."""
+    """-> contiguous fp32 tensor (on ``device`` when given; staging.py: the plain copy is at the PCIe rate here); a dtype
+    conversion happens on the device, after the copy."""
     if device is not None and t.device != device:
         t = staging.to_device(t, device)
     if t.dtype != torch.float32:
@@ -28,8 +28,8 @@ def _f32c(t, device=None):
 
 
 def to_home(t, home):
-    """Result tensor back to where the caller's inputs live: device tensors stay, CPU callers get a CPU tensor through
-    the pinned staging path (complete on return)."""
+    """Result tensor back to where the caller's inputs live: device tensors stay, CPU callers get a CPU tensor (complete
+    on return)."""
     home = torch.device(home)
     if t.device == home:
         return t

@@ -58,6 +58,8 @@ const char* anyloc_last_error(void);
  *   h3_epi_lds (1)                    LayerScale-residual epilogue with 16-byte accesses through LDS
  *   ln_rows_per_wave (0)              layernorm_h2: 1 / 2 / 4 rows per wave at every size (0 = by ln_small_rows)
  *   ln_small_rows (4096)              layernorm_h2: one row per wave below this many rows
+ *   ln_direct_rows (1200)             layernorm_h2: below this many rows one single-wave workgroup per row writes the image
+ *                                     straight from registers (no LDS tile, no barriers); 0 = never
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
@@ -73,9 +75,9 @@ const char* anyloc_last_error(void);
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
  *   h3s_enable (1)                    small-M plans of the two-term fp16 GEMM (csrc/gemm_h3s.hip: tile shape, ring depth and split-K
  *                                     factor per GEMM shape when a call has one or a few images); 0 = the round-3 small-batch kernels
- *   h3s_cfg (-1) h3s_ksplit (0) h3s_kb (0) h3s_mask (31)
+ *   h3s_cfg (-1) h3s_ksplit (0) h3s_kb (0) h3s_stages (0) h3s_mask (31)
  *                                     overrides of that plan table for sweeps: tile configuration id, split-K factor, k-blocks per
- *                                     ring stage; mask bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 other GEMMs
+ *                                     ring stage, ring depth (3 or 6); mask bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 other GEMMs
  * Unknown names are rejected (ANYLOC_ERR_INVALID_ARG).  Not thread-safe against
  * concurrent launches that read the option being changed. */
 int anyloc_set_option(const char* name, int64_t value);

@@ -1,6 +1,6 @@
-"""Host <-> device copy rates of the pinned staging path (anyloc_amd/staging.py) against plain tensor.to() / .cpu() from
-pageable memory, at the sizes the reference scripts move: one image, one image's tokens, 256 images' tokens, the 10 000-row
-VLAD database.     python tools/time_staging.py > gpurun_out/staging.log"""
+"""Host <-> device copy rates from pageable memory at the sizes the reference scripts move: one image, one image's tokens,
+256 images' tokens, the 10 000-row VLAD database (what anyloc_amd/staging.py does: plain tensor.to() / .cpu(); the pinned-ring
+variant of round 4 is in profiles/r04_staging.log).     python tools/time_staging.py > gpurun_out/staging.log"""
 import os
 import sys
 import time
@@ -16,29 +16,17 @@ for name, shape in (("image 3x322x322", (3, 322, 322)), ("tokens 529x1536", (529
     t = torch.randn(shape)
     nb = t.numel() * 4
     reps = 20 if nb < (64 << 20) else 3
-    for label, fn in (("tensor.to(device)", lambda: t.to(dev)), ("staging.to_device", lambda: staging.to_device(t, dev))):
-        fn(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            d = fn()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        print(f"H2D {name:22s} {label:18s} {dt*1e3:9.3f} ms  {nb/dt/1e9:6.2f} GB/s", flush=True)
-    for label, fn in (("tensor.cpu()", lambda: d.cpu()), ("staging.to_host", lambda: staging.to_host(d))):
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            h = fn()
-        dt = (time.perf_counter() - t0) / reps
-        print(f"D2H {name:22s} {label:18s} {dt*1e3:9.3f} ms  {nb/dt/1e9:6.2f} GB/s", flush=True)
-    for th in (1, 4, 16):
-        staging.COPY_THREADS = th
-        staging._pool = None
-        if nb >= (64 << 20):
-            staging.to_device(t, dev); torch.cuda.synchronize()
-            t0 = time.perf_counter(); staging.to_device(t, dev); torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            print(f"H2D {name:22s} staging, {th:2d} threads {dt*1e3:9.3f} ms  {nb/dt/1e9:6.2f} GB/s", flush=True)
-    staging.COPY_THREADS = 8
-    staging._pool = None
+    d = staging.to_device(t, dev); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d = staging.to_device(t, dev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"H2D {name:22s} {dt*1e3:9.3f} ms  {nb/dt/1e9:6.2f} GB/s", flush=True)
+    staging.to_host(d)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        h = staging.to_host(d)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"D2H {name:22s} {dt*1e3:9.3f} ms  {nb/dt/1e9:6.2f} GB/s", flush=True)
     del t, d, h
