@@ -90,6 +90,7 @@ SIGNATURES = {
     "anyloc_kmeans_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "anyloc_kmeans_step": (C.c_int, [c_f32p, c_i64, c_i64, c_f32p, c_i64, C.c_int, c_f32p, c_f32p,
                                      c_i64p, C.c_void_p, c_sz, C.c_void_p]),
+    "anyloc_kmeans_update": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_f32p, C.c_void_p, C.c_void_p]),
     "anyloc_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "anyloc_topk": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i64, C.c_int, C.c_uint, c_i64, c_f32p,
                               c_i64p, C.c_void_p, c_sz, C.c_void_p]),

@@ -83,30 +83,36 @@ int launch_cfg(const H3Problem& p, const Plan& pl, hipStream_t stream) {
 
 int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// the plan table (measured on one MI355X: profiles/r04_b1_plan_sweep.log) + the option overrides
+// The plan table.  Starting point: the round-3 small-batch rules (64 x 64 two-wave tiles with four / two k-blocks per ring
+// stage while a workgroup is alone on its CU, 128 x 128 four-wave tiles from 256 such tiles up).  Up to two images (M <= 1100
+// rows) the measured winners of the plan sweeps replace them (tools/sweep_b1.py on one MI355X, ViT-G/14 322 x 322, time per
+// launch inside a B = 1 / B = 2 forward: profiles/r04_b1_plan_sweep.log, r04_b1_plan_sweep_depth.log):
+//   fc2   (K = 4096, N = 1536)  64 x 128 four-wave tiles, 6-deep ring, split-K 2     B=1: 49.9 -> 39.7 us   B=2: 68.8 -> 56.6
+//   proj  (K = 1536, N = 1536)  B=1: 64 x 64, 6-deep ring 25.0 -> 22.7 us;  B=2: 64 x 128, two k-blocks per stage 32.2 -> 29.3
+//   qkv   (N = 4608)            B=1: 128 x 128, 6-deep ring 39.1 -> 37.8 us;   B=2: 64 x 128 four-wave 56.1 -> 53.4
+//   w12   (N = 8192)            the round-3 choice stays the fastest (128 x 128 at B=1: 59 us)
+// What the sweeps say about this regime: split-K pays only for the long contraction (a split workgroup's ticket hand-off and
+// the last arrival's slab reads cost what the shorter k-loop saves at K = 1536); a deeper ring (bytes in flight) helps the
+// GEMMs with the fewest workgroups; and with the weights resident on-die (a 2-block model) the same launches are no faster
+// (profiles/r04_b1_weight_residency_probe.log) -- a one-image GEMM waits for its own fill / barrier / MFMA chain, not for HBM.
 Plan choose(const H3Problem& p, int epilogue) {
   Plan pl{0, 1, 1};
   const int64_t t64 = cdiv(p.M, 64) * cdiv(p.N, 64);
-  if (option(OPT_H3S_ENABLE) == 0) {
-    // the round-3 small-batch kernels: 64 x 64 two-wave tiles (four / two k-blocks per ring stage when a workgroup is alone
-    // on its CU), 128 x 128 from 256 such tiles up; no split-K
-    if (cdiv(p.M, 128) * cdiv(p.N, 128) >= option(OPT_H3_TINY_MAX)) return Plan{4, 1, 1};
-    return Plan{0, t64 < option(OPT_H3_DEEP_MAX) ? 4 : t64 < option(OPT_H3_DEEP2_MAX) ? 2 : 1, 1};
-  }
-  // default plans: aim at >= ~3 waves per SIMD in total, >= 16 k-blocks per split
-  const int64_t t128 = cdiv(p.M, 64) * cdiv(p.N, 128);
-  if (p.N >= 4096 && t128 >= 256) {
-    pl.cfg = 1;                                            // wide outputs (qkv, w12): 64 x 128 tiles
-    pl.ksplit = t128 < 512 && p.K16 >= 64 ? 2 : 1;
-    pl.kb = 1;
-  } else if (cdiv(p.M, 128) * cdiv(p.N, 128) >= 256) {
-    pl = Plan{4, 1, 1};
-  } else {
-    pl.cfg = 0;
-    int ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, 1024 / std::max<int64_t>(1, t64)));
-    while (ks > 1 && p.K16 / ks < 16) --ks;
-    pl.ksplit = ks;
-    pl.kb = 2;
+  if (cdiv(p.M, 128) * cdiv(p.N, 128) >= option(OPT_H3_TINY_MAX)) pl = Plan{4, 1, 1};
+  else pl = Plan{0, t64 < option(OPT_H3_DEEP_MAX) ? 4 : t64 < option(OPT_H3_DEEP2_MAX) ? 2 : 1, 1};
+  if (option(OPT_H3S_ENABLE) == 0) return pl;              // the round-3 small-batch kernels, exactly
+  if (p.M <= 1100) {
+    const bool one = p.M <= 600;                           // one 322 x 322 image (530 rows) / two
+    if (p.N <= 2048 && p.K16 >= 192) {                     // fc2-like: long contraction, narrow output
+      pl = Plan{2, 1, 2};
+      pl.stages = 6;
+    } else if (p.N <= 2048) {                              // proj-like
+      pl = one ? Plan{0, 1, 1} : Plan{2, 2, 1};
+      pl.stages = one ? 6 : 3;
+    } else if (p.N < 8192) {                               // qkv-like
+      pl = one ? Plan{4, 1, 1} : Plan{2, 1, 1};
+      pl.stages = one ? 6 : 3;
+    }
   }
   const int64_t mask = option(OPT_H3S_MASK);
   const int bit = p.kind == H3_KIND_QKV ? 1 : p.kind == H3_KIND_PROJ ? 2 : p.kind == H3_KIND_FC1 ? 4 : p.kind == H3_KIND_FC2 ? 8 : 16;

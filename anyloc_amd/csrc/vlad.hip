@@ -229,6 +229,40 @@ __global__ __launch_bounds__(64) void reduce_counts_kernel(const unsigned* __res
   if (lane == 0) counts[k] = (float)t;
 }
 
+// The rest of a fast-pytorch-kmeans iteration on the device (fpk 0.1.6 fit_predict, reached from utilities.py:766,786):
+//   c_new[k,:] = sums[k,:] / counts[k]  (an empty cluster divides 0 by 0: NaN -> 0),  err = sum((c_new - c_old)^2)
+// One workgroup: K x D is 49 152 values at the headline shape, the launch is latency, not bandwidth; the error is summed in
+// float64 in a fixed order (per thread, then a fixed tree): the same bits run to run.  The host reads back 8 bytes.
+__global__ __launch_bounds__(1024) void kmeans_update_kernel(const float* __restrict__ sums, const float* __restrict__ counts,
+                                                             const float* __restrict__ c_old, int K, int D,
+                                                             float* __restrict__ c_new, double* __restrict__ err) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double e = 0.0;
+  const int64_t n = (int64_t)K * D;
+  for (int64_t i = tid; i < n; i += 1024) {
+    const int k = (int)(i / D);
+    float v = sums[i] / counts[k];
+    if (!(v == v)) v = 0.0f;                              // fpk: c_grad[c_grad != c_grad] = 0
+    const float d = v - c_old[i];
+    e += (double)(d * d);                                 // (the square in fp32, as torch computes (c_grad - c) ** 2)
+    c_new[i] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long u = __double_as_longlong(e);
+    const unsigned lo = __shfl_xor((unsigned)u, o, 64), hi = __shfl_xor((unsigned)(u >> 32), o, 64);
+    e += __longlong_as_double(((unsigned long long)hi << 32) | lo);
+  }
+  if (lane == 0) red[wave] = e;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *err = t;
+  }
+}
+
 // soft assignment weights: w[n,k] = softmax_k(temp * cos(x_n, c_k)),  F.cosine_similarity eps 1e-8:
 //   cos = x.c / (max(||x||,eps) * max(||c||,eps));  scores hold x_n . c_k (raw centres)
 __global__ __launch_bounds__(256) void soft_weights_kernel(float* __restrict__ scores, int kpad, int K,
@@ -665,6 +699,16 @@ size_t anyloc_kmeans_workspace_bytes(int64_t n, int64_t D, int64_t K) {
   b += align_up((size_t)(chunks > 0 ? chunks : 1) * K * D * sizeof(float), 256);
   b += align_up((size_t)(chunks > 0 ? chunks : 1) * K * sizeof(unsigned), 256);
   return b + 256;
+}
+
+int anyloc_kmeans_update(const float* sums, const float* counts, const float* centers_old, int64_t K, int64_t D,
+                         float* centers_new, double* err, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(sums && counts && centers_old && centers_new && err, "kmeans_update: null pointer");
+  ANYLOC_CHECK_ARG(K >= 1 && D >= 1 && K * D < (1ll << 31), "kmeans_update: bad shape");
+  ProfScope prof("kmeans_update", stream, 3.0 * K * D, 12.0 * K * D);
+  hipLaunchKernelGGL(kmeans_update_kernel, dim3(1), dim3(1024), 0, stream, sums, counts, centers_old, (int)K, (int)D, centers_new, err);
+  return launch_status("kmeans_update_kernel");
 }
 
 int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* centers, int64_t K, int mode, float* sums,

@@ -890,23 +890,34 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     // 61 images x 4 parts
     const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(a.part_buf + unit * a.parts * kd), 0, (int)imin64((int64_t)a.parts * kd * 4, 0x7fffffff), 0x00020000);
-    static_for<32>([&](auto k) {
-      if (k < a.K) {
-        float sum[CW];
-        static_for<CW>([&](auto j) { sum[(int)j] = 0.f; });
-        for (int q0 = 0; q0 < a.parts; q0 += 8) {
-          float pv[8][CW];
+    // (four clusters x up to eight parts = 32 CW-wide loads per lane in flight: one workgroup pulls the parts x K x D x 4 bytes
+    // -- 784 KB at 61 images -- through its CU's load path, so what counts is how many requests are outstanding)
+    static_for<8>([&](auto kg) {
+      constexpr int k0 = 4 * decltype(kg)::value;
+      float sum[4][CW];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+        for (int j = 0; j < CW; ++j) sum[c4][j] = 0.f;
+      for (int q0 = 0; q0 < a.parts; q0 += 8) {              // (more than 8 parts only through option vlad_parts)
+        float pv[4][8][CW];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (q0 + q < a.parts) f3_load_cols<CW>(q_rsrc, col_off, (unsigned)(((q0 + q) * kd + (int)k * D) * 4), pv[q]);
+            if (k0 + c4 < a.K && q0 + q < a.parts)
+              f3_load_cols<CW>(q_rsrc, col_off, (unsigned)(((q0 + q) * kd + (k0 + c4) * D) * 4), pv[c4][q]);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (q0 + q < a.parts) static_for<CW>([&](auto j) { sum[(int)j] += pv[q][(int)j]; });
-        }
-        static_for<CW>([&](auto j) { acc[j][(int)k] = sum[(int)j]; });
-      } else {
-        static_for<CW>([&](auto j) { acc[j][(int)k] = 0.f; });
+            if (k0 + c4 < a.K && q0 + q < a.parts)
+#pragma unroll
+              for (int j = 0; j < CW; ++j) sum[c4][j] += pv[c4][q][j];
       }
+      static_for<4>([&](auto c4) {
+        static_for<CW>([&](auto j) { acc[j][k0 + (int)c4] = sum[(int)c4][(int)j]; });
+      });
     });
   }
   // intra-norm of each cluster block (its columns are spread over the SW waves), then the global norm
@@ -1006,10 +1017,10 @@ int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t strea
   if (units <= 0) return ANYLOC_OK;
   ANYLOC_CHECK_ARG(units < (1ll << 31), "vlad_fused: too many units");
   // options kmeans_fused_v / vlad_fused_v (A/B, tests): 0 (default) = fused3_kernel -- 8 waves where D / 128 is even, 4 waves
-  // otherwise; VLAD with more than two workgroups per image stays on vlad_fused_kernel (its hand-off epilogue is cheaper);
+  // otherwise -- at every parts count (round 4: with the CW-wide hand-off 0.135 vs 0.154 ms at 61 images x 4 parts);
   // 1 = vlad_fused_kernel (both modes), 3 = fused3 with 4 waves, 4 = fused3 with 8
   const int ver = (int)option(kmeans ? OPT_KMEANS_FUSED_V : OPT_VLAD_FUSED_V);
-  const bool f3 = ver == 0 ? (kmeans || a.parts <= 2) : ver >= 3;
+  const bool f3 = ver == 0 ? true : ver >= 3;
 #define ANYLOC_FUSED_CASE(NV)                                                                         \
   case NV * 128:                                                                                      \
     if (f3) {                                                                                         \

@@ -113,9 +113,13 @@ class KMeans:
         for it in range(self.max_iter):
             sums, counts, labels = self._step(x, c, self.mode, True)
             self._all_reduce(sums, counts)
-            c_new = sums / counts[:, None]
-            c_new = torch.where(counts[:, None] > 0, c_new, torch.zeros_like(c_new))
-            err = ((c_new - c) ** 2).sum()
+            if self._step is _local_step:
+                # one launch: division, empty cluster -> 0, convergence error (float64); 8 bytes come back
+                c_new, err = ops.kmeans_update(sums, counts, c)
+            else:                                     # injected step (CPU tests of the host logic)
+                c_new = sums / counts[:, None]
+                c_new = torch.where(counts[:, None] > 0, c_new, torch.zeros_like(c_new))
+                err = ((c_new - c) ** 2).sum()
             c = c_new
             self.n_iter_ = it + 1
             if self.verbose:

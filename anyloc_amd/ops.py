@@ -329,6 +329,19 @@ def kmeans_step(x, centers, mode="cosine", want_labels=False):
     return sums, counts, labels
 
 
+def kmeans_update(sums, counts, centers_old):
+    """-> (centers_new [K,D], err float64 device scalar): sums / counts with empty clusters -> 0, and the fpk convergence
+    error sum((new - old)^2), in one launch."""
+    _need_cuda(sums, counts, centers_old)
+    sums, counts, centers_old = _f32c(sums), _f32c(counts), _f32c(centers_old)
+    K, D = sums.shape
+    new = torch.empty_like(sums)
+    err = torch.empty(1, dtype=torch.float64, device=sums.device)
+    _lib.check(_lib.load().anyloc_kmeans_update(_lib.ptr(sums), _lib.ptr(counts), _lib.ptr(centers_old), K, D, _lib.ptr(new),
+                                                _lib.ptr(err), _lib.stream_ptr()), "anyloc_kmeans_update")
+    return new, err
+
+
 TOPK_NORMALIZE_DB = 1
 
 

@@ -260,6 +260,13 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
                        int64_t* labels, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* The rest of the iteration (ABI 5): centers_new[k,:] = sums[k,:] / counts[k] (empty cluster: 0 / 0 = NaN -> 0, fpk's
+ * rule), *err = sum((centers_new - centers_old)^2) as float64 -- the quantity fpk compares with its tolerance
+ * (utilities.py:766,786 -> fast_pytorch_kmeans fit_predict).  With several GPUs the host all-reduces sums / counts between
+ * anyloc_kmeans_step and this call.  All pointers device; centers_new may not alias centers_old. */
+int anyloc_kmeans_update(const float* sums, const float* counts, const float* centers_old, int64_t K, int64_t D,
+                         float* centers_new, double* err, void* stream);
+
 /* -------------------------------------------------------------- top-k ----
  * Exact brute-force search of `nq` queries against `ndb` database rows.
  * replaces: faiss IndexFlatIP / IndexFlatL2 add + search,

@@ -64,6 +64,11 @@ def install(monkeypatch):
         onehot = (lab[None, :] == torch.arange(c.shape[0])[:, None]).to(x.dtype)
         return onehot @ x, onehot.sum(-1), lab
 
+    def kmeans_update(sums, counts, c_old):
+        c_new = sums / counts[:, None]
+        c_new[c_new != c_new] = 0
+        return c_new, ((c_new - c_old) ** 2).sum().double().reshape(1)
+
     def pool(tokens, method="average", gem_p=3.0):
         if method not in ops.POOL_MODES:
             raise NotImplementedError(f"ID: {method}")
@@ -106,6 +111,7 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "_f32c", lambda t, device=None: t.detach().to("cpu", torch.float32).contiguous())
     monkeypatch.setattr(ops, "vlad", vlad)
     monkeypatch.setattr(ops, "kmeans_step", kmeans_step)
+    monkeypatch.setattr(ops, "kmeans_update", kmeans_update)
     monkeypatch.setattr(kmeans, "_local_step", kmeans_step)
     monkeypatch.setattr(ops, "topk", lambda q, db, k, metric="ip", index_base=0, normalize_db=False:
                         faiss_flat.flat_search(q.float(), F.normalize(db.float(), dim=-1) if normalize_db else db.float(),
