@@ -78,7 +78,8 @@ enum Option {
   OPT_H3_MFMA16,         // gemm_h3: 1 = large GEMMs on the 16x16x32 MFMA kernel (gemm_h3m.hip) where it has the epilogue
   OPT_H3_SWIGLU_T,       // Python host: build the SwiGLU fc1 image in the 16-channel block layout (transposed-accumulator epilogue)
   OPT_H3_FAST_SILU,      // fused SwiGLU epilogue of the h3 w12 GEMM: SiLU on v_exp_f32 + v_rcp_f32 instead of expf + IEEE division
-  OPT_TOPK_FEWQ_X6,      // few-query retrieval scores: 1 = database split on the fly into bf16 planes (scores_x6.hip), 0 = fp32 MFMA
+  OPT_TOPK_FEWQ_X6,      // few-query retrieval scores: 2 = two fp16 planes under a running row scale (scores_h3.hip), 1 = three bf16
+                         // planes (scores_x6.hip), 0 = fp32 MFMA
   OPT_TOPK_H3,           // retrieval score panels on the two-term fp16 GEMM: -1 = where it pays, 0 = never, 1 = wherever possible
   // small-M plans of the two-term fp16 GEMM (gemm_h3s.hip): overrides of the built-in plan table for sweeps / A-B runs
   OPT_H3S_CFG,           // tile configuration id (-1 = the plan table)
@@ -180,6 +181,10 @@ int gemm_nt_splitk(const GemmProblem& p, hipStream_t stream);
 // part[s][row][0..63] and rsq_part[s][row] for K slices s < ksplit of length kslice (scores_x6.hip)
 int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice,
                    int ksplit, float* part, float* rsq_part, hipStream_t stream);
+// the same pass on two fp16 planes under a running power-of-two row scale: three fp16 MFMA products (scores_h3.hip); qinv[nq] =
+// 2^-e of the query rows (row_scales_h2)
+int scores_fewq_h3(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, const float* qinv,
+                   int64_t kslice, int ksplit, float* part, float* rsq_part, hipStream_t stream);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {
@@ -245,6 +250,8 @@ int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, flo
 // rows of any width (K % 16 == 0; used above 4096 columns): also returns the rows' sums of squares when row_sumsq != nullptr
 int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, float* row_sumsq,
                   hipStream_t stream);
+// the first half of it alone: inv_scale[row] = 2^-e of the row-scaled split (and the rows' sums of squares when asked)
+int row_scales_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, float* inv_scale, float* row_sumsq, hipStream_t stream);
 // bound (HOST array of 4 floats) != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
 // (Cauchy-Schwarz: |fc1 output| <= ||ln(x)||_2 * max_j ||W_j||_2 + max |b|), bound = {gate_norm, gate_bias, val_norm, val_bias}
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,

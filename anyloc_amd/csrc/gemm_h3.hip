@@ -436,6 +436,14 @@ int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2
   return launch_status("split_h2_wide_kernel");
 }
 
+int row_scales_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, float* inv_scale, float* row_sumsq, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(x && inv_scale && rows > 0 && K > 0 && ldx >= K && K % 4 == 0 && ldx % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && rows < (1ll << 31),
+                   "row_scales_h2: bad arguments");
+  hipLaunchKernelGGL(row_amax_sq_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ldx, K, inv_scale, row_sumsq);
+  return launch_status("row_amax_sq_kernel");
+}
+
 int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, hipStream_t stream) {
   ANYLOC_CHECK_ARG(x && h2 && inv_scale && rows > 0 && K > 0 && ldx >= K, "split_h2: bad arguments");
   ANYLOC_CHECK_ARG(K % 16 == 0 && ldx % 4 == 0, "split_h2: K must be a multiple of 16 (got %lld)", (long long)K);

@@ -152,3 +152,71 @@ def test_bench_config3_eight_ranks_on_one_gpu():
     assert out["n_gpus"] == 8 and out["unit"] == "queries/s" and out["value"] > 0
     assert out["planted_neighbours_found"] is True
     assert out["config"]["db_rows_total"] == 8 * 2048 and out["config"]["queries"] == 512
+
+
+# ---------------------------------------------------------------------------------- few-query scores, running row scale
+def _check_vs_float64(d, i, qu, db, k, metric, norm, tol=3e-6):
+    """(dist, idx) of ops.topk against the exact float64 search on the device: tie-aware index identity, distance error."""
+    q64, d64 = qu.double(), db.double()
+    if norm:
+        q64, d64 = torch.nn.functional.normalize(q64, dim=1), torch.nn.functional.normalize(d64, dim=1)
+    if metric == "ip":
+        sc = q64 @ d64.T
+        order = torch.sort(-sc, dim=1, stable=True)[1][:, :k]
+    else:
+        sc = (q64 * q64).sum(1)[:, None] + (d64 * d64).sum(1)[None] - 2 * q64 @ d64.T
+        order = torch.sort(sc, dim=1, stable=True)[1][:, :k]
+    got, want = torch.gather(sc, 1, i), torch.gather(sc, 1, order)
+    scale = float(sc.abs().max()) if not norm else 1.0
+    assert int(((i != order) & ((got - want).abs() > tol * scale)).sum()) == 0
+    assert float((d.double() - got).abs().max()) <= tol * scale, float((d.double() - got).abs().max())
+
+
+@pytest.mark.parametrize("metric,norm", [("ip", True), ("ip", False), ("l2", True), ("l2", False)])
+def test_topk_few_queries_two_fp16_planes_running_scale(metric, norm):
+    """Option topk_fewq_x6 = 2 (csrc/scores_h3.hip): <= 64 queries, database rows split on the fly into two fp16 planes under a
+    power-of-two scale that RUNS along each row -- ragged row tail, 61 and 3 queries, row norms from the same pass; rows
+    whose magnitude grows along K (a new maximum, i.e. a rescale of the accumulators, in most slabs), rows with one late
+    spike, all-zero and tiny rows.  Against float64, and reproducible run to run."""
+    from anyloc_amd import ops
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    dim, ndb = 8192, 10037
+    scale = 0.05 + torch.rand(ndb, 1, generator=g, device=DEV) * 20.0
+    db = torch.randn(ndb, dim, generator=g, device=DEV) * scale
+    ramp = torch.exp2(torch.arange(dim, device=DEV) / dim * 12.0)              # magnitudes grow 4096 x along the row
+    db[100:164] *= ramp
+    db[200:232, 7000] = 5e3                                                     # one late spike
+    db[300:310] = 0.0
+    db[320:330] *= 1e-30
+    db[5000] = db[12]
+    for nq, k in ((61, 20), (3, 7)):
+        qu = torch.randn(nq, dim, generator=g, device=DEV)
+        pick = torch.arange(min(nq, 30), device=DEV) * 301 + 12
+        qu[: len(pick)] = db[pick] + 0.3 * scale[pick] * torch.randn(len(pick), dim, generator=g, device=DEV)
+        qu[-1] = db[130]                                                        # a ramp row as the query
+        qd = torch.nn.functional.normalize(qu) if norm else qu
+        with ops.options(topk_fewq_x6=2):
+            d, i = ops.topk(qd, db, k, metric, normalize_db=norm)
+            d1, i1 = ops.topk(qd, db, k, metric, normalize_db=norm)
+        assert torch.equal(i, i1) and torch.equal(d, d1)
+        _check_vs_float64(d, i, qu, db, k, metric, norm)
+        assert int(i[0, 0]) == 12 and int(i[0, 1]) == 5000                      # the duplicated row: lower index first
+        with ops.options(topk_fewq_x6=1):
+            d0, i0 = ops.topk(qd, db, k, metric, normalize_db=norm)
+        assert float((i0 != i).float().mean()) < 0.003
+
+
+def test_topk_few_queries_running_scale_self_match_long_rows():
+    """131 072 columns (the ViT-L two-tap VLAD), queries that ARE database rows, all-positive rows: every product is a
+    square, whatever is dropped adds up.  Cosine 1 to 2e-6 and the exact top-5."""
+    from anyloc_amd import ops
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    dim, ndb, nq = 131072, 260, 8
+    db = torch.nn.functional.normalize(torch.randn(ndb, dim, generator=g, device=DEV).abs() + 0.5, dim=1) * 2.5
+    qu = db[:nq].clone()
+    with ops.options(topk_fewq_x6=2):
+        d, i = ops.topk(torch.nn.functional.normalize(qu), db, 5, "ip", normalize_db=True)
+    assert torch.equal(i[:, 0].cpu(), torch.arange(nq))
+    _check_vs_float64(d, i, qu, db, 5, "ip", True, tol=2e-6)
