@@ -71,7 +71,9 @@ const char* anyloc_last_error(void);
  *   h3_swiglu_t (1)                   read by the Python host when a model is built: SwiGLU fc1 image in the 16-channel block
  *                                     layout (anyloc_vit_block_h2.fc1_layout = 1: epilogue straight from transposed accumulators)
  *   h3_fast_silu (1)                  fused SwiGLU epilogue: SiLU on the hardware exp2 / rcp (1 ulp each)
- *   topk_fewq_x6 (1)                  anyloc_topk with <= 64 queries: database rows split on the fly into bf16 planes (HBM-bound); 0 = fp32 MFMA
+ *   topk_fewq_x6 (2)                  anyloc_topk with <= 64 queries, the database read once and split on the fly: 2 = two fp16 planes
+ *                                     under a running power-of-two row scale (three fp16 MFMA products, csrc/scores_h3.hip),
+ *                                     1 = three bf16 planes (six bf16 products, csrc/scores_x6.hip), 0 = fp32 MFMA
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
  *   h3s_enable (1)                    small-M plans of the two-term fp16 GEMM (csrc/gemm_h3s.hip: tile shape, ring depth and split-K
  *                                     factor per GEMM shape when a call has one or a few images); 0 = the round-3 small-batch kernels

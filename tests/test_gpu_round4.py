@@ -201,7 +201,8 @@ def test_topk_few_queries_two_fp16_planes_running_scale(metric, norm):
             d1, i1 = ops.topk(qd, db, k, metric, normalize_db=norm)
         assert torch.equal(i, i1) and torch.equal(d, d1)
         _check_vs_float64(d, i, qu, db, k, metric, norm)
-        assert int(i[0, 0]) == 12 and int(i[0, 1]) == 5000                      # the duplicated row: lower index first
+        if norm or metric == "l2":                                              # (the raw inner product prefers the huge ramp rows)
+            assert int(i[0, 0]) == 12 and int(i[0, 1]) == 5000                  # the duplicated row: lower index first
         with ops.options(topk_fewq_x6=1):
             d0, i0 = ops.topk(qd, db, k, metric, normalize_db=norm)
         assert float((i0 != i).float().mean()) < 0.003
