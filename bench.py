@@ -72,12 +72,12 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
                        ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
                       if split else "fp32 MFMA peak"),
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "clock_note": ("profiles/r02_pmc_fused_sq_raw.md + r02_pmc_fused_write_raw.md (h3) / r01_pmc_x6.md (x6): under these GEMMs "
-                       "the chip runs at its power limit -- 1.57 GHz with the matrix cores busy 76.6 % of all SIMD cycles for "
-                       "the h3 w12 kernel (1.65 GHz / 83.6 % for x6); `peak` is the nominal 2.4 GHz figure.  Calibration "
-                       "(profiles/r02_calib_h3_hipblaslt_zero_data.log): the same h3 kernel runs 39 % faster on all-zero operands, "
-                       "and hipBLASLt's fp16 GEMM sustains 1.04-1.43 PFLOP/s on these shapes on random data (this kernel: 1.15-1.24 "
-                       "PFLOP/s of fp16 MFMA work = 3 x achieved)") if split else None,
+        "clock_note": ("profiles/r03_pmc_h3_sq_raw.md + r03_pmc_h3_write_raw.md (h3; re-measured in round 4: r04_pmc_sq.md) / "
+                       "r01_pmc_x6.md (x6): under these GEMMs the chip runs at its power limit -- ~1.49 GHz under the profiler "
+                       "with the matrix cores busy ~82 % of all SIMD cycles for the h3 w12 kernel (1.65 GHz / 83.6 % for x6); "
+                       "`peak` is the nominal 2.4 GHz figure.  Calibration (profiles/r03_calib_h3_hipblaslt_warm.log): the same "
+                       "h3 kernel runs 39 % faster on all-zero operands, and hipBLASLt's fp16 GEMM sustains 1.19-1.42 PFLOP/s "
+                       "on these shapes on random data (this kernel: 1.14-1.28 PFLOP/s of fp16 MFMA work = 3 x achieved)") if split else None,
         # what the matrix cores SUSTAIN inside the chip's power limit on random operands, from registers, with no LDS or HBM
         # traffic at all (tools/micro/mfma_power.hip, profiles/r03_mfma_shape_power.log: 1 700-1 718 TFLOP/s for the 32x32x16
         # fp16 instruction this kernel uses; 2 424 on all-zero operands) -- `peak` above stays the guide's nominal figure
