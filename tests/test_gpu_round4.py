@@ -221,3 +221,29 @@ def test_topk_few_queries_running_scale_self_match_long_rows():
         d, i = ops.topk(torch.nn.functional.normalize(qu), db, 5, "ip", normalize_db=True)
     assert torch.equal(i[:, 0].cpu(), torch.arange(nq))
     _check_vs_float64(d, i, qu, db, 5, "ip", True, tol=2e-6)
+
+
+def test_reference_script_call_pattern_stage_on_a_small_model():
+    """bench.py's `script_path_vitg` stage -- per image ``ext(img[None].to(device)).cpu()``, ``VLAD.generate_multi`` on the CPU
+    tensor, ``get_top_k_recall`` on CPU tensors (scripts/dino_v2_vlad.py:164-188, :236-260, :372) -- on ViT-S/14 at 224 x 224:
+    the stage's own check against the batched device path must hold (tokens, cluster ids, VLADs, top-1)."""
+    import bench
+    import utilities
+    from anyloc_amd import synth, weights
+    name = "dinov2_vits14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 2, device=DEV, depth=10))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 9, "value", device=DEV)
+        db_img, qu_img, gt = synth.synthetic_places(24, 24, 224, 224, seed=3, device=DEV)
+        vlad = utilities.VLAD(8, None, cache_dir=None)
+        tok = ext(db_img)
+        np.random.seed(3)
+        vlad.fit(tok.reshape(-1, tok.shape[-1]))
+        db = torch.nn.functional.normalize(torch.randn(400, 8 * 384, generator=torch.Generator().manual_seed(1)), dim=1).to(DEV)
+        db[:24] = vlad.generate_multi(tok)
+        res = bench.stage_script_path(ext, vlad, db, qu_img, gt, n_img=24)
+        assert res["oracle_ok"], res
+        assert res["vs_batched_device_path"]["cpu_tensor_path_bitwise_equals_device_call"]
+        assert res["images_per_s"] > 0
+    finally:
+        weights.unregister_state_dict(name)
