@@ -88,7 +88,6 @@ enum Option {
   OPT_H3S_STAGES,        // ring depth: 3 or 6 (0 = the plan table)
   OPT_H3S_MASK,          // which GEMMs the three overrides apply to: bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 others
   OPT_H3S_ENABLE,        // 1 = small-M plans (default), 0 = the round-3 small-batch kernels (64x64 two-wave tiles, no split-K)
-  OPT_H3S_CONSUMER,      // 1 = one / two images: proj and fc2 leave split-K slabs, the LayerNorm behind them reduces (vit.hip)
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -228,10 +227,6 @@ struct H3Problem {
   int ksplit, kper;
   float* sk_part; unsigned* sk_tickets;
   int kind;                                 // which block GEMM this is (H3_KIND_*: plan table / option h3s_mask); 0 = other
-  // split-K with the reduction in the CONSUMER (EPI_STORE only, small-M plans): sk_consumer = 1 -> split s stores its scaled
-  // accumulators (no bias) row-major into C + s * sk_cstride and nobody reduces in this launch; the caller's next kernel
-  // (layernorm_h2 with an LnReduce) sums the slabs in split order.  *sk_used (host) receives the split count of the launch.
-  int sk_consumer; int64_t sk_cstride; int* sk_used;
   // EPI_QKV_PLANES: N = 3 * heads * 64; see QkvPlanes below
   unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
   // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])
@@ -259,17 +254,8 @@ int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2
 int row_scales_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, float* inv_scale, float* row_sumsq, hipStream_t stream);
 // bound (HOST array of 4 floats) != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
 // (Cauchy-Schwarz: |fc1 output| <= ||ln(x)||_2 * max_j ||W_j||_2 + max |b|), bound = {gate_norm, gate_bias, val_norm, val_bias}
-// reduce: the rows are first completed from the split-K slabs of the GEMM in front (few rows only: the single-wave kernel):
-//   x[row,:] += gamma * (sum_s part[s * stride + row * dim + :] + bias)   (slabs summed in split order; x updated in place)
-// ln = 0: only that (no LayerNorm, no image) -- the flush in front of a consumer that needs the fp32 rows
-struct LnReduce {
-  const float* part; int nsplit; int64_t stride;
-  const float* bias; const float* gamma;
-  int ln;
-};
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
-                 float* inv_scale, hipStream_t stream, const float* bound = nullptr, float* bound_inv = nullptr,
-                 const LnReduce* reduce = nullptr);
+                 float* inv_scale, hipStream_t stream, const float* bound = nullptr, float* bound_inv = nullptr);
 // attention on the tiles of EPI_QKV_PLANES; writes the h2 image (+ per-row 2^-e) the projection GEMM reads
 int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, int T, int D, int heads,
                  unsigned char* out2, float* out_inv, hipStream_t stream);

@@ -317,50 +317,21 @@ template <int NV>
 __global__ __launch_bounds__(64) void layernorm_h2_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, int dim, int64_t rows, float eps,
                                                                  unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
-                                                                 const f32x4 bound4, float* __restrict__ bound_inv, const LnReduce rd) {
+                                                                 const f32x4 bound4, float* __restrict__ bound_inv) {
   const int lane = threadIdx.x;
   const int n4 = dim >> 2;
   const int64_t row = blockIdx.x;
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
   f32x4 v[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < n4) v[i] = xr[lane + 64 * i];
-  if (rd.part) {
-    // the rows of the GEMM in front arrive as split-K slabs (gemm_h3s.hip, sk_consumer): x += gamma * (sum_s slab_s + bias),
-    // slabs added in split order -- the LayerScale-residual epilogue of that GEMM, moved here, where the row is read anyway
-    f32x4 acc[NV];
-    const f32x4* pr = reinterpret_cast<const f32x4*>(rd.part + row * dim);
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < n4) acc[i] = pr[lane + 64 * i];
-    for (int sp = 1; sp < rd.nsplit; ++sp) {
-      const f32x4* ps = reinterpret_cast<const f32x4*>(rd.part + sp * rd.stride + row * dim);
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < n4) {
-          const f32x4 t = ps[lane + 64 * i];
-          acc[i][0] += t[0]; acc[i][1] += t[1]; acc[i][2] += t[2]; acc[i][3] += t[3];
-        }
-    }
-    f32x4* xw = reinterpret_cast<f32x4*>(const_cast<float*>(x) + row * dim);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < n4) {
-        const f32x4 g = reinterpret_cast<const f32x4*>(rd.gamma)[idx];
-        const f32x4 bb = rd.bias ? reinterpret_cast<const f32x4*>(rd.bias)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] = v[i][j] + (acc[i][j] + bb[j]) * g[j];
-        xw[idx] = v[i];
-      }
-    }
-    if (!rd.ln) return;
-  }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < n4) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      v[i] = xr[idx];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
   const float mean = wave_sum(s) / (float)dim;
   float qs = 0.f;
 #pragma unroll
@@ -494,11 +465,8 @@ int split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, flo
 }
 
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
-                 float* inv_scale, hipStream_t stream, const float* bound, float* bound_inv, const LnReduce* reduce) {
+                 float* inv_scale, hipStream_t stream, const float* bound, float* bound_inv) {
   ANYLOC_CHECK_ARG(dim % 16 == 0 && dim <= 2048, "layernorm_h2: dim %d (needs a multiple of 16, at most 2048)", dim);
-  LnReduce rd{};
-  if (reduce) rd = *reduce;
-  ANYLOC_CHECK_ARG(!rd.part || (rd.nsplit >= 1 && rd.gamma && rows < (1ll << 31)), "layernorm_h2: bad reduce arguments");
   ProfScope prof("layernorm_h2", stream, 8.0 * rows * dim, 8.0 * rows * dim);
   unsigned char* out = static_cast<unsigned char*>(h2);
   const int nv = (dim / 4 + 63) / 64;
@@ -509,12 +477,12 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   // was the round-2 kernel, one row per wave at this size 11.4 ms -- profiles/r03_ab_attn_kbatch_ln_rpw.log).  Option
   // ln_rows_per_wave (0 = that rule) forces 1, 2 or 4 at every size (A/B; same per-row arithmetic, same bits)
   const int64_t forced = option(OPT_LN_ROWS_PER_WAVE);
-  if (rd.part || (forced == 0 && rows < option(OPT_LN_DIRECT_ROWS))) {
+  if (forced == 0 && rows < option(OPT_LN_DIRECT_ROWS)) {
     // a few hundred rows: one single-wave workgroup per row, image written straight from registers
     const dim3 grid((unsigned)rows);
 #define ANYLOC_LN_H2_D(NVV)                                                                                              \
   hipLaunchKernelGGL((layernorm_h2_direct_kernel<NVV>), grid, dim3(64), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
-                     rows, b4, bound ? bound_inv : nullptr, rd)
+                     rows, b4, bound ? bound_inv : nullptr)
     if (nv <= 1) ANYLOC_LN_H2_D(1);
     else if (nv <= 2) ANYLOC_LN_H2_D(2);
     else if (nv <= 3) ANYLOC_LN_H2_D(3);

@@ -179,10 +179,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if (p.ksplit > 1 && p.sk_consumer) {
-    // the consumer reduces (layernorm_h2 with an LnReduce): this split's scaled accumulators go, row-major, to slab `split`
-    if constexpr (EPI == EPI_STORE) p.C += (int64_t)split * p.sk_cstride;
-  } else if (p.ksplit > 1) {
+  if (p.ksplit > 1) {
     // Partial accumulators -> workspace in register order, 16 bytes per lane (whole 1-KiB runs per instruction), as
     // WRITE-THROUGH (sc1) stores: they reach the device-coherent level themselves, so no release fence -- an agent-scope
     // release is an L2 write-back, and one per workgroup made a split GEMM 3-4 x SLOWER than the unsplit one

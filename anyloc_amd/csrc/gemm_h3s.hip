@@ -142,18 +142,10 @@ int gemm_h3_small(const H3Problem& p_in, int epilogue, hipStream_t stream) {
   // the epilogues that write q|k|v tiles need whole heads per wave column block: NI even (all configurations have it)
   // split-K needs the workspace, a plain (non-accumulating) epilogue input and enough k-blocks
   const int64_t tiles = cdiv(p.M, kCfgBM[pl.cfg]) * cdiv(p.N, kCfgBN[pl.cfg]);
-  if (p.sk_consumer) {
-    // partial slabs for the consumer: more, shorter splits pay here -- a split workgroup ends with plain stores (no ticket,
-    // no slab reads, no epilogue); proj: 64 x 64 tiles, three splits; fc2: 64 x 128 four-wave tiles, four splits
-    // (tools/sweep_b1.py, profiles/r04_b1_consumer_splitk.log)
-    if (epilogue != EPI_STORE || p.accumulate || !p.C) pl.ksplit = 1;
-    else if (option(OPT_H3S_KSPLIT) <= 0 || !(option(OPT_H3S_MASK) & (p.kind == H3_KIND_PROJ ? 2 : p.kind == H3_KIND_FC2 ? 8 : 16)))
-      pl.ksplit = p.K16 >= 192 ? 4 : 3;
-  } else if (!p.sk_part || !p.sk_tickets || p.accumulate) pl.ksplit = 1;
+  if (!p.sk_part || !p.sk_tickets || p.accumulate) pl.ksplit = 1;
   pl.ksplit = (int)std::min<int64_t>(pl.ksplit, p.K16);
-  while (pl.ksplit > 1 && (p.sk_consumer ? (size_t)pl.ksplit * (size_t)p.sk_cstride * sizeof(float) > H3_SPLIT_PART_BYTES
-                                         : ((size_t)pl.ksplit * tiles * kCfgBM[pl.cfg] * kCfgBN[pl.cfg] * sizeof(float) > H3_SPLIT_PART_BYTES ||
-                                            tiles > (int64_t)H3_SPLIT_TICKETS)))
+  while (pl.ksplit > 1 && ((size_t)pl.ksplit * tiles * kCfgBM[pl.cfg] * kCfgBN[pl.cfg] * sizeof(float) > H3_SPLIT_PART_BYTES ||
+                           tiles > (int64_t)H3_SPLIT_TICKETS))
     --pl.ksplit;
   p.ksplit = pl.ksplit;
   // k-blocks per split: a multiple of the ring stage's k-blocks, so that only the LAST split can end inside a stage
@@ -165,7 +157,6 @@ int gemm_h3_small(const H3Problem& p_in, int epilogue, hipStream_t stream) {
   } else {
     p.kper = p.K16;
   }
-  if (p.sk_used) *p.sk_used = p.ksplit;
   switch (epilogue) {
     case EPI_STORE: return launch_cfg<EPI_STORE>(p, pl, stream);
     case EPI_LS_RESID: return launch_cfg<EPI_LS_RESID>(p, pl, stream);

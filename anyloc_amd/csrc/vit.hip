@@ -289,42 +289,6 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   const int norm_taps = (flags & ANYLOC_VIT_NORM_TAPS) ? 1 : 0;
   const int last_layer = tap_layers[n_taps - 1];
   if (h3m) ANYLOC_HIP(hipMemsetAsync(w.sk_tickets, 0, H3_SPLIT_TICKETS * sizeof(unsigned), stream));   // split-K arrival counters
-  // One or two images per call (fp16 mode, fused data flow): the projection and fc2 GEMMs leave their result as split-K SLABS
-  // (gemm_h3s.hip, sk_consumer) and the LayerNorm that follows anyway completes the rows -- x += gamma (sum of slabs + bias),
-  // the LayerScale-residual epilogue moved into the kernel that reads the row next -- before it normalises them.  A split
-  // workgroup then ends with plain stores: no ticket, no slab reads, no read-modify-write of x, and the contraction of the
-  // two GEMMs with the fewest workgroups is cut three / four ways (option h3s_consumer = 0: the in-GEMM epilogues).
-  const bool slab_mode = h3f && option(OPT_H3S_ENABLE) != 0 && option(OPT_H3S_CONSUMER) != 0 && M < option(OPT_LN_DIRECT_ROWS) &&
-                         (size_t)M * D * sizeof(float) * 2 <= H3_SPLIT_PART_BYTES;
-  LnReduce pending{};                                      // pending.part != nullptr: the rows of w.x wait for their slabs
-  auto take_pending = [&](LnReduce& r) -> const LnReduce* {
-    if (!pending.part) return nullptr;
-    r = pending;
-    pending = LnReduce{};
-    return &r;
-  };
-  auto flush_pending = [&]() -> int {                       // somebody needs the fp32 rows and no LayerNorm comes first
-    LnReduce r;
-    if (!take_pending(r)) return ANYLOC_OK;
-    r.ln = 0;
-    return layernorm_h2(w.x, nullptr, nullptr, M, D, 1e-6f, nullptr, nullptr, stream, nullptr, nullptr, &r);
-  };
-  auto slab_gemm = [&](const unsigned char* a2, const float* ainv, int64_t K, const void* w2, const float* winv, const float* bias,
-                       const float* gamma, int kind, const char* tag) -> int {
-    H3Problem g{};
-    g.A2 = a2; g.RA = M; g.a_inv = ainv;
-    g.W2 = static_cast<const unsigned char*>(w2); g.RW = D; g.w_inv = winv;
-    g.C = w.sk_part; g.ldc = D; g.M = M; g.N = D; g.K16 = (int)(K / 16);
-    g.sk_part = w.sk_part; g.sk_tickets = w.sk_tickets;
-    g.sk_consumer = 1; g.sk_cstride = M * (int64_t)D;
-    int used = 1;
-    g.sk_used = &used;
-    g.kind = kind; g.tag = tag;
-    ANYLOC_TRY(gemm_h3(g, EPI_STORE, stream));
-    pending.part = w.sk_part; pending.nsplit = used; pending.stride = M * (int64_t)D;
-    pending.bias = bias; pending.gamma = gamma; pending.ln = 1;
-    return ANYLOC_OK;
-  };
   // does any tap need the block OUTPUT of the last executed layer?
   bool last_needs_full = false;
   for (int t = 0; t < n_taps; ++t)
@@ -352,8 +316,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
     const bool last = (l == last_layer);
     // split-bf16 mode, fused producers: LayerNorm / attention / FFN activation write plane images directly
     const bool fuse = fuse_x6;
-    LnReduce red;
-    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, w.ainv, stream, nullptr, nullptr, take_pending(red)));
+    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, w.ainv, stream));
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm1_w, b.norm1_b, M, D, 1e-6f, stream));
     const float* y_in = fuse ? nullptr : w.y;     // nullptr: the plane image is already in w.a3
@@ -388,11 +351,8 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
                            3 * D, EPI_QKV_PLANES, nullptr, "vit_qkv_gemm", stream, nullptr, nullptr,
                            reinterpret_cast<unsigned char*>(w.qkv), w.qinv, c.heads, &w, H3_KIND_QKV));
       ANYLOC_TRY(attention_h3(reinterpret_cast<const unsigned char*>(w.qkv), w.qinv, batch, T, D, c.heads, w.a3, w.ainv, stream));
-      if (slab_mode)
-        ANYLOC_TRY(slab_gemm(w.a3, w.ainv, D, h->h2[l].proj_w2, h->h2[l].proj_inv, b.proj_b, b.ls1, H3_KIND_PROJ, "vit_proj_gemm"));
-      else
-        ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
-                             EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_PROJ));
+      ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
+                           EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_PROJ));
     } else {
       if (h3m)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, w.qkv, 3 * D, M,
@@ -418,8 +378,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
     }
     const float* fb = h3f ? h->h2[l].fc1_bound : nullptr;
     const bool fuse_ffn = fb && (fb[0] > 0.f || fb[1] > 0.f) && !(l < (int)h->ffn_exact.size() && h->ffn_exact[l]);
-    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, fuse_ffn ? fb : nullptr, w.hinv,
-                                     take_pending(red)));
+    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, fuse_ffn ? fb : nullptr, w.hinv));
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
@@ -434,11 +393,8 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
                              h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
                              w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1));
       if (h->ffn_looseness) ANYLOC_TRY(h2_row_looseness(w.h3, M, M, Hh, h->ffn_looseness + l, stream));
-      if (slab_mode)
-        ANYLOC_TRY(slab_gemm(w.h3, w.hinv, Hh, h->h2[l].fc2_w2, h->h2[l].fc2_inv, b.fc2_b, b.ls2, H3_KIND_FC2, "vit_fc2_gemm"));
-      else
-        ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
-                             EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
+      ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
+                           EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
     } else if (h3m) {
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, w.h, Hh, M, Hh,
@@ -468,10 +424,8 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       ANYLOC_TRY(linear(w.h, Hh, b.fc2_w, Hh, b.fc2_b, w.x, D, M, D, EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream));
     }
     for (int t = 0; t < n_taps; ++t)
-      if (tap_layers[t] == l && tap_facets[t] == ANYLOC_FACET_TOKEN) {
-        ANYLOC_TRY(flush_pending());                       // the block output in fp32: complete the rows first
+      if (tap_layers[t] == l && tap_facets[t] == ANYLOC_FACET_TOKEN)
         ANYLOC_TRY(facet_rows(w.x, D, 0, out, ldo, t * D, batch, T, skip, rows_per_img, D, norm_taps, 1e-12f, stream));
-      }
   }
   if (flags & ANYLOC_VIT_NORM_CONCAT)
     ANYLOC_TRY(l2norm_rows(out, ldo, out, ldo, batch * rows_per_img, ldo, 1e-12f, stream));
