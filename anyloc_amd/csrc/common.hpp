@@ -86,7 +86,6 @@ enum Option {
   OPT_H3S_KSPLIT,        // split-K factor (0 = the plan table)
   OPT_H3S_KB,            // k-blocks per ring stage: 1, 2 or 4 (0 = the plan table)
   OPT_H3S_STAGES,        // ring depth: 3 or 6 (0 = the plan table)
-  OPT_H3S_PIPE,          // fragment reads one k-block ahead of the MFMAs: 0 / 1 (-1 = the plan table); one k-block per stage only
   OPT_H3S_MASK,          // which GEMMs the three overrides apply to: bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 others
   OPT_H3S_ENABLE,        // 1 = small-M plans (default), 0 = the round-3 small-batch kernels (64x64 two-wave tiles, no split-K)
   OPT_COUNT

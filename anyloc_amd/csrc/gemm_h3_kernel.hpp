@@ -2,8 +2,6 @@
 // the C ABI) and gemm_h3s.hip (the small-M plans: other tile shapes, split-K).  Arithmetic and operand image: see the
 // header of gemm_h3.hip.
 #pragma once
-#include <type_traits>
-
 #include "common.hpp"
 #include "tile_order.hpp"
 
@@ -70,12 +68,8 @@ __device__ __forceinline__ float h3_silu_fast(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
-// PIPE = 1 (small-M plans, KB = 1): the fragment reads run ONE k-block ahead of the MFMAs, across the per-stage barrier --
-// with one wave per SIMD (a one-image GEMM) a k-block is otherwise a serial chain, counted wait -> barrier -> fragment reads
-// -> dependent MFMAs, ~600 cycles for 192 of matrix work; same products in the same order: bitwise the same result
-template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1, int PIPE = 0>
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p, int tiles_m, int tiles_n) {
-  static_assert(PIPE == 0 || (KB == 1 && STAGES >= 3), "the read-ahead loop needs one k-block per stage and a 3-deep ring");
   using Cfg = H3Cfg<MI, NI, WM, WN, STAGES, KB>;
   constexpr bool TR = EPI == EPI_SWIGLU_T || EPI == EPI_SWIGLU_T_H2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,64 +171,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
       }
     }
   };
-  if constexpr (PIPE) {
-    // fragments of k-block t + 1 are requested (after the barrier that publishes its stage) BEFORE the MFMAs of k-block t;
-    // the DMA of k-block t + STAGES - 1 then refills the stage k-block t - 1 was read from (everybody consumed those
-    // fragments before this barrier).  Two fragment sets alternate: the loop body covers an even number of ring slots.
-    f16x8 fa[2][MI][2], fb[2][NI][2];
-    auto read_frags = [&](int stage, auto par) {
-      constexpr int P = decltype(par)::value;
-      const unsigned char* sa = frag + stage * Cfg::STAGE + (wm * 32 * MI) * 32;
-      const unsigned char* sw = frag + stage * Cfg::STAGE + Cfg::A_OP + (wn * 32 * NI) * 32;
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[P][mi][pl] = *reinterpret_cast<const f16x8*>(sa + pl * Cfg::A_PLANE + mi * 1024);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fb[P][ni][pl] = *reinterpret_cast<const f16x8*>(sw + pl * Cfg::W_PLANE + ni * 1024);
-      }
-    };
-    auto mfmas = [&](auto par) {
-      constexpr int P = decltype(par)::value;
-#define ANYLOC_H3_TERM(pa, pb)                                                                       \
-  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
-      acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[P][ni][pb], fa[P][mi][pa], acc[mi][ni], 0, 0, 0) \
-                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[P][mi][pa], fb[P][ni][pb], acc[mi][ni], 0, 0, 0);
-      ANYLOC_H3_TERM(1, 0) ANYLOC_H3_TERM(0, 1) ANYLOC_H3_TERM(0, 0)
-#undef ANYLOC_H3_TERM
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::NDMA) : "memory");
-    __builtin_amdgcn_s_barrier();
-    read_frags(0, P0{});
-    constexpr int U = STAGES % 2 == 0 ? STAGES : 2 * STAGES;
-    auto step = [&](int kt, int stage, auto par) {       // k-block kt sits in `stage`, its fragments in set `par`
-      constexpr int P = decltype(par)::value;
-      // k-block kt + 1 has landed (own pieces), then everybody's; (STAGES - 3) later groups may still fly
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 3) * Cfg::NDMA) : "memory");
-      __builtin_amdgcn_s_barrier();
-      read_frags((stage + 1) % STAGES, std::integral_constant<int, 1 - P>{});
-      issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(par);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int kt = 0; kt < nk; kt += U) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (kt + u < nk) {
-          if (u % 2 == 0) step(kt + u, u % STAGES, P0{});
-          else step(kt + u, u % STAGES, P1{});
-        }
-    }
-  } else {
   for (int kt = 0; kt < nk; kt += STAGES) {
     slab(kt, 0);
 #pragma unroll
     for (int st = 1; st < STAGES; ++st)
       if (kt + st < nk) slab(kt + st, st);
-  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

@@ -20,26 +20,25 @@ namespace {
 
 struct Plan {
   int cfg, kb, ksplit;
-  int stages = 3;      // ring depth: 3 or 6 stages
-  int pipe = 0;        // 1 = fragment reads one k-block ahead of the MFMAs (kb == 1 only; same bits)
-};
+  int stages = 3;      // ring depth: 3 or 6 stages (the weights of a one-image GEMM come from HBM: bytes in flight are what
+};                     // the launch waits for)
 
 // tile configurations: id -> (MI, NI, WM, WN); BM = 32 MI WM, BN = 32 NI WN
 constexpr int NCFG = 7;
 const int kCfgBM[NCFG] = {64, 64, 64, 64, 128, 64, 64};
 const int kCfgBN[NCFG] = {64, 128, 128, 128, 128, 256, 256};
 
-template <int EPI, int MI, int NI, int WM, int WN, int KB, int ST = 3, int PIPE = 0>
+template <int EPI, int MI, int NI, int WM, int WN, int KB, int ST = 3>
 int launch_small(const H3Problem& p, hipStream_t stream) {
   using Cfg = H3Cfg<MI, NI, WM, WN, ST, KB>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
   static bool attr_set = false;
   if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB, PIPE>),
+    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB, PIPE>), dim3((unsigned)(tiles_m * tiles_n * std::max(1, p.ksplit))),
+  hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>), dim3((unsigned)(tiles_m * tiles_n * std::max(1, p.ksplit))),
                      dim3(64 * WM * WN), Cfg::LDS, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_h3_kernel (small-M plan)");
 }
@@ -52,41 +51,33 @@ constexpr bool deep_ok() {
 }
 
 template <int EPI, int MI, int NI, int WM, int WN, int KB>
-int launch_st(const H3Problem& p, int stages, int pipe, hipStream_t stream) {
+int launch_st(const H3Problem& p, int stages, hipStream_t stream) {
   if constexpr (deep_ok<MI, NI, WM, WN, KB>()) {
-    if (stages >= 6) {
-      if constexpr (KB == 1) {
-        if (pipe) return launch_small<EPI, MI, NI, WM, WN, KB, 6, 1>(p, stream);
-      }
-      return launch_small<EPI, MI, NI, WM, WN, KB, 6>(p, stream);
-    }
-  }
-  if constexpr (KB == 1) {
-    if (pipe) return launch_small<EPI, MI, NI, WM, WN, KB, 3, 1>(p, stream);
+    if (stages >= 6) return launch_small<EPI, MI, NI, WM, WN, KB, 6>(p, stream);
   }
   return launch_small<EPI, MI, NI, WM, WN, KB, 3>(p, stream);
 }
 
 template <int EPI, int MI, int NI, int WM, int WN>
-int launch_kb(const H3Problem& p, int kb, int stages, int pipe, hipStream_t stream) {
+int launch_kb(const H3Problem& p, int kb, int stages, hipStream_t stream) {
   if (kb >= 4) {
-    if constexpr (H3Cfg<MI, NI, WM, WN, 3, 4>::LDS <= 160 * 1024) return launch_st<EPI, MI, NI, WM, WN, 4>(p, stages, 0, stream);
+    if constexpr (H3Cfg<MI, NI, WM, WN, 3, 4>::LDS <= 160 * 1024) return launch_st<EPI, MI, NI, WM, WN, 4>(p, stages, stream);
     kb = 2;
   }
-  if (kb == 2) return launch_st<EPI, MI, NI, WM, WN, 2>(p, stages, 0, stream);
-  return launch_st<EPI, MI, NI, WM, WN, 1>(p, stages, pipe, stream);
+  if (kb == 2) return launch_st<EPI, MI, NI, WM, WN, 2>(p, stages, stream);
+  return launch_st<EPI, MI, NI, WM, WN, 1>(p, stages, stream);
 }
 
 template <int EPI>
 int launch_cfg(const H3Problem& p, const Plan& pl, hipStream_t stream) {
   switch (pl.cfg) {
-    case 0: return launch_kb<EPI, 1, 2, 2, 1>(p, pl.kb, pl.stages, pl.pipe, stream);    // 64 x 64, two waves of 32 x 64
-    case 1: return launch_kb<EPI, 2, 2, 1, 2>(p, pl.kb, pl.stages, pl.pipe, stream);    // 64 x 128, two waves of 64 x 64
-    case 2: return launch_kb<EPI, 1, 2, 2, 2>(p, pl.kb, pl.stages, pl.pipe, stream);    // 64 x 128, four waves of 32 x 64
-    case 3: return launch_kb<EPI, 1, 4, 2, 1>(p, pl.kb, pl.stages, pl.pipe, stream);    // 64 x 128, two waves of 32 x 128
-    case 4: return launch_kb<EPI, 2, 2, 2, 2>(p, pl.kb, pl.stages, pl.pipe, stream);    // 128 x 128, four waves of 64 x 64
-    case 5: return launch_kb<EPI, 2, 2, 1, 4>(p, pl.kb, pl.stages, pl.pipe, stream);    // 64 x 256, four waves of 64 x 64
-    default: return launch_kb<EPI, 1, 4, 2, 2>(p, pl.kb, pl.stages, pl.pipe, stream);   // 64 x 256, four waves of 32 x 128
+    case 0: return launch_kb<EPI, 1, 2, 2, 1>(p, pl.kb, pl.stages, stream);    // 64 x 64, two waves of 32 x 64
+    case 1: return launch_kb<EPI, 2, 2, 1, 2>(p, pl.kb, pl.stages, stream);    // 64 x 128, two waves of 64 x 64
+    case 2: return launch_kb<EPI, 1, 2, 2, 2>(p, pl.kb, pl.stages, stream);    // 64 x 128, four waves of 32 x 64
+    case 3: return launch_kb<EPI, 1, 4, 2, 1>(p, pl.kb, pl.stages, stream);    // 64 x 128, two waves of 32 x 128
+    case 4: return launch_kb<EPI, 2, 2, 2, 2>(p, pl.kb, pl.stages, stream);    // 128 x 128, four waves of 64 x 64
+    case 5: return launch_kb<EPI, 2, 2, 1, 4>(p, pl.kb, pl.stages, stream);    // 64 x 256, four waves of 64 x 64
+    default: return launch_kb<EPI, 1, 4, 2, 2>(p, pl.kb, pl.stages, stream);   // 64 x 256, four waves of 32 x 128
   }
 }
 
@@ -133,8 +124,6 @@ Plan choose(const H3Problem& p, int epilogue) {
     const int64_t st = option(OPT_H3S_STAGES);
     if (st == 3 || st == 6) pl.stages = (int)st;
   }
-  const int64_t pp = option(OPT_H3S_PIPE);
-  if (pp == 0 || pp == 1) pl.pipe = (int)pp;
   return pl;
 }
 

@@ -77,8 +77,6 @@ const char* anyloc_last_error(void);
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
  *   h3s_enable (1)                    small-M plans of the two-term fp16 GEMM (csrc/gemm_h3s.hip: tile shape, ring depth and split-K
  *                                     factor per GEMM shape when a call has one or a few images); 0 = the round-3 small-batch kernels
- *   h3s_pipe (-1)                     small-M plans with one k-block per stage: fragment reads one k-block ahead of the MFMAs (same
- *                                     bits); -1 = the plan table, 0 / 1 force it for every GEMM
  *   h3s_cfg (-1) h3s_ksplit (0) h3s_kb (0) h3s_stages (0) h3s_mask (31)
  *                                     overrides of that plan table for sweeps: tile configuration id, split-K factor, k-blocks per
  *                                     ring stage, ring depth (3 or 6); mask bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 other GEMMs

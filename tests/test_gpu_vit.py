@@ -199,12 +199,9 @@ def test_small_m_plans_agree_with_the_plain_kernels(batch):
             assert torch.equal(got, ext(img))
         plans = [(c, kb, ks, st) for c in range(7) for kb, ks, st in ((1, 1, 3), (2, 3, 6), (4, 2, 3), (1, 8, 6), (2, 5, 3))]
         for cfg, kb, ks, st in plans:
-            with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks, h3s_stages=st, h3s_pipe=0):
+            with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks, h3s_stages=st):
                 a = ext(img).clone()
                 b = ext(img)
-                if kb == 1:                                              # fragment reads one k-block ahead: same products, same order
-                    with ops.options(h3s_pipe=1):
-                        assert torch.equal(a, ext(img)), (cfg, kb, ks, st, "read-ahead loop changed the bits")
             assert float((a - want).abs().max()) <= 2e-6, (cfg, kb, ks, st, float((a - want).abs().max()))
             assert torch.equal(a, b), (cfg, kb, ks, st, "not reproducible")
     finally:

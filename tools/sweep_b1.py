@@ -58,20 +58,20 @@ for B in BATCHES:
           f"  max|dtok|={float((tok1 - tok0).abs().max()):.2e}", flush=True)
     best = {k: (per0[k], "round3") for k in per0}
     for cfg in range(7):
-        for kb, pipe in ((1, 0), (1, 1), (2, 0), (4, 0)):
+        for kb in (1, 2, 4):
             for st in (3, 6):
                 for ks in (1, 2, 3, 4):
-                    with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks, h3s_stages=st, h3s_pipe=pipe, h3s_mask=15):
+                    with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks, h3s_stages=st, h3s_mask=15):
                         try:
                             wall, per, tok, _ = run(img, 4)
                         except Exception as e:                                   # a plan the library rejects
-                            print(f"  cfg={cfg} kb={kb} pipe={pipe} st={st} ks={ks}: {e}", flush=True)
+                            print(f"  cfg={cfg} kb={kb} st={st} ks={ks}: {e}", flush=True)
                             continue
                     err = float((tok - tok0).abs().max())
-                    print(f"  B={B} cfg={cfg}({CFG_NAMES[cfg]}) kb={kb} pipe={pipe} st={st} ks={ks}: {wall*1e3:.3f} ms  " +
+                    print(f"  B={B} cfg={cfg}({CFG_NAMES[cfg]}) kb={kb} st={st} ks={ks}: {wall*1e3:.3f} ms  " +
                           "  ".join(f"{k}={v:.1f}" for k, v in per.items()) + f"  err={err:.1e}", flush=True)
                     if err < 5e-6:
                         for k, v in per.items():
                             if v < best[k][0]:
-                                best[k] = (v, f"cfg={cfg} kb={kb} pipe={pipe} st={st} ks={ks}")
+                                best[k] = (v, f"cfg={cfg} kb={kb} st={st} ks={ks}")
     print(f"B={B} BEST per GEMM: " + "  ".join(f"{k}: {v[0]:.1f}us [{v[1]}]" for k, v in best.items()), flush=True)
