@@ -106,6 +106,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint, c_f32p,
                                      C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_profile_enable": (C.c_int, [C.c_int]),
+    "anyloc_profile_filter": (C.c_int, [C.c_char_p]),
     "anyloc_profile_reset": (C.c_int, []),
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),
 }

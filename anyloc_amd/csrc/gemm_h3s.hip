@@ -87,8 +87,8 @@ int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // stage while a workgroup is alone on its CU, 128 x 128 four-wave tiles from 256 such tiles up).  Up to two images (M <= 1100
 // rows) the measured winners of the plan sweeps replace them (tools/sweep_b1.py on one MI355X, ViT-G/14 322 x 322, time per
 // launch inside a B = 1 / B = 2 forward: profiles/r04_b1_plan_sweep.log, r04_b1_plan_sweep_depth.log):
-//   fc2   (K = 4096, N = 1536)  64 x 128 four-wave tiles, 6-deep ring, split-K 2     B=1: 49.9 -> 39.7 us   B=2: 68.8 -> 56.6
-//   proj  (K = 1536, N = 1536)  B=1: 64 x 64, 6-deep ring 25.0 -> 22.7 us;  B=2: 64 x 128, two k-blocks per stage 32.2 -> 29.3
+//   fc2   (K = 4096, N = 1536)  64 x 128 four-wave tiles, 6-deep ring; split-K 2 at B=1: 49.9 -> 39.7 us;  B=2 unsplit: 75.7 -> 56.8
+//   proj  (K = 1536, N = 1536)  B=1: 64 x 64, 6-deep ring 25.0 -> 22.7 us;  B=2: 64 x 128, 6-deep ring 34.8 -> 28.3
 //   qkv   (N = 4608)            B=1: 128 x 128, 6-deep ring 39.1 -> 37.8 us;   B=2: 64 x 128 four-wave 56.1 -> 53.4
 //   w12   (N = 8192)            the round-3 choice stays the fastest (128 x 128 at B=1: 59 us)
 // What the sweeps say about this regime: split-K pays only for the long contraction (a split workgroup's ticket hand-off and
@@ -104,11 +104,11 @@ Plan choose(const H3Problem& p, int epilogue) {
   if (p.M <= 1100) {
     const bool one = p.M <= 600;                           // one 322 x 322 image (530 rows) / two
     if (p.N <= 2048 && p.K16 >= 192) {                     // fc2-like: long contraction, narrow output
-      pl = Plan{2, 1, 2};
+      pl = Plan{2, 1, one ? 2 : 1};
       pl.stages = 6;
     } else if (p.N <= 2048) {                              // proj-like
-      pl = one ? Plan{0, 1, 1} : Plan{2, 2, 1};
-      pl.stages = one ? 6 : 3;
+      pl = one ? Plan{0, 1, 1} : Plan{2, 1, 1};
+      pl.stages = 6;
     } else if (p.N < 8192) {                               // qkv-like
       pl = one ? Plan{4, 1, 1} : Plan{2, 1, 1};
       pl.stages = one ? 6 : 3;

@@ -19,6 +19,7 @@ struct ProfEntry {
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+std::string g_prof_filter;       // non-empty: only launches with exactly this tag are bracketed
 std::vector<ProfEntry> g_prof;   // one entry per bracketed launch since the last reset
 }  // namespace
 
@@ -94,6 +95,7 @@ int launch_status(const char* what) {
 ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_filter.empty() && g_prof_filter != name) return;
   ProfEntry e;
   e.name = name;
   e.flops = flops;
@@ -149,6 +151,12 @@ int anyloc_reset_options(void) {
 int anyloc_profile_enable(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
+  return ANYLOC_OK;
+}
+
+int anyloc_profile_filter(const char* tag) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_filter = tag ? tag : "";
   return ANYLOC_OK;
 }
 

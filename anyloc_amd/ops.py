@@ -405,6 +405,11 @@ def profile_enable(on=True):
     _lib.check(_lib.load().anyloc_profile_enable(1 if on else 0), "anyloc_profile_enable")
 
 
+def profile_filter(tag=None):
+    """Bracket only launches tagged ``tag`` (None: all)."""
+    _lib.check(_lib.load().anyloc_profile_filter(tag.encode() if tag else None), "anyloc_profile_filter")
+
+
 def profile_reset():
     _lib.check(_lib.load().anyloc_profile_reset(), "anyloc_profile_reset")
 

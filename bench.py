@@ -95,6 +95,9 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
                        "vs_fp32_mfma_peak": round(e2e / PEAK_FP32_MFMA_TFLOPS, 4)},
         "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in
                                 sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        "kernels_note": "the dominant kernel's launches are bracketed by HIP events INSIDE the timed region; the other kernels' "
+                        "times come from two fully bracketed steps run right after it, untimed (two events per launch cost a "
+                        "step ~1 % when all ~225 launches carry them)",
     }
 
 
@@ -342,7 +345,17 @@ def main():
 
     for i in range(warm):
         step(i)
+    # HIP events around EVERY launch cost the queue ~3 us each (450 per step): the timed region brackets only the launches
+    # of the dominant kernel -- found by one fully bracketed, untimed step -- and the per-kernel table comes from two more
+    # untimed steps after it (anyloc_profile_filter)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    step(0)
+    torch.cuda.synchronize()
+    ops.profile_enable(False)
+    dom_tag = max(ops.profile_dump().items(), key=lambda kv: kv[1]["ms"])[0]
     results.clear()
+    ops.profile_filter(dom_tag)
     ops.profile_enable(True)
     ops.profile_reset()
     if dist is not None:
@@ -356,19 +369,29 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
-    prof = ops.profile_dump()
+    prof_dom = ops.profile_dump()
+    ops.profile_filter(None)
     elapsed = max_over_ranks(elapsed, dist, dev)
+    timed_results = list(results)            # (the untimed steps below and the `modes` block re-use and clear `results`)
+    ops.profile_enable(True)
+    ops.profile_reset()
+    for i in range(2):
+        step(warm + i)
+    torch.cuda.synchronize()
+    ops.profile_enable(False)
+    prof = {k: {f: v[f] * (steps / 2.0) for f in ("calls", "ms", "flops", "bytes")} for k, v in ops.profile_dump().items()}
+    prof[dom_tag] = prof_dom[dom_tag]        # the dominant kernel: its launches inside the timed region
+    results.clear()
 
     if rank != 0:
         dist.destroy_process_group()
         return
 
-    timed_results = list(results)            # (the `modes` block below re-uses and clears `results`)
     images = steps * B * world
     value = images / elapsed
     # Recall@1 of the timed queries (rank 0's share): query i depicts place i of its own rank
     if world == 1:
-        idx_all = torch.cat([r[1] for r in results]).cpu().numpy()
+        idx_all = torch.cat([r[1] for r in timed_results]).cpu().numpy()
         gt_timed = np.empty(len(idx_all), dtype=object)
         for n, i in enumerate(range(warm, total_steps)):
             for j in range(B):
@@ -377,7 +400,7 @@ def main():
     else:
         # merged lists are ordered rank-major within a step; rank r's query j of step i depicts global
         # database row r*N_DB + i*B + j (its own shard's place)
-        idx_all = np.concatenate([r[1] for r in results])
+        idx_all = np.concatenate([r[1] for r in timed_results])
         gt_timed = np.empty(len(idx_all), dtype=object)
         n = 0
         for i in range(warm, total_steps):
@@ -422,6 +445,7 @@ def main():
             try:
                 step(0)
                 results.clear()
+                ops.profile_filter(dom_tag)
                 ops.profile_enable(True)
                 ops.profile_reset()
                 torch.cuda.synchronize()
@@ -431,7 +455,17 @@ def main():
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
                 ops.profile_enable(False)
-                r = roofline_of(ops.profile_dump(), mode, mode_steps * B / el, mode_steps)
+                pd = ops.profile_dump()
+                ops.profile_filter(None)
+                ops.profile_enable(True)
+                ops.profile_reset()
+                step(warm)
+                torch.cuda.synchronize()
+                ops.profile_enable(False)
+                pm = {k: {f: v[f] * float(mode_steps) for f in ("calls", "ms", "flops", "bytes")} for k, v in ops.profile_dump().items()}
+                if dom_tag in pd:
+                    pm[dom_tag] = pd[dom_tag]
+                r = roofline_of(pm, mode, mode_steps * B / el, mode_steps)
                 modes[mode] = {"value": round(mode_steps * B / el, 3), "ms_per_step": round(el / mode_steps * 1e3, 3),
                                "steps": mode_steps, "frac": r["frac"], "peak": r["peak"], "achieved": r["achieved"],
                                "end_to_end_frac": r["end_to_end"]["frac"], "kernel": r["kernel"]}

@@ -405,6 +405,10 @@ int anyloc_vit_forward(anyloc_vit_t* h, const float* img, int64_t batch,
  * kernels issued by the most recent call with profiling enabled; used by
  * bench.py for the live roofline figure.  enable: 0/1. */
 int anyloc_profile_enable(int enable);
+/* ABI 5: bracket only the launches whose profiling tag equals `tag` (NULL or "" = all).  Two HIP events around every launch cost
+ * a launch-bound sequence real time (~3 us per event on the queue); bench.py brackets only the kernel whose roofline it
+ * reports inside its timed region and takes the per-kernel table from untimed steps. */
+int anyloc_profile_filter(const char* tag);
 int anyloc_profile_reset(void);
 /* writes up to `cap` bytes of a JSON object {"kernel": {"calls":n,"ms":t,"flops":f,"bytes":b}, ...} */
 int anyloc_profile_dump(char* buf, size_t cap);
