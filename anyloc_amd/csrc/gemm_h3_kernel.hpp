@@ -153,13 +153,21 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
       }
       if (kb == 0) issue(kt + STAGES - 1, (stage + STAGES - 1) % STAGES);
       // TR (EPI_SWIGLU_T*): the weight fragment is the MFMA's A operand, so acc[mi][ni] holds the TRANSPOSED 32 x 32 block --
-      // lane = token, registers = 16 weight rows -- same products, same sums, other owner of each element
-#define ANYLOC_H3_TERM(pa, pb)                                                                       \
-  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) \
-      acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][pb], a[mi][pa], acc[mi][ni], 0, 0, 0) \
-                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
-      ANYLOC_H3_TERM(1, 0) ANYLOC_H3_TERM(0, 1) ANYLOC_H3_TERM(0, 0)
-#undef ANYLOC_H3_TERM
+      // lane = token, registers = 16 weight rows -- same products, same sums, other owner of each element.
+      // The three products of a block are issued back to back on their accumulator (smallest first: lo x hi, hi x lo, hi x hi).
+      // Round 3 issued each product for all blocks before the next one -- per accumulator the same additions in the same
+      // order, so the same bits -- but the dependent chain measures 0.5 % faster end to end (w12 -0.5 %, qkv / fc2 -1 %,
+      // interleaved A/B on one box, profiles/r04_ab_mfma_chain.log; column-block-outer traversal: the same, the bf16 and the
+      // 16x16x32 kernels: neutral): a block's accumulator is forwarded from one MFMA to the next instead of making three
+      // round trips through the register file, and at the power limit joules are time.
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {
+        acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][0], a[mi][1], acc[mi][ni], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][1], a[mi][0], acc[mi][ni], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][0], a[mi][0], acc[mi][ni], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);
+      }
     }
     if constexpr (KB == 1) {
       constexpr int PIECES = Cfg::NDMA, G = (3 * MI * NI) / (PIECES + 1);
