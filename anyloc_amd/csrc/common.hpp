@@ -63,6 +63,7 @@ enum Option {
   OPT_H3_EPI_LDS,        // gemm_h3 LayerScale-residual epilogue: 1 = 16-byte accesses through LDS, 0 = dword read-modify-write
   OPT_LN_ROWS_PER_WAVE,  // layernorm_h2: 0 = by ln_small_rows; 1 / 2 / 4 = rows per wave at every size (A/B)
   OPT_LN_SMALL_ROWS,     // layernorm_h2: below this many rows one row per wave
+  OPT_LN_WAVES,          // layernorm_h2 with two rows per wave: waves per block, 8 (16 rows: 512-byte store runs) or 4
   OPT_LN_DIRECT_ROWS,    // layernorm_h2: below this many rows one single-wave workgroup per row, no LDS tile (0 = never)
   OPT_H3_FUSE,           // h3 forward: 1 = q|k|v, attention output and FFN activation stay in fp16 planes; 0 = fp32 + quantiser passes
   OPT_X6_FUSE,           // x6 forward: the same for the bf16 plane images

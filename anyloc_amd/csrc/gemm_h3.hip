@@ -26,15 +26,15 @@ namespace {
 // (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
 // store chunk i (256 columns) of 16 rows, already scaled and sitting in the LDS tile, in IMAGE order
 // (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
-template <int RB = 16>
+template <int RB = 16, int NT = 256>
 __device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, int dim, int64_t row0, int64_t rows,
                                                unsigned char* out, int64_t R) {
-  static_assert(RB == 16 || RB == 8 || RB == 4, "16 rows per block (4 per wave), 8 (2 per wave) or 4 (1 per wave)");
+  static_assert(RB == 32 || RB == 16 || RB == 8 || RB == 4, "rows per block: a power of two (k-block, row, half) decoding");
   const int tid = threadIdx.x;
   constexpr int ITEMS = RB * 32;                           // (k-block, row, half) triples of one 256-column chunk
 #pragma unroll
-  for (int u = 0; u < (ITEMS + 255) / 256; ++u) {
-    const int item = tid + 256 * u;
+  for (int u = 0; u < (ITEMS + NT - 1) / NT; ++u) {
+    const int item = tid + NT * u;
     const int kbl = item / (2 * RB), r = (item >> 1) & (RB - 1), half = item & 1;
     const int k0 = 256 * i + 16 * kbl + 8 * half;
     const int64_t row = row0 + r;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, in
 }
 
 // rows held in registers: the scaled values of 16 rows go through the LDS tile chunk by chunk
-template <int NV, int RPW = 4>
+template <int NV, int RPW = 4, int NW = 4>
 __device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[RPW][NV], const float (&scale)[RPW], float (*tile)[256 + 4],
                                               int dim, int64_t row0, int64_t rows, unsigned char* out, int64_t R) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[RPW][NV], const f
       }
     }
     __syncthreads();
-    h2_store_chunk<4 * RPW>(tile, i, dim, row0, rows, out, R);
+    h2_store_chunk<NW * RPW, 64 * NW>(tile, i, dim, row0, rows, out, R);
   }
 }
 
@@ -246,15 +246,15 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
 // RPW rows per wave (4 waves per block): 4 by default; 1 when there are few rows (one or two images: 530 rows are 34
 // blocks of 16 rows on 256 CUs -- 25 us of latency per launch; 133 blocks of 4 rows spread them).  Per-row arithmetic does
 // not depend on RPW, so the results are bitwise the same.
-template <int NV, int RPW>
-__global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int NV, int RPW, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void layernorm_h2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, int dim, int64_t rows, float eps,
                                                            unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
                                                            const f32x4 bound4, float* __restrict__ bound_inv) {
-  __shared__ __attribute__((aligned(16))) float tile[4 * RPW][256 + 4];
+  __shared__ __attribute__((aligned(16))) float tile[NW * RPW][256 + 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n4 = dim >> 2;
-  const int64_t row0 = (int64_t)blockIdx.x * (4 * RPW);
+  const int64_t row0 = (int64_t)blockIdx.x * (NW * RPW);
   f32x4 v[RPW][NV];
   float scale[RPW];
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void layernorm_h2_kernel(const float* __restri
       if (lane == 0 && row0 + wave * RPW + q < rows) bound_inv[row] = biv;
     }
   }
-  h2_store_rows<NV, RPW>(v, scale, tile, dim, row0, rows, out, R);
+  h2_store_rows<NV, RPW, NW>(v, scale, tile, dim, row0, rows, out, R);
 }
 
 
@@ -493,15 +493,20 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
     return launch_status("layernorm_h2_direct_kernel");
   }
   const int rpw = (forced == 1 || forced == 2 || forced == 4) ? (int)forced : (rows < option(OPT_LN_SMALL_ROWS) ? 1 : 2);
-  const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
-#define ANYLOC_LN_H2_R(NVV, RPWV)                                                                                        \
-  hipLaunchKernelGGL((layernorm_h2_kernel<NVV, RPWV>), grid, dim3(256), 0, stream, x, w, b, dim, rows, eps, out, inv_scale, \
-                     rows, b4, bound ? bound_inv : nullptr)
+  // two rows per wave: EIGHT waves per block (option ln_waves = 8, default) -- 16 rows per block, i.e. 512-byte runs per store
+  // instruction instead of the 256-byte runs of four waves, at the register count of two rows per wave (B = 61: 5.5 -> ? ms
+  // per step; four rows per wave on four waves: 6.4, one row per wave: 11.1 -- the run length is what the stores want)
+  const int nw = (rpw == 2 && option(OPT_LN_WAVES) == 8) ? 8 : 4;
+  const dim3 grid((unsigned)((rows + nw * rpw - 1) / (nw * rpw)));
+#define ANYLOC_LN_H2_R(NVV, RPWV, NWV)                                                                                   \
+  hipLaunchKernelGGL((layernorm_h2_kernel<NVV, RPWV, NWV>), grid, dim3(64 * NWV), 0, stream, x, w, b, dim, rows, eps, out,  \
+                     inv_scale, rows, b4, bound ? bound_inv : nullptr)
 #define ANYLOC_LN_H2(NVV)              \
   do {                                 \
-    if (rpw == 1) ANYLOC_LN_H2_R(NVV, 1);      \
-    else if (rpw == 2) ANYLOC_LN_H2_R(NVV, 2); \
-    else ANYLOC_LN_H2_R(NVV, 4);               \
+    if (rpw == 1) ANYLOC_LN_H2_R(NVV, 1, 4);      \
+    else if (rpw == 2 && nw == 8) ANYLOC_LN_H2_R(NVV, 2, 8); \
+    else if (rpw == 2) ANYLOC_LN_H2_R(NVV, 2, 4); \
+    else ANYLOC_LN_H2_R(NVV, 4, 4);               \
   } while (0)
   if (nv <= 1) ANYLOC_LN_H2(1);
   else if (nv <= 2) ANYLOC_LN_H2(2);

@@ -58,6 +58,7 @@ const char* anyloc_last_error(void);
  *   h3_epi_lds (1)                    LayerScale-residual epilogue with 16-byte accesses through LDS
  *   ln_rows_per_wave (0)              layernorm_h2: 1 / 2 / 4 rows per wave at every size (0 = by ln_small_rows)
  *   ln_small_rows (4096)              layernorm_h2: one row per wave below this many rows
+ *   ln_waves (8)                      layernorm_h2, two rows per wave: waves per block (8 = 16 rows per block, 512-byte store runs; 4)
  *   ln_direct_rows (1200)             layernorm_h2: below this many rows one single-wave workgroup per row writes the image
  *                                     straight from registers (no LDS tile, no barriers); 0 = never
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels

@@ -378,7 +378,8 @@ def test_scheduling_variants_are_bitwise_equal():
         img = torch.randn(5, 3, 322, 322, generator=torch.Generator().manual_seed(4)).to("cuda")
         base = ext(img).clone()
         assert torch.isfinite(base).all()
-        for opts in (dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2), dict(ln_rows_per_wave=4)):
+        for opts in (dict(ln_rows_per_wave=1), dict(ln_rows_per_wave=2), dict(ln_rows_per_wave=4), dict(ln_waves=4), dict(ln_waves=8),
+                     dict(ln_rows_per_wave=2, ln_waves=4)):
             with ops.options(**opts):
                 assert torch.equal(ext(img), base), opts
     finally:
