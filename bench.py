@@ -908,11 +908,14 @@ def stage_config3_shard(dev, check):
     return res
 
 
-def stage_vitl(dev, check):
+def stage_vitl(dev, check, B=23):
     """BASELINE.json configs[4]: ViT-L/14 518 x 518 (1369 tokens), taps at layers 20 and 23 ('value') concatenated to
-    2048-d, K = 64 VLAD (131 072-d): 64 database + 16 query images end to end (extract_multi -> VLAD -> top-20)."""
+    2048-d, K = 64 VLAD (131 072-d): 64 database + 16 query images end to end (extract_multi -> VLAD -> top-20).
+    Batches of 23 images = 31 510 token rows = 247 row tiles of 128: the 247 x {4, 12, 16} tile grids of the D = 1024 GEMMs fill
+    96.5 % of whole rounds of the 512 resident workgroups (what B = 61 is for ViT-g); batches of 16 leave the two N = 1024
+    GEMMs at 688 tiles = 1.34 rounds (profiles/r04_vitl_batch.log; batches of 8: 309 images/s, of 16: 339)."""
     import utilities
-    name, layers, K, hw, B = "dinov2_vitl14", [20, 23], 64, 518, 16    # (batches of 8: 309 images/s, of 16: 339 -- profiles/r03_vitl_batch.log)
+    name, layers, K, hw = "dinov2_vitl14", [20, 23], 64, 518
     sd = synth.synthetic_state_dict(name, seed=0, device=str(dev))
     weights.register_state_dict(name, sd)
     try:
@@ -924,16 +927,17 @@ def stage_vitl(dev, check):
         vl.fit(toks.reshape(-1, toks.shape[-1]))
         del toks
 
+        all_img = torch.cat([db_img, qu_img])
+
         def run():
-            d = torch.cat([vl.generate_multi(ext.extract_multi(db_img[s:s + B], layers)) for s in range(0, 64, B)])
-            q = torch.cat([vl.generate_multi(ext.extract_multi(qu_img[s:s + B], layers)) for s in range(0, 16, B)])
-            return retrieval.search(d, q, TOPK)
+            v = torch.cat([vl.generate_multi(ext.extract_multi(all_img[s:s + B], layers)) for s in range(0, 80, B)])
+            return retrieval.search(v[:64], v[64:], TOPK)
         el, (dist_, idx), kern = _timed(run, iters=2, warm=1)
         rec = retrieval.recalls_from_indices([1, 5, 10], idx.cpu().numpy(), gt)
         T = 1370
         f_block = 2 * T * 1024 * 3072 + 4 * T * T * 1024 + 2 * T * 1024 * 1024 + 16 * T * 1024 * 1024
         f_img = 2 * 1369 * 588 * 1024 + 23 * f_block + 2 * T * 1024 * 1024 + 2 * T * 1024 * 3072
-        res = {"workload": "BASELINE.json configs[4]: ViT-L/14 518x518, taps L20+L23 'value' -> 2048-d, K=64 VLAD (131072-d), 64 db + 16 qu in batches of 16",
+        res = {"workload": f"BASELINE.json configs[4]: ViT-L/14 518x518, taps L20+L23 'value' -> 2048-d, K=64 VLAD (131072-d), 64 db + 16 qu in batches of {B}",
                "images_per_s": round(80 / el, 2), "ms": round(el * 1e3, 2), "bound": "mfma",
                "achieved": round(80 * f_img / el / 1e12, 1), "unit": "TFLOP/s (algorithmic, fp32-equivalent)",
                "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "frac": round(80 * f_img / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),

@@ -27,9 +27,10 @@ def main():
     for n in names:
         if n.startswith("vlad_"):
             res = bench.stage_vlad(dev, _Vocab(dev), int(n.split("_")[1].replace("img", "")), check)
+        elif n.startswith("vitl_518_2taps"):           # vitl_518_2taps[:batch]
+            res = bench.stage_vitl(dev, check, *([int(n.split(":")[1])] if ":" in n else []))
         else:
-            res = {"kmeans_5Mx1536": bench.stage_kmeans, "config3_shard": bench.stage_config3_shard,
-                   "vitl_518_2taps": bench.stage_vitl}[n](dev, check)
+            res = {"kmeans_5Mx1536": bench.stage_kmeans, "config3_shard": bench.stage_config3_shard}[n](dev, check)
         print(json.dumps({n: res, "options": os.environ.get("ANYLOC_OPTIONS", "")}), flush=True)
 
 
