@@ -72,6 +72,7 @@ enum Option {
   OPT_ATTN_CFG,          // fp32-MFMA attention: workgroup shape (micro-benchmarks)
   OPT_ATTN_X6,           // anyloc_attention: 1 = split-bf16 products for every call, 0 = never, -1 = as the caller asks
   OPT_VLAD_PARTS,        // workgroups per image of the fused VLAD kernel (0 = chosen from the image count)
+  OPT_VLAD_GROUP,        // fused VLAD gather: 1 = label-grouped centre loads (runs of equal labels load once), 0 = one load per token
   OPT_VLAD_TWO_PASS,     // 1 = force the general two-pass VLAD path
   OPT_VLAD_FUSED_V,      // fused VLAD kernel: 0 = default choice, 1 = exact-score kernel, 3 / 4 = screening kernel with 4 / 8 waves
   OPT_KMEANS_FUSED_V,    // the same for the k-means step
@@ -306,6 +307,7 @@ struct FusedArgs {
   int64_t* lab64;          // optional [total] labels
   int norm_descs, intra;
   int metric;              // 0 cosine (||chat_k|| = 1), 1 euclidean (chat = 2 c, cbias = -||c||^2): scales fused3's error bound
+  int group;               // VLAD: 1 = a token with its predecessor's label reuses that token's centre columns (option vlad_group)
   int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
   float* part_buf;         // [units, parts, K, D] partial sums
   unsigned* part_tickets;  // [units] arrival counters (zeroed by the launcher)

@@ -817,9 +817,24 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             for (int e = 0; e < 4; ++e) kk[n4 + e] = __builtin_amdgcn_readfirstlane(lq[e]);
           }
           float c[TG][CW];
+          if (a.group) {
+            // label-grouped (option vlad_group): a token whose label equals its predecessor's in the round reuses that
+            // token's centre columns instead of requesting them again -- patch tokens are spatially coherent, neighbours in
+            // raster order mostly share a cluster; the additions and their order do not change (wave-uniform branches)
 #pragma unroll
-          for (int e = 0; e < TG; ++e)
-            f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
+            for (int e = 0; e < TG; ++e) {
+              if (e > 0 && kk[e] == kk[e - 1]) {
+#pragma unroll
+                for (int j = 0; j < CW; ++j) c[e][j] = c[e - 1][j];
+              } else {
+                f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < TG; ++e)
+              f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
+          }
 #pragma unroll
           for (int n4 = 0; n4 < TG; n4 += 4) {
             const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + g0 + n4);
