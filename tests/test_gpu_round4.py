@@ -247,3 +247,32 @@ def test_reference_script_call_pattern_stage_on_a_small_model():
         assert res["images_per_s"] > 0
     finally:
         weights.unregister_state_dict(name)
+
+
+def test_reference_call_pattern_driver_through_anyloc_amd_run(tmp_path):
+    """``python -m anyloc_amd.run tests/drivers/vlad_driver_standin.py`` in a fresh interpreter on the GPU box: the reference
+    driver's call sequence on the ``utilities`` surface (scripts/dino_v2_vlad.py:157-188, :195-260, :372-376) -- tyro CLI and
+    torchvision transforms through the shims, one image per extractor call with ``.to(device)`` / ``.cpu()``, ``VLAD.fit`` +
+    ``generate_multi`` with cache ids (``c_centers.pt``, ``_r/_l`` files), ``get_top_k_recall`` on CPU tensors -- twice: the
+    second run restores the vocabulary and the VLADs from the cache and must print the same recalls and top-1 indices.
+    (The reference's own script runs the same way wherever its tree exists: tests/test_gpu_round3.py.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synth_dataset
+    make_synth_dataset.write(str(tmp_path / "data"), "st_lucia", n_db=6, n_qu=4, h=112, w=140)
+    env = dict(os.environ, ANYLOC_SYNTHETIC_WEIGHTS="0", PYTHONPATH=ROOT)
+    outs = []
+    for _ in range(2):
+        res = subprocess.run([sys.executable, "-m", "anyloc_amd.run", os.path.join(ROOT, "tests", "drivers", "vlad_driver_standin.py"),
+                              "--data-dir", str(tmp_path / "data"), "--cache-dir", str(tmp_path / "cache"), "--num-clusters", "4"],
+                             env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and "Traceback" not in res.stdout + res.stderr, (res.stdout[-2000:], res.stderr[-2000:])
+        outs.append(res.stdout)
+    for out in outs:
+        assert "Database VLADs shape: torch.Size([6, 1536])" in out and "Query VLADs shape: torch.Size([4, 1536])" in out
+        assert "device of the results: cpu cpu" in out
+    pick = lambda out: [l for l in out.splitlines() if l.startswith("R@") or l.startswith("top-1")]
+    assert pick(outs[0]) == pick(outs[1]) and len(pick(outs[0])) == 4
+    assert "Using cached cluster centers" in outs[1] and "Using cached cluster centers" not in outs[0]
+    assert pick(outs[0])[0] == "R@1: 1.0000", outs[0][-800:]            # query q depicts place q: the synthetic set is easy
+    pts = [f for dp, _, fs in os.walk(tmp_path / "cache") for f in fs if f.endswith(".pt")]
+    assert "c_centers.pt" in pts and any(f.endswith("_r.pt") for f in pts) and any(f.endswith("_l.pt") for f in pts)

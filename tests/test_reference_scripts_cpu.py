@@ -192,3 +192,17 @@ def _cpu_device(real):
         def __instancecheck__(self, inst):
             return isinstance(inst, real)
     return _D()
+
+
+def test_stand_in_driver_with_the_reference_call_pattern(cpu_backend, tmp_path, capsys):
+    """tests/drivers/vlad_driver_standin.py (the script the GPU suite runs through ``python -m anyloc_amd.run`` where the
+    reference tree is absent): the same plumbing check as the reference's own script above, on the CPU stand-in backend."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import make_synth_dataset
+    make_synth_dataset.write(str(tmp_path / "data"), "st_lucia", n_db=6, n_qu=3, h=112, w=140)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    launcher.main([os.path.join(root, "tests", "drivers", "vlad_driver_standin.py"), "--data-dir", str(tmp_path / "data"),
+                   "--cache-dir", str(tmp_path / "cache"), "--num-clusters", "4", "--no-use-gpu"])
+    out = capsys.readouterr().out
+    assert "Database VLADs shape: torch.Size([6, 1536])" in out and "Query VLADs shape: torch.Size([3, 1536])" in out
+    assert "R@1: 1.0000" in out and "device of the results: cpu cpu" in out
