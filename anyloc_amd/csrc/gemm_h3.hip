@@ -311,8 +311,11 @@ __global__ __launch_bounds__(64 * NW) void layernorm_h2_kernel(const float* __re
 
 // The same LayerNorm for FEW rows (one or two images): one wave per row, one row per workgroup, and every lane stores its own
 // four-column groups straight into the image (8 bytes per plane and group) -- no LDS tile, no barriers.  A 530-row launch
-// is 530 single-wave workgroups on 256 CUs and is bound by one wave's load -> two reductions -> store chain instead of the
-// 12 barriers of the tiled kernel (13 -> 7 us per launch, profiles/r04_b1_kernels.log).  Per-row arithmetic as above: same bits.
+// is 530 single-wave workgroups on 256 CUs, one wave's load -> two reductions -> store chain each, instead of 133 blocks with
+// 12 barriers.  Measured: the same 12 us per HIP-event-bracketed launch as the tiled kernel (profiles/r04_b1_plan_sweep_depth.log:
+// ~6 us of that is the bracket, the rest launch ramp and one dependent load chain) -- kept because it needs no LDS; at large
+// M its scattered 8-byte stores are 2.3 x slower than the tiled kernel (option ln_direct_rows).  Per-row arithmetic as above:
+// same bits.
 template <int NV>
 __global__ __launch_bounds__(64) void layernorm_h2_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, int dim, int64_t rows, float eps,

@@ -2,10 +2,9 @@
 //
 // The reference's scripts call the extractor with ONE image (scripts/dino_v2_vlad.py:164-188, demo/anyloc_vlad_generate.py
 // :163-186): 530 token rows at 322 x 322.  A block GEMM then has a handful of row tiles and the 128 x 256 tiling of the
-// batched forward leaves most of the 256 CUs idle.  What bounds such a GEMM is not the matrix cores but (i) how many
-// waves exist at all -- proj / fc2 of ViT-g on 64 x 64 tiles are 216 two-wave workgroups = 432 waves for 1024 SIMDs --
-// and (ii) the dependent chain of a lone wave per SIMD: counted wait -> barrier -> fragment reads -> 6 MFMAs per k-block.
-// A plan = (tile shape, k-blocks per ring stage, split-K factor) picked per GEMM from its shape:
+// batched forward leaves most of the 256 CUs idle: proj / fc2 of ViT-g on 64 x 64 tiles are 216 two-wave workgroups = 432
+// waves for 1024 SIMDs.  A plan = (tile shape, k-blocks per ring stage, ring depth, split-K factor) picked per GEMM from its
+// shape -- the table in choose() holds the measured winners; what the sweeps showed about this regime is written there:
 //   * split-K: the contraction is cut into `ksplit` ranges, one workgroup each, so a K = 4096 GEMM of 216 tiles becomes 864
 //     workgroups of 64 k-blocks; partial accumulators meet in a workspace and the LAST arrival of a tile (ticket) sums them
 //     in split order -- deterministic -- and runs the fused epilogue (LayerScale-residual, q|k|v planes, SwiGLU + quantise);
@@ -20,8 +19,8 @@ namespace {
 
 struct Plan {
   int cfg, kb, ksplit;
-  int stages = 3;      // ring depth: 3 or 6 stages (the weights of a one-image GEMM come from HBM: bytes in flight are what
-};                     // the launch waits for)
+  int stages = 3;      // ring depth: 3 or 6 stages
+};
 
 // tile configurations: id -> (MI, NI, WM, WN); BM = 32 MI WM, BN = 32 NI WN
 constexpr int NCFG = 7;
