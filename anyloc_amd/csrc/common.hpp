@@ -90,6 +90,7 @@ enum Option {
   OPT_H3S_STAGES,        // ring depth: 3 or 6 (0 = the plan table)
   OPT_H3S_MASK,          // which GEMMs the three overrides apply to: bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 others
   OPT_H3S_ENABLE,        // 1 = small-M plans (default), 0 = the round-3 small-batch kernels (64x64 two-wave tiles, no split-K)
+  OPT_H3_PATCH,          // fp16 mode: patch embedding on the two-term fp16 GEMM (1, default) or the fp32 MFMA GEMM (0)
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -229,6 +230,7 @@ struct H3Problem {
   int ksplit, kper;
   float* sk_part; unsigned* sk_tickets;
   int kind;                                 // which block GEMM this is (H3_KIND_*: plan table / option h3s_mask); 0 = other
+  const float* pos; int patches;            // EPI_PATCH: position table [patches + 1, N]; row b * patches + p -> C row b * (patches + 1) + 1 + p
   // EPI_QKV_PLANES: N = 3 * heads * 64; see QkvPlanes below
   unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
   // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])

@@ -588,6 +588,9 @@ int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
   switch (epilogue) {
     case EPI_STORE: return dispatch_h3<EPI_STORE>(p, stream);
     case EPI_GELU: return dispatch_h3<EPI_GELU>(p, stream);
+    case EPI_PATCH:
+      ANYLOC_CHECK_ARG(p.pos && p.patches > 0 && p.M % p.patches == 0, "gemm_h3: PATCH needs pos and M = batch * patches");
+      return dispatch_h3<EPI_PATCH>(p, stream);
     case EPI_LS_RESID: {
       ANYLOC_CHECK_ARG(p.gamma && p.resid, "gemm_h3: LS_RESID needs gamma and resid");
       H3Problem q = p;

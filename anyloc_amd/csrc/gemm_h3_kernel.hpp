@@ -563,11 +563,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
         const int64_t row = wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
         if (row < p.M) {
           const float ai = p.a_inv[row];
+          int64_t orow = row, prow = 0;
+          if constexpr (EPI == EPI_PATCH) {                // patch p of image b -> token row b * T + 1 + p, + pos[1 + p]
+            const int64_t img = row / p.patches;
+            prow = row - img * p.patches + 1;
+            orow = img * (p.patches + 1) + prow;
+          }
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             if (cok[ni]) {
               const float v = acc[mi][ni][r] * (ai * sw_[ni]) + bv[ni];
-              const int64_t o = row * p.ldc + wcol0 + ni * 32;
+              const int64_t o = orow * p.ldc + wcol0 + ni * 32;
+              if constexpr (EPI == EPI_PATCH) p.C[o] = v + p.pos[prow * p.N + wcol0 + ni * 32];
+              else
               if constexpr (EPI == EPI_STORE) p.C[o] = p.accumulate ? p.C[o] + v : v;
               else if constexpr (EPI == EPI_GELU) p.C[o] = h3_gelu_erf(v);
               else p.C[o] = p.resid[o] + v * gam[ni];

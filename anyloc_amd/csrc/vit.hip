@@ -33,6 +33,14 @@ struct anyloc_vit {
   std::vector<anyloc_vit_block_h2> h2;      // optional: two-plane fp16 images + row scales of the same matrices
   std::vector<char> ffn_exact;              // per block: 1 = quantise the FFN activation against the exact row maximum
   float* ffn_looseness = nullptr;           // telemetry target (device [depth]) or null
+  unsigned char* patch_w2 = nullptr;        // fp16 mode: two-plane image + row scales of patch_w, built (and owned) by
+  float* patch_inv = nullptr;               // anyloc_vit_attach_h2
+  void drop_patch_image() {
+    if (patch_w2) (void)hipFree(patch_w2);
+    if (patch_inv) (void)hipFree(patch_inv);
+    patch_w2 = nullptr;
+    patch_inv = nullptr;
+  }
 };
 
 namespace anyloc {
@@ -56,7 +64,7 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   w.x = a.take<float>(M * c.dim);
   w.y = a.take<float>(M * c.dim);
   // fp32 [M, 3D], or the im2col patches, or (fp16 mode) the q | k | v tiles of attention_h3: rows padded to 32
-  const int64_t qkv_elems = std::max<int64_t>((M + 31) / 32 * 32 * 3 * c.dim, batch * np * c.patch_k_pad);
+  const int64_t qkv_elems = std::max<int64_t>((M + 31) / 32 * 32 * 3 * c.dim, batch * np * ((c.patch_k_pad + 15) / 16 * 16));
   w.qkv = a.take<float>(qkv_elems);
   w.h = a.take<float>(M * c.ffn_hidden);
   w.a3 = a.take<unsigned char>(x3_bytes(M, c.dim));
@@ -222,6 +230,7 @@ int anyloc_vit_attach_x3(anyloc_vit_t* h, const anyloc_vit_block_x3* blocks) {
 
 int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
   ANYLOC_CHECK_ARG(h, "vit_attach_h2: null handle");
+  h->drop_patch_image();
   if (!blocks) {
     h->h2.clear();
     return ANYLOC_OK;
@@ -237,6 +246,28 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
                      b.fc1_layout);
   }
   h->h2.assign(blocks, blocks + h->cfg.depth);
+  // the patch-embedding weights [dim, patch_k_pad] as an operand image of the same GEMM, the contraction zero-padded to
+  // whole 16-element k-blocks (one-off, on the null stream)
+  {
+    const int64_t D = h->cfg.dim, K0 = h->cfg.patch_k_pad, Kp = (K0 + 15) / 16 * 16;
+    float* padded = nullptr;
+    ANYLOC_HIP(hipMalloc(reinterpret_cast<void**>(&padded), sizeof(float) * D * Kp));
+    ANYLOC_HIP(hipMemset(padded, 0, sizeof(float) * D * Kp));
+    ANYLOC_HIP(hipMemcpy2D(padded, sizeof(float) * Kp, h->patch_w, sizeof(float) * K0, sizeof(float) * K0, D, hipMemcpyDeviceToDevice));
+    int rc = ANYLOC_OK;
+    if (hipMalloc(reinterpret_cast<void**>(&h->patch_w2), h2_bytes(D, Kp)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->patch_inv), sizeof(float) * D) != hipSuccess) {
+      set_error("vit_attach_h2: out of device memory for the patch-embedding image");
+      rc = ANYLOC_ERR_HIP;
+    }
+    if (rc == ANYLOC_OK) rc = split_h2(padded, Kp, D, Kp, h->patch_w2, h->patch_inv, nullptr);
+    if (rc == ANYLOC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = ANYLOC_ERR_HIP;
+    (void)hipFree(padded);
+    if (rc != ANYLOC_OK) {
+      h->drop_patch_image();
+      return rc;
+    }
+  }
   return ANYLOC_OK;
 }
 
@@ -253,7 +284,10 @@ int anyloc_vit_block_ffn_exact(anyloc_vit_t* h, int32_t layer, int32_t exact) {
   return ANYLOC_OK;
 }
 
-void anyloc_vit_destroy(anyloc_vit_t* h) { delete h; }
+void anyloc_vit_destroy(anyloc_vit_t* h) {
+  if (h) h->drop_patch_image();
+  delete h;
+}
 
 size_t anyloc_vit_workspace_bytes(const anyloc_vit_t* h, int64_t batch, int64_t img_h, int64_t img_w) {
   if (!h || batch <= 0 || img_h < h->cfg.patch || img_w < h->cfg.patch) return 0;
@@ -296,8 +330,23 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
 
   // ---- patch embedding: conv 14x14 stride 14 == GEMM over gathered patches, + bias + pos ----
   float* col = w.qkv;
-  ANYLOC_TRY(im2col(img, col, batch, (int)img_h, (int)img_w, c.patch, c.patch_k_pad, stream));
-  {
+  const bool patch_h3 = h3m && h->patch_w2 && option(OPT_H3_PATCH) != 0;
+  const int kp = patch_h3 ? (c.patch_k_pad + 15) / 16 * 16 : c.patch_k_pad;    // fp16 mode: whole 16-element k-blocks
+  ANYLOC_TRY(im2col(img, col, batch, (int)img_h, (int)img_w, c.patch, kp, stream));
+  if (patch_h3) {
+    // fp16 mode: the gathered patches are quantised like every other operand (row maximum -> power-of-two scale)
+    ANYLOC_TRY(split_h2(col, kp, batch * np, kp, w.a3, w.ainv, stream));
+    H3Problem g{};
+    g.A2 = w.a3; g.RA = batch * np; g.a_inv = w.ainv;
+    g.W2 = h->patch_w2; g.RW = D; g.w_inv = h->patch_inv;
+    g.C = w.x; g.ldc = D;
+    g.M = batch * np; g.N = D; g.K16 = kp / 16;
+    g.bias = h->patch_b;
+    g.pos = pos;
+    g.patches = np;
+    g.tag = "vit_patch_embed_gemm";
+    ANYLOC_TRY(gemm_h3(g, EPI_PATCH, stream));
+  } else {
     GemmProblem g{};
     g.A = col; g.lda = c.patch_k_pad;
     g.W = h->patch_w; g.ldw = c.patch_k_pad;

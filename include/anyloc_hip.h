@@ -77,6 +77,8 @@ const char* anyloc_last_error(void);
  *                                     under a running power-of-two row scale (three fp16 MFMA products, csrc/scores_h3.hip),
  *                                     1 = three bf16 planes (six bf16 products, csrc/scores_x6.hip), 0 = fp32 MFMA
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
+ *   h3_patch (1)                      ANYLOC_VIT_SPLIT_FP16: the patch embedding runs on the two-term fp16 GEMM too (weights quantised by
+ *                                     anyloc_vit_attach_h2); 0 = on the fp32 matrix-core GEMM
  *   h3s_enable (1)                    small-M plans of the two-term fp16 GEMM (csrc/gemm_h3s.hip: tile shape, ring depth and split-K
  *                                     factor per GEMM shape when a call has one or a few images); 0 = the round-3 small-batch kernels
  *   h3s_cfg (-1) h3s_ksplit (0) h3s_kb (0) h3s_stages (0) h3s_mask (31)

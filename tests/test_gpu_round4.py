@@ -277,3 +277,29 @@ def test_reference_call_pattern_driver_through_anyloc_amd_run(tmp_path):
     assert 0.5 <= rec[0] <= rec[1] <= rec[2] <= 1.0, outs[0][-800:]    # query q depicts place q (random-weight ViT-S: mostly found)
     pts = [f for dp, _, fs in os.walk(tmp_path / "cache") for f in fs if f.endswith(".pt")]
     assert "c_centers.pt" in pts and any(f.endswith("_r.pt") for f in pts) and any(f.endswith("_l.pt") for f in pts)
+
+
+@pytest.mark.parametrize("name,batch,hw", [("dinov2_vits14", 1, (224, 322)), ("dinov2_vitg14", 3, (322, 322))])
+def test_patch_embedding_on_the_fp16_gemm_agrees_with_the_fp32_gemm(name, batch, hw):
+    """fp16 mode runs the patch embedding (conv 14x14 / 14 = a GEMM over 588-element patches, zero-padded to 592) on the
+    two-term fp16 GEMM, the gathered patches and the weights quantised like every other operand (22 bits).  Against the fp32
+    matrix-core GEMM (option h3_patch = 0) the layer-0 tokens -- the embedding after one block -- agree to 2e-6 of their
+    scale, for unnormalised pixel values too (0 .. 255: the row scale is a power of two of the row's own maximum), and the
+    result is the same run to run."""
+    import utilities
+    from anyloc_amd import ops, synth, weights
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 7, device=DEV, depth=1))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 0, "token", device=DEV)
+        ext.dino_model.ffn_check_every = 0
+        g = torch.Generator().manual_seed(5)
+        for img in (torch.randn(batch, 3, *hw, generator=g), torch.rand(batch, 3, *hw, generator=g) * 255.0):
+            img = img.to(DEV)
+            with ops.options(h3_patch=0):
+                want = ext(img).clone()
+            got = ext(img).clone()
+            assert torch.isfinite(got).all()
+            assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+            assert torch.equal(got, ext(img))
+    finally:
+        weights.unregister_state_dict(name)
