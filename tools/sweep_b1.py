@@ -2,7 +2,7 @@
 every (tile configuration, k-blocks per ring stage, split-K factor) forced through the h3s_* options; per GEMM kind the
 time per launch from the library's HIP-event scopes, and the tokens' distance from the round-3 kernels (h3s_enable = 0).
 
-    python tools/sweep_b1.py [batches, e.g. 1,2,4] > gpurun_out/b1_plan_sweep.log
+    python tools/sweep_b1.py [batches, e.g. 1,2,4] [configurations, e.g. 2,4] > gpurun_out/b1_plan_sweep.log
 """
 import os
 import sys
@@ -23,6 +23,7 @@ BATCHES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 els
 TAGS = {"qkv": "vit_qkv_gemm", "proj": "vit_proj_gemm", "fc1": "vit_w12_gemm", "fc2": "vit_fc2_gemm"}
 CFG_NAMES = ["64x64/2w", "64x128/2w(64x64)", "64x128/4w(32x64)", "64x128/2w(32x128)", "128x128/4w", "64x256/4w(64x64)",
              "64x256/4w(32x128)"]
+CFGS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else tuple(range(len(CFG_NAMES)))
 
 
 def run(img, n):
@@ -57,7 +58,7 @@ for B in BATCHES:
     print(f"B={B} default plans:   {wall1*1e3:.3f} ms/forward  " + "  ".join(f"{k}={v:.1f}us" for k, v in per1.items()) +
           f"  max|dtok|={float((tok1 - tok0).abs().max()):.2e}", flush=True)
     best = {k: (per0[k], "round3") for k in per0}
-    for cfg in range(7):
+    for cfg in CFGS:
         for kb in (1, 2, 4):
             for st in (3, 6):
                 for ks in (1, 2, 3, 4):
