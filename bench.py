@@ -149,7 +149,9 @@ def respawn_under_torchrun(args):
 def init_ranks(args):
     """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE); backend "nccl" = RCCL over xGMI.
     ``ANYLOC_DIST_BACKEND=gloo`` (tests on a one-GPU box) runs the same code with the collectives staged through the
-    host; ranks then share the visible GPUs round-robin."""
+    host; ranks then share the visible GPUs round-robin.  ``ANYLOC_DIST_FORCE=1`` creates the process group at N = 1 too:
+    the sharded step (all-gather of the queries, per-shard top-k, gather + merge) then runs on REAL RCCL with one rank --
+    what a one-GPU box can execute of the N > 1 path (tests/test_gpu_round4.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -158,9 +160,10 @@ def init_ranks(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ANYLOC_DIST_FORCE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("ANYLOC_DIST_BACKEND", "nccl")
         n_vis = torch.cuda.device_count()
@@ -209,7 +212,7 @@ def main_config3(args):
     results = []
 
     def step():
-        if world == 1:
+        if dist is None:
             d, i = retrieval.search(db, qu, TOPK)
             results.append((d, i))
         else:
@@ -335,7 +338,7 @@ def main():
         imgs = qu_img[blk * B:(blk + 1) * B]
         tokens = ext(imgs)                                   # [B,529,1536] on device (ext: the current mode's extractor)
         q = vlad.generate_multi(tokens)                      # [B,49152]
-        if world == 1:
+        if dist is None:
             d, idx = retrieval.search(db, q, TOPK)           # normalise + top-k, device tensors
             results.append((d, idx, q))
         else:
@@ -390,7 +393,7 @@ def main():
     images = steps * B * world
     value = images / elapsed
     # Recall@1 of the timed queries (rank 0's share): query i depicts place i of its own rank
-    if world == 1:
+    if dist is None:
         idx_all = torch.cat([r[1] for r in timed_results]).cpu().numpy()
         gt_timed = np.empty(len(idx_all), dtype=object)
         for n, i in enumerate(range(warm, total_steps)):
@@ -425,7 +428,7 @@ def main():
                                "322x322, top-20 vs 10k-row database per GPU", "batch_per_gpu": B, "gemm": args.gemm,
                    "images_per_step": B * world, "db_rows_per_gpu": N_DB, "vlad_dim": K_CLUSTERS * 1536,
                    "weights": "random-init, hub layout (no checkpoint available offline)",
-                   "parallelism": f"dp{world}+db-shard{world}" if world > 1 else "single"},
+                   "parallelism": f"dp{world}+db-shard{world}" if dist is not None else "single"},
         "recall": rec, "setup_s": round(t_setup, 1), "roofline": roofline,
     }
 
@@ -477,7 +480,7 @@ def main():
         out["modes"] = modes
 
     failed = None
-    if world == 1:
+    if dist is None:
         # identity of the retrieval of EVERY timed query with an exact (float64) flat search over the whole database
         rchk = retrieval_identity(timed_results, db, gt_timed)
         out["retrieval_check"] = rchk

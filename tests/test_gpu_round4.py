@@ -303,3 +303,72 @@ def test_patch_embedding_on_the_fp16_gemm_agrees_with_the_fp32_gemm(name, batch,
             assert torch.equal(got, ext(img))
     finally:
         weights.unregister_state_dict(name)
+
+
+@pytest.mark.parametrize("workload", ["config2", "config3"])
+def test_sharded_step_on_real_rccl_with_one_rank(workload):
+    """``ANYLOC_DIST_FORCE=1 python bench.py --gpus 1``: the process group is created with backend "nccl" (= RCCL) although
+    there is one rank, and the step takes the SHARDED route -- all-gather of the query VLADs, per-shard top-k on the HIP
+    kernels, gather of the [Q, k] lists to rank 0, host merge (retrieval.sharded_search) -- so every collective of the
+    N > 1 path (device tensors, their dtypes, the barrier + MAX-over-ranks timing) executes on real RCCL, which a one-GPU
+    box otherwise never does.  Recalls / planted neighbours as in the single-process run."""
+    env = dict(os.environ, ANYLOC_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ANYLOC_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"]
+    if workload == "config2":
+        cmd += ["--batch", "8", "--no-cpu-baseline", "--no-modes", "--no-stages"]
+    else:
+        cmd += ["--workload", "config3", "--queries", "300", "--shard-rows", "4096"]
+    def run(e):
+        res = subprocess.run(cmd, env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        return json.loads(lines[0])
+    out = run(env)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    if workload == "config2":
+        assert out["config"]["parallelism"] == "dp1+db-shard1"
+        plain = run({k: v for k, v in env.items() if k != "ANYLOC_DIST_FORCE"})  # the single-process route: same recalls
+        assert plain["config"]["parallelism"] == "single" and plain["recall"] == out["recall"]
+    else:
+        assert out["config"]["parallelism"] == "db-shard1" and out["planted_neighbours_found"] is True
+
+
+_RCCL_ONE_RANK_JOB = r"""
+import numpy as np, torch, torch.distributed as dist
+from anyloc_amd import kmeans as hk, retrieval, synth
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(0)
+db, qu = torch.randn(1501, 4096, generator=g).to(dev), torch.randn(13, 4096, generator=g).to(dev)
+d, i = retrieval.sharded_search(db, 0, qu, 7)                       # all-gather of the queries, top-k, gather, host merge
+d_ref, i_ref = retrieval.search(db, qu, 7)
+assert np.array_equal(i, i_ref.cpu().numpy()) and np.allclose(d, d_ref.cpu().numpy(), atol=1e-6)
+x = synth.clustered_tokens(1, 3000, 384, n_modes=6, seed=2, noise=0.5)[0].to(dev)
+np.random.seed(11)
+km = hk.KMeans(6, mode="cosine", process_group=dist.group.WORLD)    # sharded init (broadcast + all-reduce), all-reduce per iteration
+km.fit(x)
+np.random.seed(11)
+flat = hk.KMeans(6, mode="cosine")
+flat.fit(x)
+assert km.n_iter_ == flat.n_iter_ and torch.equal(km.centroids, flat.centroids)
+assert torch.equal(km.predict(x), flat.predict(x))
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+def test_sharded_search_and_sharded_kmeans_on_real_rccl_with_one_rank():
+    """The library-level N > 1 entry points -- ``retrieval.sharded_search`` and ``KMeans(process_group=...)`` -- on a process
+    group whose backend IS RCCL (one rank, cuda:0): broadcast, all-reduce, all-gather and gather of device tensors all run,
+    and the results are those of the unsharded calls (bitwise for k-means: one shard = the flat fit)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK_JOB], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "RCCL-ONE-RANK-OK" in res.stdout, (res.stdout[-1500:], res.stderr[-3000:])
