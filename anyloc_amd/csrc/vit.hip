@@ -67,7 +67,8 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   const int64_t qkv_elems = std::max<int64_t>((M + 31) / 32 * 32 * 3 * c.dim, batch * np * ((c.patch_k_pad + 15) / 16 * 16));
   w.qkv = a.take<float>(qkv_elems);
   w.h = a.take<float>(M * c.ffn_hidden);
-  w.a3 = a.take<unsigned char>(x3_bytes(M, c.dim));
+  // (fp16 mode also quantises the gathered patches into a3: [batch * np, patch_k_pad rounded up to 16] as two fp16 planes)
+  w.a3 = a.take<unsigned char>(std::max(x3_bytes(M, c.dim), h2_bytes(batch * np, (c.patch_k_pad + 15) / 16 * 16)));
   w.h3 = a.take<unsigned char>(x3_bytes(M, c.ffn_hidden));
   w.ainv = a.take<float>(M);
   w.hinv = a.take<float>(M);
