@@ -497,8 +497,9 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   }
   const int rpw = (forced == 1 || forced == 2 || forced == 4) ? (int)forced : (rows < option(OPT_LN_SMALL_ROWS) ? 1 : 2);
   // two rows per wave: EIGHT waves per block (option ln_waves = 8, default) -- 16 rows per block, i.e. 512-byte runs per store
-  // instruction instead of the 256-byte runs of four waves, at the register count of two rows per wave (B = 61: 5.5 -> ? ms
-  // per step; four rows per wave on four waves: 6.4, one row per wave: 11.1 -- the run length is what the stores want)
+  // instruction instead of the 256-byte runs of four waves, at the register count of two rows per wave (B = 61: 5.65 -> 5.55 ms
+  // per step; four rows per wave on four waves: 6.4, one row per wave: 11.1, sixteen waves = 32 rows per block: 6.2 -- a bare
+  // copy in this pattern takes 80 us per call against LayerNorm's 87-89: tools/micro/ln_store_pattern.hip)
   const int nw = (rpw == 2 && option(OPT_LN_WAVES) == 8) ? 8 : 4;
   const dim3 grid((unsigned)((rows + nw * rpw - 1) / (nw * rpw)));
 #define ANYLOC_LN_H2_R(NVV, RPWV, NWV)                                                                                   \
