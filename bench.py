@@ -837,7 +837,29 @@ def stage_kmeans(dev, check):
            "frac": round(n * d * 4 / (k_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
            "achieved_wall": round(n * d * 4 / el / 1e12, 3), "kernel_ms_note": KERNEL_MS_NOTE, "kernels_ms": kern, "kernels_ms_first_iteration": kern1,
            "rows_counted": float(counts.sum()), "oracle_ok": None}
+    # the whole fit through the class the reference touches (fpk surface: init rows from NumPy's global RNG, <= 100 iterations,
+    # tol 1e-4; anyloc_amd/kmeans.py): iterations to converge and wall time
+    from anyloc_amd import kmeans as hk
+    np.random.seed(42)
+    km = hk.KMeans(k, mode="cosine")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km.fit(x)
+    torch.cuda.synchronize()
+    res["fit"] = {"iterations": int(km.n_iter_), "seconds": round(time.perf_counter() - t0, 3), "max_iter": km.max_iter, "tol": km.tol,
+                  "modes_recovered": int((torch.nn.functional.normalize(km.centroids, dim=1) @ modes.T).max(0)[0].gt(0.99).sum())}
     if check:
+        # the whole fit on the first 200 000 rows against the fpk restatement run on the host from the same drawn rows:
+        # same number of iterations, same centroids
+        from oracle import vlad_ref as _vr
+        m2 = 200000
+        draw = np.random.RandomState(5).choice(m2, size=[k], replace=False)
+        g_fit = hk.KMeans(k, mode="cosine")
+        g_fit.fit(x[:m2], centroids=x[:m2][torch.as_tensor(draw, device=dev)])
+        c_ref, it_ref = _vr.kmeans_fit(x[:m2].cpu(), k, norm_descs=False, mode="cosine", init_idx=draw)
+        cerr = float((g_fit.centroids.cpu() - c_ref).abs().max())
+        res["fit"].update({"oracle_rows": m2, "oracle_iterations": int(it_ref), "subset_iterations": int(g_fit.n_iter_),
+                           "oracle_centroid_max_abs_diff": cerr, "oracle_ok": bool(int(it_ref) == int(g_fit.n_iter_) and cerr < 1e-5)})
         # the same kernel on the first 20 000 rows against the fpk restatement (labels by cosine arg-max, sums of the rows)
         from oracle import vlad_ref
         m = 20000
@@ -850,7 +872,7 @@ def stage_kmeans(dev, check):
         tie_only = bool(((top2[:, 0] - top2[:, 1])[flips] < 1e-6).all()) if flips.any() else True
         s_r = torch.zeros(k, d, dtype=torch.float64).index_add_(0, l_g.cpu(), xc.double())
         err = float((s_g.cpu().double() - s_r).abs().max() / s_r.abs().max())
-        res.update({"oracle_ok": bool(tie_only and err < 1e-5 and float(c_g.sum()) == m), "oracle_rows": m,
+        res.update({"oracle_ok": bool(tie_only and err < 1e-5 and float(c_g.sum()) == m and res["fit"]["oracle_ok"]), "oracle_rows": m,
                     "oracle_label_flips": int(flips.sum()), "oracle_sums_rel_err": err})
     del x
     torch.cuda.empty_cache()
