@@ -74,6 +74,12 @@ class HipDinoV2:
     """Device-resident DINOv2 weights + the C handle of the HIP forward."""
 
     def __init__(self, name, state_dict, device, max_layer=None, gemm=None):
+        # the weight images are quantised by HIP launches and the library allocates the patch-embedding image itself: all of
+        # it on the MODEL's device, whatever the current one is
+        with _on_device(device):
+            self._build(name, state_dict, device, max_layer, gemm)
+
+    def _build(self, name, state_dict, device, max_layer, gemm):
         """``gemm``: "x6" runs the block GEMMs as six bf16 MFMA products of exact three-way bf16 splits
         (csrc/gemm_x6.hip); "h3" as three fp16 MFMA products of row-scaled two-term fp16 splits (csrc/gemm_h3.hip);
         both have fp32-level accuracy; "f32" keeps them on the fp32 MFMA kernel.  Env ANYLOC_GEMM sets the default."""
