@@ -91,6 +91,7 @@ enum Option {
   OPT_H3S_MASK,          // which GEMMs the three overrides apply to: bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 others
   OPT_H3S_ENABLE,        // 1 = small-M plans (default), 0 = the round-3 small-batch kernels (64x64 two-wave tiles, no split-K)
   OPT_H3_PATCH,          // fp16 mode: patch embedding on the two-term fp16 GEMM (1, default) or the fp32 MFMA GEMM (0)
+  OPT_TOPK_FEWQ_QDMA,    // few-query scores on fp16 planes: 1 = queries pre-split once, DMA'd into LDS per slab; 0 = split per slab
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -186,8 +187,11 @@ int scores_fewq_x6(const float* db, int64_t ldd, int64_t rows, const float* quer
                    int ksplit, float* part, float* rsq_part, hipStream_t stream);
 // the same pass on two fp16 planes under a running power-of-two row scale: three fp16 MFMA products (scores_h3.hip); qinv[nq] =
 // 2^-e of the query rows (row_scales_h2)
+size_t fewq_query_image_bytes(int64_t dim);
+int fewq_query_image(const float* queries, int64_t ldq, int64_t nq, const float* qinv, int64_t dim, unsigned char* qimg,
+                     hipStream_t stream);
 int scores_fewq_h3(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, const float* qinv,
-                   int64_t kslice, int ksplit, float* part, float* rsq_part, hipStream_t stream);
+                   const unsigned char* qimg, int64_t kslice, int ksplit, float* part, float* rsq_part, hipStream_t stream);
 
 // split-bf16 GEMM on three-plane bf16 operand images (gemm_x6.hip)
 struct X6Problem {

@@ -21,10 +21,14 @@
 // scales are applied in the epilogue) and the partial row sums of squares rsq[s][row] from the fp32 values as staged.
 // Per 32-k slab and workgroup: database values global -> registers (two slabs ahead) -> amax over the row's 8 staging lanes
 // (three DPP max) -> scale, split ONCE by the staging lane (the bf16 kernel splits at every fragment read: 88 vector
-// instructions per wave and slab) -> LDS as two fp16 planes -> 4 + 8 fragment reads, 12 MFMAs.
+// instructions per wave and slab) -> LDS as two fp16 planes -> 4 + 8 fragment reads, 12 MFMAs.  The QUERIES are split once per
+// call (fewq_query_image_kernel: per slab the exact bytes of a stage's B region) and reach LDS by DMA -- 36 of the ~240 vector
+// instructions per wave and slab and 16 registers less, same bits: 0.413-0.418 -> 0.400-0.403 ms at the bench shape,
+// 4.9 TB/s (option topk_fewq_qdma = 0: the lanes split them per slab; profiles/r04_fewq_qdma.log).
 #include <type_traits>
 
 #include "common.hpp"
+#include "tile_order.hpp"
 
 namespace anyloc {
 
@@ -61,9 +65,14 @@ __device__ __forceinline__ void sh_pack2(float a, float b, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// QDMA: the queries arrive pre-split (fewq_query_image_kernel: per 32-k slab the two fp16 planes of the 64 query rows in
+// exactly the bytes of a stage's B region, 10 KiB) and go global -> LDS by ten 1-KiB DMA pieces per slab -- no registers, no
+// vector instructions; !QDMA: the round-4 first version, queries split by the staging lanes like the database
+template <bool QDMA>
 __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __restrict__ db, int64_t ldd, int64_t rows,
                                                                 const float* __restrict__ qu, int64_t ldq, int nq,
                                                                 const float* __restrict__ qinv, int64_t kslice,
+                                                                const unsigned char* __restrict__ qimg,
                                                                 float* __restrict__ part, float* __restrict__ rsq_part) {
   constexpr int LPR = SH_BK / 4, RPP = 256 / LPR, A_LD = SH_BM / RPP, B_LD = SH_BN / RPP;   // 8 lanes per row, 32 rows per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char sh_smem[];
@@ -74,8 +83,10 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __r
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(db + m0 * ldd + sl * kslice), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(qu + sl * kslice), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = QDMA
+      ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(qimg + sl * (kslice / SH_BK) * (int64_t)(2 * SH_B_PLANE)), 0,
+                                          0x7fffffff, 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qu + sl * kslice), 0, 0x7fffffff, 0x00020000);
   unsigned a_off[A_LD], b_off[B_LD];
   float b_scale[B_LD];                                   // 2^e of the query row (0 for the padding rows: their planes are zero)
 #pragma unroll
@@ -109,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) ra[S][i] = sh_load16(a_rsrc, a_off[i], kb);
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) rb[S][i] = sh_load16(b_rsrc, b_off[i], kb);
+    for (int i = 0; i < B_LD; ++i)
+      if constexpr (!QDMA) rb[S][i] = sh_load16(b_rsrc, b_off[i], kb);
   };
   // register set S -> LDS stage: amax of the row's slab, running scale, split, planes; `real` = 0.0f for the copy of the last
   // slab the unconditional prefetch brings in past the end (same values: no new maximum; its squares are not counted again)
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __r
       *reinterpret_cast<sh_u32x2*>(ad) = sh_u32x2{h0, h1};
       *reinterpret_cast<sh_u32x2*>(ad + SH_A_PLANE) = sh_u32x2{l0, l1};
     }
+    if constexpr (!QDMA)
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const f32x4 q = rb[S][i];
@@ -203,26 +216,54 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __r
   if (tid < 8) reinterpret_cast<int*>(sh_smem + (tid >> 2) * SH_STAGE + SH_FAC + SH_BM * 4)[tid & 3] = 0;
   __syncthreads();
   const int last = nk - 1;
+  // QDMA: slab kt's query planes -> the B region of `stage`: pieces w, w + 4, w + 8 (< 10) of 1 KiB by wave w.  Issued BEFORE
+  // the half-step's database fetch, so "at most A_LD vector-memory operations outstanding" means the pieces have landed
+  // while the fetch stays in flight (the counter retires in order); meet() = that wait + the LDS writes + the barrier.
+  auto dma_b = [&](int kt, int stage) {
+    if constexpr (QDMA) {
+      unsigned char* dst = sh_smem + stage * SH_STAGE + 2 * SH_A_PLANE;
+      const unsigned so = (unsigned)kt * (unsigned)(2 * SH_B_PLANE);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int piece = __builtin_amdgcn_readfirstlane(wave) + 4 * c;   // (scalar: a real branch, not an exec mask)
+        if (piece < (2 * SH_B_PLANE) / 1024) dma16_to_lds(b_rsrc, dst + piece * 1024, (unsigned)(piece * 1024 + lane * 16), so);
+      }
+    }
+  };
+  auto meet = [&]() {
+    if constexpr (QDMA) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_LD) : "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+  };
+  static_assert((2 * SH_B_PLANE) % 1024 == 0 && (2 * SH_B_PLANE) / 1024 <= 12, "query planes of a slab: whole 1-KiB pieces, <= 3 per wave");
+  dma_b(0, 0);
   fetch(0, S0{});
   fetch(min(1, last), S1{});
   stash(S0{}, 0, 1.0f);
+  if constexpr (QDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
+    dma_b(min(kt + 1, last), 1);
     fetch(min(kt + 2, last), S0{});
     __builtin_amdgcn_sched_barrier(0);
     contract(0);
     __builtin_amdgcn_sched_barrier(0);
     stash(S1{}, 1, kt + 1 < nk ? 1.0f : 0.0f);
-    __syncthreads();
+    meet();
     if (kt + 1 < nk) {
+      dma_b(min(kt + 2, last), 0);
       fetch(min(kt + 3, last), S1{});
       __builtin_amdgcn_sched_barrier(0);
       contract(1);
       __builtin_amdgcn_sched_barrier(0);
       stash(S0{}, 0, kt + 2 < nk ? 1.0f : 0.0f);
-      __syncthreads();
+      meet();
     }
   }
+  if constexpr (QDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- partial row sums of squares (the 8 staging lanes of a row hold its pieces) and the rows' final 2^-e ----
   float* einv = reinterpret_cast<float*>(sh_smem + SH_FAC);     // (stage 0's factor table: nobody contracts any more)
@@ -255,10 +296,44 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __r
   }
 }
 
+// queries [nq <= 64, dim] fp32 + their 2^-e -> per 32-k slab the bytes of a stage's B region: [plane][64 rows][SH_ROW] (rows
+// past nq: zeros; the 16 pad bytes of a row are never read)
+__global__ __launch_bounds__(256) void fewq_query_image_kernel(const float* __restrict__ qu, int64_t ldq, int nq,
+                                                               const float* __restrict__ qinv, int64_t dim,
+                                                               unsigned char* __restrict__ qimg) {
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (slab, row, k-quad of 4)
+  const int kq = (int)(item & 7), row = (int)((item >> 3) & 63);
+  const int64_t slab = item >> 9;
+  if (slab >= dim / SH_BK) return;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  float sc = 0.f;
+  if (row < nq) {
+    v = *reinterpret_cast<const f32x4*>(qu + (int64_t)row * ldq + slab * SH_BK + 4 * kq);
+    sc = __uint_as_float((254u << 23) - __float_as_uint(qinv[row]));      // 2^e from the stored 2^-e
+  }
+  unsigned h0, l0, h1, l1;
+  sh_pack2(v[0] * sc, v[1] * sc, h0, l0);
+  sh_pack2(v[2] * sc, v[3] * sc, h1, l1);
+  unsigned char* dst = qimg + slab * (int64_t)(2 * SH_B_PLANE) + row * SH_ROW + kq * 8;
+  *reinterpret_cast<sh_u32x2*>(dst) = sh_u32x2{h0, h1};
+  *reinterpret_cast<sh_u32x2*>(dst + SH_B_PLANE) = sh_u32x2{l0, l1};
+}
+
 }  // namespace
 
+size_t fewq_query_image_bytes(int64_t dim) { return (size_t)(dim / SH_BK) * (size_t)(2 * SH_B_PLANE); }
+
+int fewq_query_image(const float* queries, int64_t ldq, int64_t nq, const float* qinv, int64_t dim, unsigned char* qimg,
+                     hipStream_t stream) {
+  ANYLOC_CHECK_ARG(queries && qinv && qimg && nq > 0 && nq <= 64 && dim % SH_BK == 0 && ldq % 4 == 0, "fewq_query_image: bad arguments");
+  const int64_t items = dim / SH_BK * 512;
+  hipLaunchKernelGGL(fewq_query_image_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, queries, ldq, (int)nq, qinv,
+                     dim, qimg);
+  return launch_status("fewq_query_image_kernel");
+}
+
 int scores_fewq_h3(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, const float* qinv,
-                   int64_t kslice, int ksplit, float* part, float* rsq_part, hipStream_t stream) {
+                   const unsigned char* qimg, int64_t kslice, int ksplit, float* part, float* rsq_part, hipStream_t stream) {
   ANYLOC_CHECK_ARG(db && queries && qinv && part && rsq_part, "scores_fewq_h3: null operand");
   ANYLOC_CHECK_ARG(rows > 0 && nq > 0 && nq <= 64 && kslice > 0 && kslice % 32 == 0 && ksplit >= 1 && ksplit < 65536,
                    "scores_fewq_h3: needs <= 64 queries, a K slice that is a multiple of 32 and 1 <= ksplit < 65536");
@@ -270,14 +345,21 @@ int scores_fewq_h3(const float* db, int64_t ldd, int64_t rows, const float* quer
   const int64_t tiles = (rows + SH_BM - 1) / SH_BM;
   ANYLOC_CHECK_ARG(tiles < (1ll << 31), "scores_fewq_h3: grid too large");
   ProfScope prof("topk_scores_gemm", stream, 2.0 * rows * 64 * kslice * ksplit, 4.0 * (rows + 64.0) * kslice * ksplit);
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   2 * SH_STAGE));
-    attr = true;
-  }
-  hipLaunchKernelGGL(scores_fewq_h3_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SH_STAGE, stream, db, ldd, rows,
-                     queries, ldq, (int)nq, qinv, kslice, part, rsq_part);
+  // qimg != nullptr: the queries' pre-split planes (fewq_query_image) go to LDS by DMA; nullptr: split by the staging lanes
+#define ANYLOC_FEWQ_H3(QD)                                                                                                       \
+  do {                                                                                                                           \
+    static bool attr = false;                                                                                                    \
+    if (!attr) {                                                                                                                 \
+      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_h3_kernel<QD>),                                   \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SH_STAGE));                                 \
+      attr = true;                                                                                                               \
+    }                                                                                                                            \
+    hipLaunchKernelGGL(scores_fewq_h3_kernel<QD>, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SH_STAGE, stream, db,  \
+                       ldd, rows, queries, ldq, (int)nq, qinv, kslice, qimg, part, rsq_part);                                    \
+  } while (0)
+  if (qimg) ANYLOC_FEWQ_H3(true);
+  else ANYLOC_FEWQ_H3(false);
+#undef ANYLOC_FEWQ_H3
   return launch_status("scores_fewq_h3_kernel");
 }
 

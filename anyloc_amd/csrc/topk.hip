@@ -296,7 +296,8 @@ TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim) {
   const int64_t panel = std::min<int64_t>(w.panel, std::max<int64_t>(ndb, 1));
   w.scores = a.take<float>(std::max<int64_t>(nq, 1) * panel);
   const int64_t n_qchunks = h3 ? (nq + w.q_chunk - 1) / w.q_chunk : 0;
-  w.qimg = a.take<unsigned char>(h3 ? (size_t)n_qchunks * h2_bytes(w.q_chunk, dim) : 1);
+  // (few-query fp16 path: the queries' pre-split planes, 10 KiB per 32-k slab)
+  w.qimg = a.take<unsigned char>(h3 ? (size_t)n_qchunks * h2_bytes(w.q_chunk, dim) : few_queries(nq, dim) ? fewq_query_image_bytes(dim) : 1);
   w.dimg = a.take<unsigned char>(h3 ? h2_bytes(panel, dim) : 1);
   w.qinv = a.take<float>(h3 ? nq : 64);                  // (few-query fp16 path: the <= 64 queries' row scales)
   w.dinv = a.take<float>(h3 ? panel : 1);
@@ -428,8 +429,12 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
       g.rowsq = w.rsq_part;
       const int64_t fewq = option(OPT_TOPK_FEWQ_X6);
       if (fewq == 2) {
-        if (c0 == 0) ANYLOC_TRY(row_scales_h2(queries, dim, nq, dim, w.qinv, nullptr, stream));   // the queries' row scales, once per call
-        ANYLOC_TRY(scores_fewq_h3(g.A, g.lda, pc, queries, dim, nq, w.qinv, g.K, S, w.part, w.rsq_part, stream));
+        const bool qdma = option(OPT_TOPK_FEWQ_QDMA) != 0;
+        if (c0 == 0) {                                                                 // once per call: the queries' row scales and planes
+          ANYLOC_TRY(row_scales_h2(queries, dim, nq, dim, w.qinv, nullptr, stream));
+          if (qdma) ANYLOC_TRY(fewq_query_image(queries, dim, nq, w.qinv, dim, w.qimg, stream));
+        }
+        ANYLOC_TRY(scores_fewq_h3(g.A, g.lda, pc, queries, dim, nq, w.qinv, qdma ? w.qimg : nullptr, g.K, S, w.part, w.rsq_part, stream));
       } else if (fewq != 0)
         ANYLOC_TRY(scores_fewq_x6(g.A, g.lda, pc, queries, dim, nq, g.K, S, w.part, w.rsq_part, stream));
       else

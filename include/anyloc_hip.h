@@ -76,6 +76,8 @@ const char* anyloc_last_error(void);
  *   topk_fewq_x6 (2)                  anyloc_topk with <= 64 queries, the database read once and split on the fly: 2 = two fp16 planes
  *                                     under a running power-of-two row scale (three fp16 MFMA products, csrc/scores_h3.hip),
  *                                     1 = three bf16 planes (six bf16 products, csrc/scores_x6.hip), 0 = fp32 MFMA
+ *   topk_fewq_qdma (1)                few-query fp16 scores: the queries are split into planes once per call and DMA'd into LDS per slab;
+ *                                     0 = split by the staging lanes at every slab (same bits)
  *   topk_h3 (-1)                      anyloc_topk score panels on the two-term fp16 GEMM: -1 where it pays, 0 never, 1 wherever possible
  *   h3_patch (1)                      ANYLOC_VIT_SPLIT_FP16: the patch embedding runs on the two-term fp16 GEMM too (weights quantised by
  *                                     anyloc_vit_attach_h2); 0 = on the fp32 matrix-core GEMM

@@ -200,6 +200,9 @@ def test_topk_few_queries_two_fp16_planes_running_scale(metric, norm):
             d, i = ops.topk(qd, db, k, metric, normalize_db=norm)
             d1, i1 = ops.topk(qd, db, k, metric, normalize_db=norm)
         assert torch.equal(i, i1) and torch.equal(d, d1)
+        with ops.options(topk_fewq_x6=2, topk_fewq_qdma=0):                     # queries split per slab by the staging lanes: the same bits
+            d2, i2 = ops.topk(qd, db, k, metric, normalize_db=norm)
+        assert torch.equal(i, i2) and torch.equal(d, d2)
         _check_vs_float64(d, i, qu, db, k, metric, norm)
         if norm or metric == "l2":                                              # (the raw inner product prefers the huge ramp rows)
             assert int(i[0, 0]) == 12 and int(i[0, 1]) == 5000                  # the duplicated row: lower index first

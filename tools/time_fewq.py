@@ -19,9 +19,9 @@ ndb, dim, nq = 10000, 49152, 61
 db = torch.nn.functional.normalize(torch.randn(ndb, dim, generator=g, device=dev), dim=1)
 qu = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g, device=dev), dim=1)
 ref = None
-for rep in range(3):
-    for depth in (2,):
-        with ops.options(topk_fewq_x6=2):
+for rep in range(8):
+    for depth in (0, 1):
+        with ops.options(topk_fewq_x6=2, topk_fewq_qdma=depth):
             for _ in range(3):
                 d, i = ops.topk(qu, db, 20, "ip", normalize_db=True)
             torch.cuda.synchronize()
@@ -37,5 +37,5 @@ for rep in range(3):
         same = torch.equal(d, ref[0]) and torch.equal(i, ref[1])
         ms = prof["topk_scores_gemm"]["ms"] / prof["topk_scores_gemm"]["calls"]
         total = sum(v["ms"] for v in prof.values()) / 10
-        print(f"rep {rep}: scores {ms:.4f} ms = {ndb * dim * 4 / ms * 1e-9:.2f} TB/s   whole search {total:.4f} ms   "
+        print(f"rep {rep} topk_fewq_qdma={depth}: scores {ms:.4f} ms = {ndb * dim * 4 / ms * 1e-9:.2f} TB/s   whole search {total:.4f} ms   "
               f"same bits as the first repetition: {same}", flush=True)
