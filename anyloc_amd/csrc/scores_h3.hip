@@ -24,7 +24,8 @@
 // instructions per wave and slab) -> LDS as two fp16 planes -> 4 + 8 fragment reads, 12 MFMAs.  The QUERIES are split once per
 // call (fewq_query_image_kernel: per slab the exact bytes of a stage's B region) and reach LDS by DMA -- 36 of the ~240 vector
 // instructions per wave and slab and 16 registers less, same bits: 0.413-0.418 -> 0.400-0.403 ms at the bench shape,
-// 4.9 TB/s (option topk_fewq_qdma = 0: the lanes split them per slab; profiles/r04_fewq_qdma.log).
+// 4.9 TB/s (option topk_fewq_qdma = 0: the lanes split them per slab; profiles/r04_fewq_qdma.log); with the row maxima taken on the
+// bit patterns (integer max: no canonicalising v_max_f32, the DPP moves fold into it) 0.381-0.385 ms = 5.1 TB/s.
 #include <type_traits>
 
 #include "common.hpp"
@@ -50,7 +51,11 @@ __device__ __forceinline__ f32x4 sh_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned
 }
 template <int CTRL>
 __device__ __forceinline__ float sh_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned sh_dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 __device__ __forceinline__ float sh_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }   // e in [-126, 127]
 __device__ __forceinline__ void sh_pack2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -132,11 +137,17 @@ __global__ __launch_bounds__(256, 2) void scores_fewq_h3_kernel(const float* __r
     for (int i = 0; i < A_LD; ++i) {
       const f32x4 v = ra[S][i];
       rsq[i] += real * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-      float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      am = fmaxf(am, sh_dpp<0xB1>(am));                  // quad_perm [1,0,3,2]
-      am = fmaxf(am, sh_dpp<0x4E>(am));                  // quad_perm [2,3,0,1]
-      am = fmaxf(am, sh_dpp<0x141>(am));                 // row_half_mirror: the other quad of the 8 lanes
-      const int ex = (int)((__float_as_uint(am) >> 23) & 0xff);
+      // largest magnitude of the row's slab on the BIT PATTERNS (|x| as unsigned integers order like the floats; no
+      // canonicalising v_max_f32 per operand, and the DPP moves fold into the integer max).  Row by row: taking the four rows
+      // of a lane through every reduction step together removes the DPP wait states (72 -> 12 nop cycles per two slabs) but
+      // measures 7 % SLOWER -- every row then waits for the lane's last load
+      constexpr unsigned MAG = 0x7fffffffu;
+      unsigned am = max(max(__float_as_uint(v[0]) & MAG, __float_as_uint(v[1]) & MAG),
+                        max(__float_as_uint(v[2]) & MAG, __float_as_uint(v[3]) & MAG));
+      am = max(am, sh_dpp_u<0xB1>(am));                  // quad_perm [1,0,3,2]
+      am = max(am, sh_dpp_u<0x4E>(am));                  // quad_perm [2,3,0,1]
+      am = max(am, sh_dpp_u<0x141>(am));                 // row_half_mirror: the other quad of the 8 lanes
+      const int ex = (int)(am >> 23);
       const int e_slab = ex == 0 ? 100 : max(-100, min(100, 14 - (ex - 127)));
       const int e_new = min(e_run[i], e_slab);
       const int row = r0 + RPP * i;
