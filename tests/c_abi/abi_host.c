@@ -1,0 +1,345 @@
+/*
+ * abi_host.c -- a host program in plain C (no Python, no torch) that drives libanyloc_hip.so through
+ * include/anyloc_hip.h exactly as a non-Python caller would: hipMalloc'd buffers, the *_workspace_bytes queries,
+ * a caller-owned stream, status codes + anyloc_last_error().  It is the proof that the drop-in boundary is the C ABI
+ * and not the ctypes layer above it.  Every result is compared with the C restatement of the reference's arithmetic
+ * (oracle/c/anyloc_oracle.c -- the checker, linked only into this test binary).
+ *
+ * Cases (reference lines: see the entry points in include/anyloc_hip.h):
+ *   vlad     hard-assignment VLAD of packed ragged images incl. an empty one, at the headline width (D = 1536,
+ *            K = 32: the fused one-pass kernel) and at an odd width (D = 100, K = 5: the general kernels), with and
+ *            without re-normalisation / intra-normalisation, cosine and euclidean labels
+ *   kmeans   one anyloc_kmeans_step + anyloc_kmeans_update against one fpk iteration
+ *   topk     anyloc_l2norm_rows + anyloc_topk(NORMALIZE_DB): a few queries of long rows (the split-K stream over the
+ *            database) and many queries of short rows (score panels), IP and L2, k > ndb padding, index_base
+ *   errors   a too-small workspace and a null pointer come back as status codes with a message, nothing crashes
+ *
+ * Exit code 0 = all cases agree, 1 = a mismatch or an unexpected status, 77 = no HIP device (the product has no CPU
+ * path: the program says so and stops).  One line per case on stdout, a final JSON line.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "anyloc_hip.h"
+#include "anyloc_oracle.h"
+
+static int failures = 0;
+
+#define HIP_OK(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      fprintf(stderr, "%s:%d: %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      exit(1);                                                                                \
+    }                                                                                         \
+  } while (0)
+
+#define ANYLOC_OK_OR_FAIL(call)                                                                      \
+  do {                                                                                               \
+    int s_ = (call);                                                                                 \
+    if (s_ != ANYLOC_OK) {                                                                           \
+      fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #call, s_, anyloc_last_error()); \
+      exit(1);                                                                                       \
+    }                                                                                                \
+  } while (0)
+
+/* ---- seeded data (SplitMix64 + Box-Muller): the same bytes on every run and every machine ---- */
+static uint64_t rng_state;
+static uint64_t rng_u64(void) {
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static double rng_uniform(void) { return ((double)(rng_u64() >> 11) + 0.5) / 9007199254740992.0; }
+static float rng_normal(void) {
+  return (float)(sqrt(-2.0 * log(rng_uniform())) * cos(6.283185307179586 * rng_uniform()));
+}
+
+static void* dev_alloc(size_t bytes) {
+  void* p = NULL;
+  HIP_OK(hipMalloc(&p, bytes ? bytes : 16));
+  return p;
+}
+static void* dev_from(const void* host, size_t bytes) {
+  void* p = dev_alloc(bytes);
+  if (bytes) HIP_OK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+  return p;
+}
+
+static void report(const char* name, int ok, const char* detail) {
+  printf("%-44s %s  %s\n", name, ok ? "ok  " : "FAIL", detail);
+  if (!ok) ++failures;
+}
+
+/* tokens scattered around `modes` random directions (what patch descriptors look like to k-means), rows scaled over
+   three decades so that "tokens as passed" and "re-normalised tokens" differ */
+static void clustered_rows(float* x, int64_t n, int64_t D, int modes, float noise, int scale_rows) {
+  float* m = (float*)malloc(sizeof(float) * (size_t)(modes * D));
+  for (int64_t i = 0; i < modes * D; ++i) m[i] = rng_normal();
+  for (int64_t r = 0; r < n; ++r) {
+    const float* c = m + (int64_t)(rng_u64() % (uint64_t)modes) * D;
+    float s = scale_rows ? (float)pow(10.0, 3.0 * rng_uniform() - 1.5) : 1.0f;
+    for (int64_t j = 0; j < D; ++j) x[r * D + j] = s * (c[j] + noise * rng_normal());
+  }
+  free(m);
+}
+
+/* ------------------------------------------------------------------ VLAD */
+static void case_vlad(hipStream_t stream, int64_t D, int64_t K, unsigned flags, const int64_t* offsets, int64_t n_img,
+                      const char* name) {
+  const int64_t total = offsets[n_img];
+  float* tok = (float*)malloc(sizeof(float) * (size_t)(total * D));
+  float* cen = (float*)malloc(sizeof(float) * (size_t)(K * D));
+  clustered_rows(tok, total, D, (int)K + 3, 0.7f, 1);
+  for (int64_t k = 0; k < K; ++k) {            /* centres = scaled tokens: raw (un-normalised) centroids as k-means leaves them */
+    int64_t r = (int64_t)(rng_u64() % (uint64_t)total);
+    for (int64_t j = 0; j < D; ++j) cen[k * D + j] = 0.6f * tok[r * D + j] + 0.05f * rng_normal();
+  }
+  float* want = (float*)malloc(sizeof(float) * (size_t)(n_img * K * D));
+  int64_t* want_lab = (int64_t*)malloc(sizeof(int64_t) * (size_t)total);
+  double* gap = (double*)malloc(sizeof(double) * (size_t)total);
+  oracle_vlad_hard(tok, offsets, n_img, D, cen, K, flags, want, want_lab, gap);
+
+  float* d_tok = (float*)dev_from(tok, sizeof(float) * (size_t)(total * D));
+  float* d_cen = (float*)dev_from(cen, sizeof(float) * (size_t)(K * D));
+  int64_t* d_off = (int64_t*)dev_from(offsets, sizeof(int64_t) * (size_t)(n_img + 1));
+  float* d_out = (float*)dev_alloc(sizeof(float) * (size_t)(n_img * K * D));
+  int64_t* d_lab = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)total);
+  size_t ws_bytes = anyloc_vlad_workspace_bytes(total, n_img, D, K);
+  void* d_ws = dev_alloc(ws_bytes);
+  HIP_OK(hipMemsetAsync(d_out, 0xff, sizeof(float) * (size_t)(n_img * K * D), stream));   /* NaN pattern: every element must be written */
+  ANYLOC_OK_OR_FAIL(anyloc_vlad_hard(d_tok, d_off, n_img, total, D, d_cen, K, flags, d_out, d_lab, d_ws, ws_bytes, stream));
+  float* got = (float*)malloc(sizeof(float) * (size_t)(n_img * K * D));
+  int64_t* got_lab = (int64_t*)malloc(sizeof(int64_t) * (size_t)total);
+  HIP_OK(hipMemcpyAsync(got, d_out, sizeof(float) * (size_t)(n_img * K * D), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(got_lab, d_lab, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+
+  /* labels: identical, except where the exact top-2 similarity gap is below what fp32 resolves (cosine scores are
+     O(1): 1e-6; euclidean similarities scale with the squared row norms) */
+  int64_t flips = 0, bad_flips = 0;
+  double worst = 0.0;
+  int ok = 1;
+  for (int64_t t = 0; t < total; ++t) {
+    if (got_lab[t] < 0 || got_lab[t] >= K) { ok = 0; got_lab[t] = 0; continue; }
+    if (got_lab[t] == want_lab[t]) continue;
+    ++flips;
+    double bar = 1e-6;
+    if (flags & ANYLOC_VLAD_EUCLIDEAN) {
+      double ss = 0.0;
+      for (int64_t j = 0; j < D; ++j) ss += (double)tok[t * D + j] * tok[t * D + j];
+      bar = 1e-5 * (ss > 1.0 ? ss : 1.0);
+    }
+    if (gap[t] > bar) ++bad_flips;
+  }
+  /* descriptors: against the exact VLAD of the assignment the library reported (equal to `want` when nothing flipped),
+     so a legitimate near-tie does not hide the sums from the check */
+  if (flips) oracle_vlad_assigned(tok, offsets, n_img, D, cen, K, flags, got_lab, want);
+  for (int64_t im = 0; im < n_img; ++im) {
+    double num = 0.0, den = 0.0;
+    for (int64_t j = 0; j < K * D; ++j) {
+      double g = got[im * K * D + j], w = want[im * K * D + j];
+      if (!(g == g)) ok = 0;                   /* NaN: an element the launch never wrote, or a bad norm */
+      num += (g - w) * (g - w);
+      den += w * w;
+    }
+    double rel = den > 0.0 ? sqrt(num / den) : sqrt(num);   /* an empty image: the zero vector, exactly */
+    if (!(rel <= worst)) worst = rel;
+  }
+  ok = ok && bad_flips == 0 && worst <= 1e-5;
+  char detail[160];
+  snprintf(detail, sizeof detail, "%lld images, %lld tokens: %lld label flips (%lld outside the gap bar), worst rel err %.2e",
+           (long long)n_img, (long long)total, (long long)flips, (long long)bad_flips, worst);
+  report(name, ok, detail);
+  hipFree(d_tok); hipFree(d_cen); hipFree(d_off); hipFree(d_out); hipFree(d_lab); hipFree(d_ws);
+  free(tok); free(cen); free(want); free(want_lab); free(gap); free(got); free(got_lab);
+}
+
+/* --------------------------------------------------------------- k-means */
+static void case_kmeans(hipStream_t stream, int64_t n, int64_t D, int64_t K, int mode, const char* name) {
+  float* x = (float*)malloc(sizeof(float) * (size_t)(n * D));
+  clustered_rows(x, n, D, (int)K, 0.5f, 0);
+  if (mode == 0) oracle_l2norm_rows(x, x, n, D);             /* VLAD.fit normalises the rows first (utilities.py:782) */
+  float* cen = (float*)malloc(sizeof(float) * (size_t)(K * D));
+  for (int64_t k = 0; k < K; ++k) memcpy(cen + k * D, x + (int64_t)(rng_u64() % (uint64_t)n) * D, sizeof(float) * (size_t)D);
+  memcpy(cen + (K - 1) * D, cen, sizeof(float) * (size_t)D);  /* a duplicated initial row: the later copy ends up EMPTY -> centre 0 */
+  float* want = (float*)malloc(sizeof(float) * (size_t)(K * D));
+  int64_t* want_lab = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+  double* want_cnt = (double*)malloc(sizeof(double) * (size_t)K);
+  double want_err = oracle_kmeans_iteration(x, n, D, cen, K, mode, want, want_lab, want_cnt);
+  double* gap = (double*)malloc(sizeof(double) * (size_t)n);
+  oracle_fpk_labels(x, n, D, cen, K, mode, want_lab, gap);
+
+  float* d_x = (float*)dev_from(x, sizeof(float) * (size_t)(n * D));
+  float* d_cen = (float*)dev_from(cen, sizeof(float) * (size_t)(K * D));
+  float* d_sums = (float*)dev_alloc(sizeof(float) * (size_t)(K * D));
+  float* d_cnt = (float*)dev_alloc(sizeof(float) * (size_t)K);
+  float* d_new = (float*)dev_alloc(sizeof(float) * (size_t)(K * D));
+  double* d_err = (double*)dev_alloc(sizeof(double));
+  int64_t* d_lab = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)n);
+  size_t ws_bytes = anyloc_kmeans_workspace_bytes(n, D, K);
+  void* d_ws = dev_alloc(ws_bytes);
+  ANYLOC_OK_OR_FAIL(anyloc_kmeans_step(d_x, n, D, d_cen, K, mode, d_sums, d_cnt, d_lab, d_ws, ws_bytes, stream));
+  ANYLOC_OK_OR_FAIL(anyloc_kmeans_update(d_sums, d_cnt, d_cen, K, D, d_new, d_err, stream));
+  float* got = (float*)malloc(sizeof(float) * (size_t)(K * D));
+  float* got_cnt = (float*)malloc(sizeof(float) * (size_t)K);
+  int64_t* got_lab = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+  double got_err = 0.0;
+  HIP_OK(hipMemcpyAsync(got, d_new, sizeof(float) * (size_t)(K * D), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(got_cnt, d_cnt, sizeof(float) * (size_t)K, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(got_lab, d_lab, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(&got_err, d_err, sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  int64_t flips = 0, bad = 0;
+  int lab_ok = 1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (got_lab[i] < 0 || got_lab[i] >= K) { lab_ok = 0; got_lab[i] = 0; continue; }
+    if (got_lab[i] != want_lab[i]) { ++flips; if (gap[i] > (mode == 0 ? 1e-6 : 1e-4)) ++bad; }
+  }
+  /* sums, counts, centres and err against the exact update of the assignment the library reported */
+  if (flips) want_err = oracle_kmeans_update_from_labels(x, n, D, cen, K, got_lab, want, want_cnt);
+  double worst = 0.0;
+  int counts_ok = lab_ok;
+  for (int64_t k = 0; k < K; ++k) {
+    if ((double)got_cnt[k] != want_cnt[k]) counts_ok = 0;
+    for (int64_t j = 0; j < D; ++j) {
+      double d = fabs((double)got[k * D + j] - (double)want[k * D + j]);
+      if (!(d <= worst)) worst = d;
+    }
+  }
+  int empty_ok = want_cnt[K - 1] == 0.0 && got_cnt[K - 1] == 0.0f;
+  for (int64_t j = 0; j < D; ++j) empty_ok = empty_ok && got[(K - 1) * D + j] == 0.0f;
+  int err_ok = fabs(got_err - want_err) <= 1e-5 * (want_err > 1.0 ? want_err : 1.0);
+  int ok = bad == 0 && counts_ok && empty_ok && err_ok && worst <= 1e-5;
+  char detail[200];
+  snprintf(detail, sizeof detail, "%lld rows: %lld flips (%lld outside the bar), centres max err %.2e, empty cluster -> 0: %s, err %.6g vs %.6g",
+           (long long)n, (long long)flips, (long long)bad, worst, empty_ok ? "yes" : "NO", got_err, want_err);
+  report(name, ok, detail);
+  hipFree(d_x); hipFree(d_cen); hipFree(d_sums); hipFree(d_cnt); hipFree(d_new); hipFree(d_err); hipFree(d_lab); hipFree(d_ws);
+  free(x); free(cen); free(want); free(want_lab); free(want_cnt); free(gap); free(got); free(got_cnt); free(got_lab);
+}
+
+/* ----------------------------------------------------------------- top-k */
+static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, int64_t k, int metric, int64_t base,
+                      const char* name) {
+  float* db = (float*)malloc(sizeof(float) * (size_t)(ndb * dim));
+  float* qu = (float*)malloc(sizeof(float) * (size_t)(nq * dim));
+  clustered_rows(db, ndb, dim, 12, 1.0f, 1);                 /* raw rows of very different norms: NORMALIZE_DB has work to do */
+  clustered_rows(qu, nq, dim, 12, 1.0f, 1);
+  for (int64_t q = 0; q < nq && q < ndb; q += 3)             /* every third query depicts a database row */
+    for (int64_t j = 0; j < dim; ++j) qu[q * dim + j] = 0.8f * db[((q * 7) % ndb) * dim + j] + 0.2f * qu[q * dim + j];
+  if (ndb > 10) memcpy(db + 9 * dim, db + 4 * dim, sizeof(float) * (size_t)dim);   /* an exact duplicate: the tie goes to row 4 */
+  float* qn = (float*)malloc(sizeof(float) * (size_t)(nq * dim));
+  oracle_l2norm_rows(qu, qn, nq, dim);
+  float* want_d = (float*)malloc(sizeof(float) * (size_t)(nq * k));
+  int64_t* want_i = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq * k));
+  oracle_flat_topk(qn, nq, db, ndb, dim, k, metric, 1, want_d, want_i);
+
+  float* d_db = (float*)dev_from(db, sizeof(float) * (size_t)(ndb * dim));
+  float* d_qu = (float*)dev_from(qu, sizeof(float) * (size_t)(nq * dim));
+  float* d_qn = (float*)dev_alloc(sizeof(float) * (size_t)(nq * dim));
+  float* d_dist = (float*)dev_alloc(sizeof(float) * (size_t)(nq * k));
+  int64_t* d_idx = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)(nq * k));
+  size_t ws_bytes = anyloc_topk_workspace_bytes(nq, ndb, dim, k);
+  void* d_ws = dev_alloc(ws_bytes);
+  ANYLOC_OK_OR_FAIL(anyloc_l2norm_rows(d_qu, d_qn, nq, dim, 1e-12f, stream));
+  ANYLOC_OK_OR_FAIL(anyloc_topk(d_qn, nq, d_db, ndb, dim, k, metric, ANYLOC_TOPK_NORMALIZE_DB, base, d_dist, d_idx, d_ws,
+                                ws_bytes, stream));
+  float* got_d = (float*)malloc(sizeof(float) * (size_t)(nq * k));
+  int64_t* got_i = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq * k));
+  HIP_OK(hipMemcpyAsync(got_d, d_dist, sizeof(float) * (size_t)(nq * k), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(got_i, d_idx, sizeof(int64_t) * (size_t)(nq * k), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  int64_t swaps = 0, bad = 0, pad_bad = 0;
+  double worst = 0.0;
+  for (int64_t q = 0; q < nq; ++q)
+    for (int64_t j = 0; j < k; ++j) {
+      int64_t w = want_i[q * k + j], g = got_i[q * k + j];
+      if (w < 0) { if (g != -1) ++pad_bad; continue; }        /* k > ndb: idx -1 (faiss) */
+      double dd = fabs((double)got_d[q * k + j] - (double)want_d[q * k + j]);
+      if (dd > worst) worst = dd;
+      if (g != w + base) {
+        ++swaps;                                              /* acceptable only between candidates whose exact scores tie to 3e-6 */
+        if (dd > 3e-6) ++bad;
+      }
+    }
+  int ok = bad == 0 && pad_bad == 0 && worst <= 3e-6;
+  if (ndb > 10) {                                            /* the duplicated row: wherever both appear, 4 comes before 9 */
+    for (int64_t q = 0; q < nq; ++q) {
+      int64_t p4 = -1, p9 = -1;
+      for (int64_t j = 0; j < k; ++j) { if (got_i[q * k + j] == 4 + base) p4 = j; if (got_i[q * k + j] == 9 + base) p9 = j; }
+      if (p9 >= 0 && (p4 < 0 || p4 > p9)) ok = 0;
+    }
+  }
+  char detail[200];
+  snprintf(detail, sizeof detail, "%lld x %lld x %lld, k=%lld: %lld near-tie swaps (%lld outside 3e-6), max |dist err| %.2e, padding %s",
+           (long long)nq, (long long)ndb, (long long)dim, (long long)k, (long long)swaps, (long long)bad, worst, pad_bad ? "WRONG" : "ok");
+  report(name, ok, detail);
+  hipFree(d_db); hipFree(d_qu); hipFree(d_qn); hipFree(d_dist); hipFree(d_idx); hipFree(d_ws);
+  free(db); free(qu); free(qn); free(want_d); free(want_i); free(got_d); free(got_i);
+}
+
+/* ---------------------------------------------------------------- errors */
+static void case_errors(hipStream_t stream) {
+  float* d = (float*)dev_alloc(sizeof(float) * 64 * 8);
+  int64_t* di = (int64_t*)dev_alloc(sizeof(int64_t) * 64);
+  int s1 = anyloc_topk(d, 4, d, 8, 8, 2, 0, 0, 0, d, di, d, 0 /* workspace_bytes */, stream);
+  const char* m1 = anyloc_last_error();
+  int ok1 = s1 == ANYLOC_ERR_WORKSPACE && m1 && m1[0];
+  int s2 = anyloc_l2norm_rows(NULL, d, 4, 8, 1e-12f, stream);
+  const char* m2 = anyloc_last_error();
+  int ok2 = s2 == ANYLOC_ERR_INVALID_ARG && m2 && m2[0];
+  int64_t v = -1;
+  int s3 = anyloc_get_option("no_such_option", &v);
+  int ok3 = s3 != ANYLOC_OK;
+  HIP_OK(hipStreamSynchronize(stream));
+  char detail[200];
+  snprintf(detail, sizeof detail, "small workspace -> %d, null pointer -> %d, unknown option -> %d", s1, s2, s3);
+  report("errors are status codes", ok1 && ok2 && ok3, detail);
+  hipFree(d); hipFree(di);
+}
+
+int main(void) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+    fprintf(stderr, "abi_host: no HIP device -- libanyloc_hip.so has no CPU path, nothing to run\n");
+    return 77;
+  }
+  if (anyloc_version() != ANYLOC_ABI_VERSION) {
+    fprintf(stderr, "abi_host: library ABI %d, header ABI %d -- rebuild\n", anyloc_version(), ANYLOC_ABI_VERSION);
+    return 1;
+  }
+  HIP_OK(hipSetDevice(0));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));                          /* a caller-owned, non-default stream */
+  rng_state = 20240925u;
+
+  {  /* headline width: three full images + an empty one + two ragged ones */
+    const int64_t off[] = {0, 529, 529, 1058, 1075, 1076, 1605};
+    case_vlad(stream, 1536, 32, ANYLOC_VLAD_NORM_DESCS | ANYLOC_VLAD_INTRA_NORM, off, 6, "vlad D=1536 K=32 norm+intra");
+    case_vlad(stream, 1536, 32, ANYLOC_VLAD_NORM_DESCS, off, 6, "vlad D=1536 K=32 norm only");
+  }
+  {
+    const int64_t off[] = {0, 300, 300, 301, 700};
+    case_vlad(stream, 100, 5, ANYLOC_VLAD_NORM_DESCS | ANYLOC_VLAD_INTRA_NORM, off, 4, "vlad D=100 K=5 norm+intra");
+    case_vlad(stream, 100, 5, ANYLOC_VLAD_INTRA_NORM, off, 4, "vlad D=100 K=5 tokens as passed");
+    case_vlad(stream, 100, 5, ANYLOC_VLAD_NORM_DESCS | ANYLOC_VLAD_INTRA_NORM | ANYLOC_VLAD_EUCLIDEAN, off, 4,
+              "vlad D=100 K=5 euclidean labels");
+  }
+  case_kmeans(stream, 40000, 1536, 32, 0, "kmeans step+update 40000x1536 K=32 cosine");
+  case_kmeans(stream, 5000, 64, 16, 1, "kmeans step+update 5000x64 K=16 euclidean");
+  case_topk(stream, 5, 2000, 49152, 20, 0, 0, "topk 5 queries x 49152 dims, IP");
+  case_topk(stream, 5, 2000, 49152, 20, 1, 1000000, "topk 5 queries x 49152 dims, L2, base 1e6");
+  case_topk(stream, 300, 3000, 256, 10, 0, 0, "topk 300 queries x 256 dims, IP");
+  case_topk(stream, 3, 12, 64, 20, 0, 0, "topk k > ndb padding");
+  case_errors(stream);
+
+  HIP_OK(hipStreamDestroy(stream));
+  printf("{\"abi_host\": \"%s\", \"failures\": %d, \"abi\": %d}\n", failures ? "FAIL" : "ok", failures, anyloc_version());
+  return failures ? 1 : 0;
+}
