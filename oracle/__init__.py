@@ -17,4 +17,9 @@ vendored in the reference (facebookresearch/dinov2 @ main via torch.hub,
 fast-pytorch-kmeans==0.1.6, faiss==1.7.2) are restated from their published
 algorithms; DINOv2 is additionally cross-checked against the independent
 ``transformers`` implementation (tests/test_oracle_dinov2_hf.py).
+
+``oracle/c/`` holds the same VLAD / k-means / flat-search / recall arithmetic as scalar C with double accumulators
+(``anyloc_oracle.c``; built by ``oracle/cbuild.py`` = ``__graft_entry__.build()``, bound with ctypes), pinned against the
+same recordings by ``tests/test_oracle_c.py``; it is the checker inside the torch-free C caller of the ABI
+(``tests/c_abi/abi_host.c``).
 """
