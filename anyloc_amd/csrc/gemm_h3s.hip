@@ -23,9 +23,9 @@ struct Plan {
 };
 
 // tile configurations: id -> (MI, NI, WM, WN); BM = 32 MI WM, BN = 32 NI WN
-constexpr int NCFG = 7;
-const int kCfgBM[NCFG] = {64, 64, 64, 64, 128, 64, 64};
-const int kCfgBN[NCFG] = {64, 128, 128, 128, 128, 256, 256};
+constexpr int NCFG = 8;
+const int kCfgBM[NCFG] = {64, 64, 64, 64, 128, 64, 64, 192};
+const int kCfgBN[NCFG] = {64, 128, 128, 128, 128, 256, 256, 128};
 
 template <int EPI, int MI, int NI, int WM, int WN, int KB, int ST = 3>
 int launch_small(const H3Problem& p, hipStream_t stream) {
@@ -76,6 +76,7 @@ int launch_cfg(const H3Problem& p, const Plan& pl, hipStream_t stream) {
     case 3: return launch_kb<EPI, 1, 4, 2, 1>(p, pl.kb, pl.stages, stream);    // 64 x 128, two waves of 32 x 128
     case 4: return launch_kb<EPI, 2, 2, 2, 2>(p, pl.kb, pl.stages, stream);    // 128 x 128, four waves of 64 x 64
     case 5: return launch_kb<EPI, 2, 2, 1, 4>(p, pl.kb, pl.stages, stream);    // 64 x 256, four waves of 64 x 64
+    case 7: return launch_kb<EPI, 3, 2, 2, 2>(p, pl.kb, pl.stages, stream);    // 192 x 128, four waves of 96 x 64 (530 rows = 3 row tiles)
     default: return launch_kb<EPI, 1, 4, 2, 2>(p, pl.kb, pl.stages, stream);   // 64 x 256, four waves of 32 x 128
   }
 }
@@ -89,7 +90,12 @@ int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 //   fc2   (K = 4096, N = 1536)  64 x 128 four-wave tiles, 6-deep ring; split-K 2 at B=1: 49.9 -> 39.7 us;  B=2 unsplit: 75.7 -> 56.8
 //   proj  (K = 1536, N = 1536)  B=1: 64 x 64, 6-deep ring 25.0 -> 22.7 us;  B=2: 64 x 128, 6-deep ring 34.8 -> 28.3
 //   qkv   (N = 4608)            B=1: 128 x 128, 6-deep ring 39.1 -> 37.8 us;   B=2: 64 x 128 four-wave 56.1 -> 53.4
-//   w12   (N = 8192)            the round-3 choice stays the fastest (128 x 128 at B=1: 59 us)
+//   w12   (N = 8192)            among the 64- / 128-row shapes the round-3 choice stays the fastest (128 x 128 at B=1: 59 us by HIP
+//                               events, 55 us by dispatch timestamps) -- but its 5 x 64 = 320 workgroups put TWO on 64 of the 256 CUs
+//                               while 192 CUs hold one: the launch lasts as long as two tiles on one CU (qkv on the same tile,
+//                               180 workgroups = one per CU, takes 33 us).  One image is 530 rows = 3 row tiles of 192 (576 rows:
+//                               8 % padding instead of 21 %): 192 x 128 tiles are 3 x 64 = 192 equal workgroups, one per CU, each
+//                               1.5 x the work of a 128 x 128 tile instead of 2 x (option h3s_w12_tall, default 1; 0 = 128 x 128)
 // What the sweeps say about this regime: split-K pays only for the long contraction (a split workgroup's ticket hand-off and
 // the last arrival's slab reads cost what the shorter k-loop saves at K = 1536); a deeper ring (bytes in flight) helps the
 // GEMMs with the fewest workgroups; and with the weights resident on-die (a 2-block model) the same launches are no faster
@@ -111,6 +117,8 @@ Plan choose(const H3Problem& p, int epilogue) {
     } else if (p.N < 8192) {                               // qkv-like
       pl = one ? Plan{4, 1, 1} : Plan{2, 1, 1};
       pl.stages = one ? 6 : 3;
+    } else if (one && p.M > 384 && option(OPT_H3S_W12_TALL)) {   // w12-like, 385 ... 576 rows: three 192-row tiles, one workgroup per CU
+      pl = Plan{7, 1, 1};
     }
   }
   const int64_t mask = option(OPT_H3S_MASK);

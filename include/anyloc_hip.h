@@ -86,6 +86,8 @@ const char* anyloc_last_error(void);
  *   h3s_cfg (-1) h3s_ksplit (0) h3s_kb (0) h3s_stages (0) h3s_mask (31)
  *                                     overrides of that plan table for sweeps: tile configuration id, split-K factor, k-blocks per
  *                                     ring stage, ring depth (3 or 6); mask bit 0 qkv, 1 proj, 2 fc1 / w12, 3 fc2, 4 other GEMMs
+ *   h3s_w12_tall (1)                  the FFN input GEMM (N >= 8192) of ONE image of 385 ... 576 token rows on 192 x 128 tiles: three
+ *                                     row tiles, one workgroup per CU; 0 = 128 x 128 tiles (320 workgroups: two on 64 of the CUs)
  * Unknown names are rejected (ANYLOC_ERR_INVALID_ARG).  Not thread-safe against
  * concurrent launches that read the option being changed. */
 int anyloc_set_option(const char* name, int64_t value);

@@ -197,7 +197,7 @@ def test_small_m_plans_agree_with_the_plain_kernels(batch):
         assert torch.equal(got, ext(img))
         with ops.options(ln_direct_rows=0):                              # the single-wave LayerNorm of few-row calls: same bits as the tiled one
             assert torch.equal(got, ext(img))
-        plans = [(c, kb, ks, st) for c in range(7) for kb, ks, st in ((1, 1, 3), (2, 3, 6), (4, 2, 3), (1, 8, 6), (2, 5, 3))]
+        plans = [(c, kb, ks, st) for c in range(8) for kb, ks, st in ((1, 1, 3), (2, 3, 6), (4, 2, 3), (1, 8, 6), (2, 5, 3))]
         for cfg, kb, ks, st in plans:
             with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks, h3s_stages=st):
                 a = ext(img).clone()

@@ -22,7 +22,7 @@ ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device=dev)
 BATCHES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 2, 4)
 TAGS = {"qkv": "vit_qkv_gemm", "proj": "vit_proj_gemm", "fc1": "vit_w12_gemm", "fc2": "vit_fc2_gemm"}
 CFG_NAMES = ["64x64/2w", "64x128/2w(64x64)", "64x128/4w(32x64)", "64x128/2w(32x128)", "128x128/4w", "64x256/4w(64x64)",
-             "64x256/4w(32x128)"]
+             "64x256/4w(32x128)", "192x128/4w(96x64)"]
 CFGS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else tuple(range(len(CFG_NAMES)))
 
 
