@@ -95,7 +95,10 @@ int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 //                               while 192 CUs hold one: the launch lasts as long as two tiles on one CU (qkv on the same tile,
 //                               180 workgroups = one per CU, takes 33 us).  One image is 530 rows = 3 row tiles of 192 (576 rows:
 //                               8 % padding instead of 21 %): 192 x 128 tiles are 3 x 64 = 192 equal workgroups, one per CU, each
-//                               1.5 x the work of a 128 x 128 tile instead of 2 x (option h3s_w12_tall, default 1; 0 = 128 x 128)
+//                               1.5 x the work of a 128 x 128 tile instead of 2 x (option h3s_w12_tall, default 1; 0 = 128 x 128):
+//                               61.0 -> 51.1 us per launch, 49.2 with the 6-deep ring (120 KiB: one workgroup per CU is all there
+//                               is), 6.21 -> 5.83 ms per forward, the SAME bits (an unsplit plan keeps the order over k);
+//                               192-row tiles forced on qkv / proj / fc2 lose (108 / 72 / 36 tiles; profiles/r04_b1_w12_tall.log)
 // What the sweeps say about this regime: split-K pays only for the long contraction (a split workgroup's ticket hand-off and
 // the last arrival's slab reads cost what the shorter k-loop saves at K = 1536); a deeper ring (bytes in flight) helps the
 // GEMMs with the fewest workgroups; and with the weights resident on-die (a 2-block model) the same launches are no faster
@@ -119,6 +122,7 @@ Plan choose(const H3Problem& p, int epilogue) {
       pl.stages = one ? 6 : 3;
     } else if (one && p.M > 384 && option(OPT_H3S_W12_TALL)) {   // w12-like, 385 ... 576 rows: three 192-row tiles, one workgroup per CU
       pl = Plan{7, 1, 1};
+      pl.stages = 6;
     }
   }
   const int64_t mask = option(OPT_H3S_MASK);
