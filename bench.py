@@ -703,7 +703,8 @@ def _timed(fn, iters, warm=1):
 
 def stage_b1(ext, qu_img):
     """The way the reference's scripts call the extractor (scripts/dino_v2_vlad.py:169-183: one image per call): ViT-g/14
-    322 x 322 at B = 1, tokens on the device, launch-latency-bound (~220 dependent launches)."""
+    322 x 322 at B = 1, tokens on the device: ~225 small launches whose own fill / k-step chain / drain is the time (dispatch
+    timestamps: 98 % inside the kernels, 0.17 us between them -- profiles/r04_b1_kernel_trace_gaps.md)."""
     imgs = [qu_img[i:i + 1] for i in range(8)]
     state = {"i": 0}
 
@@ -722,7 +723,8 @@ def stage_b1(ext, qu_img):
     fl = flops_per_image()
     return {"workload": "DinoV2ExtractFeatures.__call__ at B=1, ViT-G/14 L31 value, 322x322 (the reference scripts' calling convention)",
             "ms_per_image": round(el * 1e3, 3), "images_per_s": round(1.0 / el, 1),
-            "bound": "latency: ~220 dependent launches, each a few hundred small tiles (DESIGN.md 4.1d)",
+            "bound": "latency inside ~225 small launches (98 % of the time is inside kernels of a few hundred tiles each: fill, "
+                     "per-k-step chain, drain; 0.17 us between dependent launches -- DESIGN.md 4.1d)",
             "achieved": round(fl / el / 1e12, 1), "unit": "TFLOP/s (algorithmic)", "kernels_ms": kern,
             "oracle_ok": bool(max(first, other) <= 2e-6), "max_abs_diff_vs_batch_position_0": first,
             "max_abs_diff_vs_batch_position_3": other}
