@@ -211,3 +211,116 @@ void oracle_recalls(const int64_t* idx, int64_t nq, int64_t kmax, const int64_t*
     }
   for (int64_t j = 0; j < n_k; ++j) recalls[j] = nq > 0 ? recalls[j] / (double)nq : 0.0;
 }
+
+/* ------------------------------------------------------------------ DINOv2 ViT (see anyloc_oracle.h) */
+static void linear_rows(const float* x, int64_t rows, int64_t in, const float* w, const float* b, int64_t out_dim, float* y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r)
+    for (int64_t o = 0; o < out_dim; ++o)
+      y[r * out_dim + o] = (float)(dot_d(x + r * in, w + o * in, in) + (b ? (double)b[o] : 0.0));
+}
+
+static void layernorm_rows(const float* x, int64_t rows, int64_t dim, const float* w, const float* b, float* y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r) {                     /* nn.LayerNorm(dim, eps=1e-6): biased variance */
+    const float* p = x + r * dim;
+    double mean = 0.0, var = 0.0;
+    for (int64_t c = 0; c < dim; ++c) mean += p[c];
+    mean /= (double)dim;
+    for (int64_t c = 0; c < dim; ++c) var += ((double)p[c] - mean) * ((double)p[c] - mean);
+    const double rstd = 1.0 / sqrt(var / (double)dim + 1e-6);
+    for (int64_t c = 0; c < dim; ++c) y[r * dim + c] = (float)(((double)p[c] - mean) * rstd * (double)w[c] + (double)b[c]);
+  }
+}
+
+void oracle_vit_facet(const oracle_vit_config* cfg, const float* patch_w, const float* patch_b, const float* cls_token,
+                      const float* pos, const oracle_vit_block* blocks, const float* img, int64_t B, int64_t H, int64_t W,
+                      int32_t layer, int32_t facet, int use_cls, int norm, float* out) {
+  const int64_t D = cfg->dim, P = cfg->patch, gh = H / P, gw = W / P, N = gh * gw, T = N + 1, R = B * T;
+  const int64_t heads = cfg->heads, hd = D / heads, Hh = cfg->ffn_hidden, PK = 3 * P * P;
+  float* x = (float*)malloc(sizeof(float) * (size_t)(R * D));
+  float* y = (float*)malloc(sizeof(float) * (size_t)(R * D));
+  float* qkv = (float*)malloc(sizeof(float) * (size_t)(R * 3 * D));
+  float* att = (float*)malloc(sizeof(float) * (size_t)(R * D));
+  float* hid = (float*)malloc(sizeof(float) * (size_t)(R * 2 * Hh));
+  /* prepare_tokens: conv 14x14 stride 14 as a contraction over (channel, py, px), CLS in front, + positional table */
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < R; ++r) {
+    const int64_t b = r / T, t = r % T;
+    if (t == 0) {
+      for (int64_t c = 0; c < D; ++c) x[r * D + c] = (float)((double)cls_token[c] + (double)pos[c]);
+      continue;
+    }
+    const int64_t py0 = ((t - 1) / gw) * P, px0 = ((t - 1) % gw) * P;
+    for (int64_t c = 0; c < D; ++c) {
+      double s = patch_b[c];
+      for (int64_t ch = 0; ch < 3; ++ch)
+        for (int64_t py = 0; py < P; ++py) {
+          const float* ip = img + ((b * 3 + ch) * H + py0 + py) * W + px0;
+          const float* wp = patch_w + c * PK + (ch * P + py) * P;
+          for (int64_t px = 0; px < P; ++px) s += (double)ip[px] * (double)wp[px];
+        }
+      x[r * D + c] = (float)((double)(float)s + (double)pos[t * D + c]);      /* conv output is an fp32 tensor, then + pos */
+    }
+  }
+  const float* tap = NULL;
+  int64_t tap_ld = D, tap_off = 0;
+  for (int32_t l = 0; l <= layer; ++l) {
+    const oracle_vit_block* bw = blocks + l;
+    layernorm_rows(x, R, D, bw->norm1_w, bw->norm1_b, y);
+    linear_rows(y, R, D, bw->qkv_w, bw->qkv_b, 3 * D, qkv);
+    if (l == layer && facet != 3) { tap = qkv; tap_ld = 3 * D; tap_off = (int64_t)facet * D; break; }
+    /* softmax((q * hd^-0.5) k^T) v per (image, head); qkv row = [3][heads][hd] */
+    const double scale = 1.0 / sqrt((double)hd);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t bh = 0; bh < B * heads * T; ++bh) {
+      const int64_t b = bh / (heads * T), h = (bh / T) % heads, i = bh % T;
+      const float* q = qkv + (b * T + i) * 3 * D + h * hd;
+      double* sc = (double*)malloc(sizeof(double) * (size_t)T);
+      double m = -INFINITY, den = 0.0;
+      for (int64_t j = 0; j < T; ++j) {
+        const float* k = qkv + (b * T + j) * 3 * D + D + h * hd;
+        double s = 0.0;
+        for (int64_t d = 0; d < hd; ++d) s += (double)(float)((double)q[d] * scale) * (double)k[d];
+        sc[j] = s;
+        if (s > m) m = s;
+      }
+      for (int64_t j = 0; j < T; ++j) { sc[j] = exp(sc[j] - m); den += sc[j]; }
+      for (int64_t d = 0; d < hd; ++d) {
+        double o = 0.0;
+        for (int64_t j = 0; j < T; ++j) o += sc[j] * (double)qkv[(b * T + j) * 3 * D + 2 * D + h * hd + d];
+        att[(b * T + i) * D + h * hd + d] = (float)(o / den);
+      }
+      free(sc);
+    }
+    linear_rows(att, R, D, bw->proj_w, bw->proj_b, D, y);
+    for (int64_t i = 0; i < R * D; ++i) x[i] = (float)((double)x[i] + (double)(float)((double)y[i] * (double)bw->ls1[i % D]));
+    layernorm_rows(x, R, D, bw->norm2_w, bw->norm2_b, y);
+    if (cfg->ffn_kind == 0) {
+      linear_rows(y, R, D, bw->fc1_w, bw->fc1_b, Hh, hid);
+      for (int64_t i = 0; i < R * Hh; ++i) {
+        const double v = hid[i];
+        hid[i] = (float)(0.5 * v * (1.0 + erf(v * 0.70710678118654752440)));
+      }
+    } else {
+      linear_rows(y, R, D, bw->fc1_w, bw->fc1_b, 2 * Hh, hid);           /* w12: [gate | value] */
+      for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < Hh; ++c) {
+          const double g = hid[r * 2 * Hh + c], v = hid[r * 2 * Hh + Hh + c];
+          hid[r * Hh + c] = (float)((double)(float)(g / (1.0 + exp(-g))) * v);    /* F.silu(x1) * x2; packed in place (c < Hh <= 2 Hh r) */
+        }
+    }
+    linear_rows(hid, R, Hh, bw->fc2_w, bw->fc2_b, D, y);
+    for (int64_t i = 0; i < R * D; ++i) x[i] = (float)((double)x[i] + (double)(float)((double)y[i] * (double)bw->ls2[i % D]));
+    if (l == layer) { tap = x; tap_ld = D; tap_off = 0; }
+  }
+  const int64_t rows_out = use_cls ? T : N, skip = use_cls ? 0 : 1;
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t t = 0; t < rows_out; ++t) {
+      const float* src = tap + (b * T + t + skip) * tap_ld + tap_off;
+      float* dst = out + (b * rows_out + t) * D;
+      const double den = norm ? fnorm_denominator(dot_d(src, src, D)) : 1.0;
+      for (int64_t c = 0; c < D; ++c) dst[c] = (float)((double)src[c] / den);
+    }
+  free(x); free(y); free(qkv); free(att); free(hid);
+}

@@ -75,6 +75,25 @@ void oracle_flat_topk(const float* qu, int64_t nq, const float* db, int64_t ndb,
 void oracle_recalls(const int64_t* idx, int64_t nq, int64_t kmax, const int64_t* top_k, int64_t n_k,
                     const int64_t* gt, const int64_t* gt_off, double* recalls);
 
+/* ---- DINOv2 ViT facet extraction: DinoV2ExtractFeatures.__call__ (utilities.py:263-285) on the hub model
+ * (facebookresearch/dinov2 @ main, not vendored in the reference: dinov2/models/vision_transformer.py and dinov2/layers,
+ * restated as in oracle/dinov2_ref.py).  Weights in the HUB layout (torch Linear [out, in]; SwiGLU w12 = H gate rows then
+ * H value rows); activations are kept in fp32 between layers as the fp32 model keeps them, every contraction, LayerNorm
+ * statistic and softmax is accumulated in double.  `pos` is the positional table ALREADY interpolated for (H, W)
+ * ([1 + N, D], row 0 = CLS), as the C ABI takes it.  facet: 0 query, 1 key, 2 value (slices of blocks[layer].attn.qkv's
+ * output, :270-281), 3 token (output of blocks[layer]); CLS row dropped unless use_cls (:270-273); rows L2-normalised when
+ * norm != 0 (:282-283).  out [B, N (+1), D]. */
+typedef struct oracle_vit_block {
+  const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ls1;
+  const float *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ls2;   /* fc1 = mlp.fc1 / mlp.w12, fc2 = mlp.fc2 / mlp.w3 */
+} oracle_vit_block;
+typedef struct oracle_vit_config {
+  int32_t dim, depth, heads, ffn_kind /* 0 mlp (erf GELU), 1 swiglu */, ffn_hidden, patch;
+} oracle_vit_config;
+void oracle_vit_facet(const oracle_vit_config* cfg, const float* patch_w /* [D, 3*P*P] */, const float* patch_b,
+                      const float* cls_token, const float* pos, const oracle_vit_block* blocks, const float* img,
+                      int64_t B, int64_t H, int64_t W, int32_t layer, int32_t facet, int use_cls, int norm, float* out);
+
 #ifdef __cplusplus
 }
 #endif

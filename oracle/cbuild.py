@@ -97,6 +97,56 @@ class COracle:
                                   1 if normalize_db else 0, dist, idx)
         return dist, idx
 
+    def vit_facet(self, name, state_dict, img, layer, facet="value", use_cls=False, norm_descs=True):
+        """DinoV2ExtractFeatures.__call__ on the hub model `name` with the hub-layout `state_dict` (torch tensors or arrays),
+        img [B,3,H,W]: tokens [B, N(+1), D].  The positional table is interpolated by oracle.dinov2_ref (torch), as the
+        product interpolates it on the host with the same call."""
+        import torch
+        from . import dinov2_ref
+        dim, depth, heads, ffn, hidden = dinov2_ref.ARCH[name]
+        sd = {k: (v.detach().cpu() if torch.is_tensor(v) else torch.as_tensor(v)).to(torch.float32) for k, v in state_dict.items()}
+        img = np.ascontiguousarray(np.asarray(img, dtype=np.float32))
+        B, _, H, W = img.shape
+        pos = self._f(dinov2_ref.interpolate_pos_embed(sd["pos_embed"], H, W)[0].numpy())
+        keep = []
+
+        def a(key, shape=None):
+            arr = self._f(sd[key].numpy().reshape(shape) if shape else sd[key].numpy())
+            keep.append(arr)
+            return arr.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+        class Block(ctypes.Structure):
+            _fields_ = [(f, ctypes.POINTER(ctypes.c_float)) for f in
+                        ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
+                         "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+        class Cfg(ctypes.Structure):
+            _fields_ = [(f, ctypes.c_int32) for f in ("dim", "depth", "heads", "ffn_kind", "ffn_hidden", "patch")]
+
+        n_blocks = layer + 1
+        blocks = (Block * n_blocks)()
+        f1, f2 = ("mlp.fc1", "mlp.fc2") if ffn == "mlp" else ("mlp.w12", "mlp.w3")
+        for i in range(n_blocks):
+            p = f"blocks.{i}."
+            for fld, key in (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
+                             ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+                             ("ls1", "ls1.gamma"), ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"),
+                             ("fc1_w", f1 + ".weight"), ("fc1_b", f1 + ".bias"), ("fc2_w", f2 + ".weight"),
+                             ("fc2_b", f2 + ".bias"), ("ls2", "ls2.gamma")):
+                setattr(blocks[i], fld, a(p + key))
+        cfg = Cfg(dim, n_blocks, heads, 0 if ffn == "mlp" else 1, hidden, dinov2_ref.PATCH)
+        N = (H // dinov2_ref.PATCH) * (W // dinov2_ref.PATCH)
+        out = np.empty((B, N + (1 if use_cls else 0), dim), dtype=np.float32)
+        fn = self.lib.oracle_vit_facet
+        fn.restype = None
+        fn.argtypes = [ctypes.POINTER(Cfg), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                       ctypes.POINTER(ctypes.c_float), _F, ctypes.POINTER(Block), _F, _i64, _i64, _i64,
+                       ctypes.c_int32, ctypes.c_int32, _int, _int, _F]
+        fn(ctypes.byref(cfg), a("patch_embed.proj.weight", (dim, -1)), a("patch_embed.proj.bias"), a("cls_token", (dim,)), pos,
+           blocks, img, B, H, W, layer, ("query", "key", "value", "token").index(facet), 1 if use_cls else 0,
+           1 if norm_descs else 0, out)
+        return out
+
     def recalls(self, idx, top_k, gt_pos):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         off = np.zeros(len(gt_pos) + 1, dtype=np.int64)

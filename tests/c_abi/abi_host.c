@@ -12,6 +12,9 @@
  *   kmeans   one anyloc_kmeans_step + anyloc_kmeans_update against one fpk iteration
  *   topk     anyloc_l2norm_rows + anyloc_topk(NORMALIZE_DB): a few queries of long rows (the split-K stream over the
  *            database) and many queries of short rows (score panels), IP and L2, k > ndb padding, index_base
+ *   vit      anyloc_vit_create / anyloc_vit_forward (two taps in one call) on GELU-mlp and SwiGLU models, on the fp32 matrix-core
+ *            kernels and with anyloc_split_h2 images attached (the default two-term fp16 arithmetic), against the C restatement
+ *            of the hub model
  *   errors   a too-small workspace and a null pointer come back as status codes with a message, nothing crashes
  *
  * Exit code 0 = all cases agree, 1 = a mismatch or an unexpected status, 77 = no HIP device (the product has no CPU
@@ -284,6 +287,136 @@ static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, 
   free(db); free(qu); free(qn); free(want_d); free(want_i); free(got_d); free(got_i);
 }
 
+
+/* ------------------------------------------------------------------- ViT */
+typedef struct { float *h, *d; size_t n; } pair_t;            /* a host array and its device copy */
+static pair_t mk(size_t n, float mean, float std) {
+  pair_t p;
+  p.n = n;
+  p.h = (float*)malloc(sizeof(float) * n);
+  for (size_t i = 0; i < n; ++i) p.h[i] = mean + std * rng_normal();
+  p.d = (float*)dev_from(p.h, sizeof(float) * n);
+  return p;
+}
+static void rm(pair_t* p) { free(p->h); hipFree(p->d); }
+
+/* DinoV2ExtractFeatures.__call__ through anyloc_vit_create / anyloc_vit_forward on a 3-block model of the ViT-S width
+   (ffn_kind 0: GELU mlp; 1: SwiGLU as in ViT-g), two taps in one call (token of block 1 | value of block 2), first on the
+   exact-fp32 matrix-core kernels, then with the two-term fp16 images attached (anyloc_split_h2 of every weight matrix +
+   the Cauchy-Schwarz constants of the FFN input projection) -- against the C restatement of the hub model. */
+static void case_vit(hipStream_t stream, int ffn_kind, const char* name) {
+  enum { D = 384, HEADS = 6, DEPTH = 3, P = 14, PK = 3 * 14 * 14 };
+  const int64_t HID = ffn_kind ? 1024 : 1536, F1 = ffn_kind ? 2 * HID : HID;
+  const int64_t B = 3, H = 112, W = 168, N = (H / P) * (W / P), T = N + 1;
+  pair_t img = mk((size_t)(B * 3 * H * W), 0.0f, 1.0f), pos = mk((size_t)(T * D), 0.0f, 0.3f);
+  pair_t pw = mk((size_t)D * PK, 0.0f, 0.04f), pb = mk(D, 0.0f, 0.1f), cls = mk(D, 0.0f, 0.5f);
+  pair_t w[DEPTH][14];
+  oracle_vit_block ob[DEPTH];
+  anyloc_vit_block_weights ab[DEPTH];
+  float* fc1_il[DEPTH] = {0};                                 /* SwiGLU: the 32 gate / 32 value interleave the ABI takes */
+  float* fc1b_il[DEPTH] = {0};
+  for (int l = 0; l < DEPTH; ++l) {
+    const size_t sz[14] = {D, D, (size_t)3 * D * D, 3 * D, (size_t)D * D, D, D, D, D, (size_t)F1 * D, (size_t)F1, (size_t)D * HID, D, D};
+    const float mean[14] = {1, 0, 0, 0, 0, 0, 0.5f, 1, 0, 0, 0, 0, 0, 0.5f};
+    const float sd[14] = {0.1f, 0.1f, 0.05f, 0.1f, 0.05f, 0.1f, 0.2f, 0.1f, 0.1f, 0.05f, 0.1f, 0.03f, 0.1f, 0.2f};
+    for (int f = 0; f < 14; ++f) w[l][f] = mk(sz[f], mean[f], sd[f]);
+    const float** oh = (const float**)&ob[l];
+    for (int f = 0; f < 14; ++f) oh[f] = w[l][f].h;           /* oracle_vit_block: 14 pointers in this order */
+    ab[l].norm1_w = w[l][0].d; ab[l].norm1_b = w[l][1].d; ab[l].qkv_w = w[l][2].d; ab[l].qkv_b = w[l][3].d;
+    ab[l].proj_w = w[l][4].d; ab[l].proj_b = w[l][5].d; ab[l].ls1 = w[l][6].d; ab[l].norm2_w = w[l][7].d; ab[l].norm2_b = w[l][8].d;
+    ab[l].fc1_w = w[l][9].d; ab[l].fc1_b = w[l][10].d; ab[l].fc2_w = w[l][11].d; ab[l].fc2_b = w[l][12].d; ab[l].ls2 = w[l][13].d;
+    if (ffn_kind) {                                           /* hub w12 = [HID gate rows; HID value rows] -> per 32 channels: 32 gate rows, 32 value rows */
+      float* il = (float*)malloc(sizeof(float) * (size_t)(F1 * D));
+      float* bl = (float*)malloc(sizeof(float) * (size_t)F1);
+      for (int64_t c = 0; c < HID; ++c)
+        for (int v = 0; v < 2; ++v) {
+          const int64_t dst = (c / 32) * 64 + v * 32 + c % 32, src = v * HID + c;
+          memcpy(il + dst * D, w[l][9].h + src * D, sizeof(float) * D);
+          bl[dst] = w[l][10].h[src];
+        }
+      fc1_il[l] = (float*)dev_from(il, sizeof(float) * (size_t)(F1 * D));
+      fc1b_il[l] = (float*)dev_from(bl, sizeof(float) * (size_t)F1);
+      ab[l].fc1_w = fc1_il[l];
+      ab[l].fc1_b = fc1b_il[l];
+      free(il); free(bl);
+    }
+  }
+  oracle_vit_config oc = {D, DEPTH, HEADS, ffn_kind, (int32_t)HID, P};
+  float* want_tok = (float*)malloc(sizeof(float) * (size_t)(B * N * D));
+  float* want_val = (float*)malloc(sizeof(float) * (size_t)(B * N * D));
+  oracle_vit_facet(&oc, pw.h, pb.h, cls.h, pos.h, ob, img.h, B, H, W, 1, 3, 0, 1, want_tok);
+  oracle_vit_facet(&oc, pw.h, pb.h, cls.h, pos.h, ob, img.h, B, H, W, 2, 2, 0, 1, want_val);
+
+  anyloc_vit_config cfg = {D, DEPTH, HEADS, ffn_kind, (int32_t)HID, P, PK};
+  anyloc_vit_t* vit = NULL;
+  ANYLOC_OK_OR_FAIL(anyloc_vit_create(&vit, &cfg, pw.d, pb.d, cls.d, ab));
+  const size_t ws_bytes = anyloc_vit_workspace_bytes(vit, B, H, W);
+  void* d_ws = dev_alloc(ws_bytes);
+  float* d_out = (float*)dev_alloc(sizeof(float) * (size_t)(B * N * 2 * D));
+  float* got = (float*)malloc(sizeof(float) * (size_t)(B * N * 2 * D));
+  const int32_t layers[2] = {1, 2}, facets[2] = {ANYLOC_FACET_TOKEN, ANYLOC_FACET_VALUE};
+  void* img2[DEPTH][4] = {{0}};
+  float* inv2[DEPTH][4] = {{0}};
+  anyloc_vit_block_h2 hb[DEPTH];
+  memset(hb, 0, sizeof hb);
+  for (int mode = 0; mode < 2; ++mode) {
+    unsigned flags = ANYLOC_VIT_NORM_TAPS;
+    if (mode == 1) {
+      for (int l = 0; l < DEPTH; ++l) {
+        const float* mat[4] = {ab[l].qkv_w, ab[l].proj_w, ab[l].fc1_w, ab[l].fc2_w};
+        const int64_t rows[4] = {3 * D, D, F1, D}, kk[4] = {D, D, D, HID};
+        for (int f = 0; f < 4; ++f) {
+          img2[l][f] = dev_alloc(anyloc_h2_bytes(rows[f], kk[f]));
+          inv2[l][f] = (float*)dev_alloc(sizeof(float) * (size_t)rows[f]);
+          ANYLOC_OK_OR_FAIL(anyloc_split_h2(mat[f], kk[f], rows[f], kk[f], img2[l][f], inv2[l][f], stream));
+        }
+        hb[l].qkv_w2 = img2[l][0]; hb[l].qkv_inv = inv2[l][0]; hb[l].proj_w2 = img2[l][1]; hb[l].proj_inv = inv2[l][1];
+        hb[l].fc1_w2 = img2[l][2]; hb[l].fc1_inv = inv2[l][2]; hb[l].fc2_w2 = img2[l][3]; hb[l].fc2_inv = inv2[l][3];
+        /* |fc1_j(y)| <= ||y|| max_j ||W_j|| + max_j |b_j|: largest row norm and bias of the gate (mlp: fc1) rows, then of the value rows */
+        double bound[4] = {0, 0, 0, 0};
+        for (int64_t r = 0; r < F1; ++r) {
+          double ss = 0.0;
+          for (int64_t c = 0; c < D; ++c) ss += (double)w[l][9].h[r * D + c] * w[l][9].h[r * D + c];
+          const int v = (ffn_kind && r >= HID) ? 2 : 0;
+          if (sqrt(ss) > bound[v]) bound[v] = sqrt(ss);
+          if (fabs((double)w[l][10].h[r]) > bound[v + 1]) bound[v + 1] = fabs((double)w[l][10].h[r]);
+        }
+        for (int j = 0; j < 4; ++j) hb[l].fc1_bound[j] = (float)(bound[j] * (1.0 + 1e-6));
+        hb[l].fc1_b2 = NULL;
+        hb[l].fc1_layout = 0;
+      }
+      ANYLOC_OK_OR_FAIL(anyloc_vit_attach_h2(vit, hb));
+      flags |= ANYLOC_VIT_SPLIT_FP16;
+    }
+    HIP_OK(hipMemsetAsync(d_out, 0xff, sizeof(float) * (size_t)(B * N * 2 * D), stream));
+    ANYLOC_OK_OR_FAIL(anyloc_vit_forward(vit, img.d, B, H, W, pos.d, 2, layers, facets, flags, d_out, d_ws, ws_bytes, stream));
+    HIP_OK(hipMemcpyAsync(got, d_out, sizeof(float) * (size_t)(B * N * 2 * D), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    double worst_t = 0.0, worst_v = 0.0;
+    for (int64_t r = 0; r < B * N; ++r)
+      for (int64_t c = 0; c < D; ++c) {
+        const double dt = fabs((double)got[r * 2 * D + c] - (double)want_tok[r * D + c]);
+        const double dv = fabs((double)got[r * 2 * D + D + c] - (double)want_val[r * D + c]);
+        if (!(dt <= worst_t)) worst_t = dt;
+        if (!(dv <= worst_v)) worst_v = dv;
+      }
+    char label[96], detail[200];
+    snprintf(label, sizeof label, "%s, %s", name, mode ? "two-term fp16 GEMMs" : "fp32 matrix-core GEMMs");
+    snprintf(detail, sizeof detail, "%lld images of %lldx%lld, %lld tokens x %d: max |err| token tap %.2e, value tap %.2e (unit rows; bar 2e-5)",
+             (long long)B, (long long)H, (long long)W, (long long)N, D, worst_t, worst_v);
+    report(label, worst_t <= 2e-5 && worst_v <= 2e-5, detail);
+  }
+  anyloc_vit_destroy(vit);
+  for (int l = 0; l < DEPTH; ++l) {
+    for (int f = 0; f < 14; ++f) rm(&w[l][f]);
+    for (int f = 0; f < 4; ++f) { hipFree(img2[l][f]); hipFree(inv2[l][f]); }
+    hipFree(fc1_il[l]); hipFree(fc1b_il[l]);
+  }
+  rm(&img); rm(&pos); rm(&pw); rm(&pb); rm(&cls);
+  hipFree(d_ws); hipFree(d_out);
+  free(got); free(want_tok); free(want_val);
+}
+
 /* ---------------------------------------------------------------- errors */
 static void case_errors(hipStream_t stream) {
   float* d = (float*)dev_alloc(sizeof(float) * 64 * 8);
@@ -337,6 +470,8 @@ int main(void) {
   case_topk(stream, 5, 2000, 49152, 20, 1, 1000000, "topk 5 queries x 49152 dims, L2, base 1e6");
   case_topk(stream, 300, 3000, 256, 10, 0, 0, "topk 300 queries x 256 dims, IP");
   case_topk(stream, 3, 12, 64, 20, 0, 0, "topk k > ndb padding");
+  case_vit(stream, 0, "vit 3 blocks D=384 mlp");
+  case_vit(stream, 1, "vit 3 blocks D=384 swiglu");
   case_errors(stream);
 
   HIP_OK(hipStreamDestroy(stream));

@@ -41,4 +41,4 @@ def test_c_host_parity_against_the_c_restatement():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = json.loads(r.stdout.strip().splitlines()[-1])
     assert last["abi_host"] == "ok" and last["failures"] == 0
-    assert r.stdout.count(" ok  ") >= 12 and "FAIL" not in r.stdout
+    assert r.stdout.count(" ok  ") >= 16 and "FAIL" not in r.stdout

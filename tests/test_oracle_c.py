@@ -107,3 +107,38 @@ def test_c_labels_match_torch_restatement_on_random_rows(co):
         scale = 1.0 if mode == "cosine" else float((x * x).sum(1).max())
         assert (gap[lab != want] < 1e-5 * scale).all()
         assert (lab != want).mean() < 0.01
+
+
+def test_c_dinov2_forward_against_reference_recordings(golden_dir, co):
+    """The C restatement of the hub model's forward + the reference's facet hook (oracle_vit_facet) on the config-1 run:
+    ViT-S/14, layer 9, `value` -- the tokens the REFERENCE's own __call__ recorded for images 0 and 31 -- and the other
+    facets' probe projections; then a SwiGLU model (the ViT-g architecture at depth 2) against the torch restatement."""
+    from oracle import dinov2_ref
+    from oracle.make_golden import probe_vector
+    g = np.load(os.path.join(golden_dir, "config1_vits14_l9_value_k8.npz"))
+    name = str(g["model"])
+    sd = synth.synthetic_state_dict(name, int(g["weights_seed"]))
+    db, qu, _ = synth.synthetic_places(int(g["n_db"]), int(g["n_qu"]), int(g["hw"]), int(g["hw"]), seed=int(g["images_seed"]))
+    imgs = torch.cat([db, qu])
+    tok = co.vit_facet(name, sd, imgs[[0, 31]].numpy(), int(g["layer"]), str(g["facet"]))
+    assert np.abs(tok[0] - g["tokens_img0"]).max() <= 1e-6 and np.abs(tok[1] - g["tokens_img31"]).max() <= 1e-6
+    pv = probe_vector(384).numpy().astype(np.float64)
+    for fname, kw in {"query": dict(layer=9, facet="query"), "key": dict(layer=9, facet="key"),
+                      "token": dict(layer=9, facet="token"),
+                      "value_cls_raw": dict(layer=9, facet="value", use_cls=True, norm_descs=False),
+                      "token_l11": dict(layer=11, facet="token")}.items():
+        out = co.vit_facet(name, sd, imgs[:1].numpy(), **kw)[0]
+        assert tuple(out.shape) == tuple(g[f"facet_{fname}_shape"])
+        want = g[f"facet_{fname}_proj"].astype(np.float64)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(out.astype(np.float64) @ pv - want).max() <= 2e-5 * scale, fname
+    gname = "dinov2_vitg14"
+    sdg = synth.synthetic_state_dict(gname, 4, depth=2)
+    model = dinov2_ref.DinoVisionTransformer(gname)
+    model.blocks = model.blocks[:2]
+    model.load_state_dict(sdg, strict=True)
+    img = torch.randn(1, 3, 42, 70, generator=torch.Generator().manual_seed(9))
+    for facet in ("value", "token"):
+        want = dinov2_ref.extract_facet(model.eval(), img, 1, facet).numpy()
+        got = co.vit_facet(gname, sdg, img.numpy(), 1, facet)
+        assert np.abs(got - want).max() <= 1e-6, facet
