@@ -320,8 +320,9 @@ static void case_vit(hipStream_t stream, int ffn_kind, const char* name) {
     const float mean[14] = {1, 0, 0, 0, 0, 0, 0.5f, 1, 0, 0, 0, 0, 0, 0.5f};
     const float sd[14] = {0.1f, 0.1f, 0.05f, 0.1f, 0.05f, 0.1f, 0.2f, 0.1f, 0.1f, 0.05f, 0.1f, 0.03f, 0.1f, 0.2f};
     for (int f = 0; f < 14; ++f) w[l][f] = mk(sz[f], mean[f], sd[f]);
-    const float** oh = (const float**)&ob[l];
-    for (int f = 0; f < 14; ++f) oh[f] = w[l][f].h;           /* oracle_vit_block: 14 pointers in this order */
+    ob[l].norm1_w = w[l][0].h; ob[l].norm1_b = w[l][1].h; ob[l].qkv_w = w[l][2].h; ob[l].qkv_b = w[l][3].h;
+    ob[l].proj_w = w[l][4].h; ob[l].proj_b = w[l][5].h; ob[l].ls1 = w[l][6].h; ob[l].norm2_w = w[l][7].h; ob[l].norm2_b = w[l][8].h;
+    ob[l].fc1_w = w[l][9].h; ob[l].fc1_b = w[l][10].h; ob[l].fc2_w = w[l][11].h; ob[l].fc2_b = w[l][12].h; ob[l].ls2 = w[l][13].h;
     ab[l].norm1_w = w[l][0].d; ab[l].norm1_b = w[l][1].d; ab[l].qkv_w = w[l][2].d; ab[l].qkv_b = w[l][3].d;
     ab[l].proj_w = w[l][4].d; ab[l].proj_b = w[l][5].d; ab[l].ls1 = w[l][6].d; ab[l].norm2_w = w[l][7].d; ab[l].norm2_b = w[l][8].d;
     ab[l].fc1_w = w[l][9].d; ab[l].fc1_b = w[l][10].d; ab[l].fc2_w = w[l][11].d; ab[l].fc2_b = w[l][12].d; ab[l].ls2 = w[l][13].d;
