@@ -5,6 +5,10 @@
 #include "common.hpp"
 #include "tile_order.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "gemm_h3_kernel.hpp: the split-K hand-off relies on the sc1 (write-through / coherent-read) cache policy of gfx942 / gfx950"
+#endif
+
 namespace anyloc {
 
 namespace {
@@ -194,8 +198,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
     // (profiles/r04_b1_plan_sweep_fences.log).  Every wave drains its stores, the workgroup meets, ONE lane takes the tile's
     // ticket (relaxed, agent scope), and the last arrival reads all slabs back with sc1 loads (the per-XCD L2s are not
     // coherent with each other) IN SPLIT ORDER -- deterministic whichever workgroup arrives last.  The hand-off recipe of
-    // cdna_hip_programming.md section 6 (counter form).  The flag travels through the (now idle) LDS ring: a second
-    // __shared__ object would cost every k-step of the pipeline a full vmcnt drain.
+    // cdna_hip_programming.md section 6 (counter form, its sc1 variant: "sc1 slab stores -> every wave s_waitcnt vmcnt(0) ->
+    // __syncthreads() -> lane 0 relaxed agent fetch_add; the reducer reads the slabs with sc1 loads").  This is a property of
+    // the gfx942 / gfx950 cache policy bits (sc1 = write-through to / read from the device-coherent level), NOT of the HIP
+    // memory model: the file refuses to compile for any other target (the #error below), and
+    // tests/test_gpu_vit.py::test_split_k_hand_off_under_load hammers it (hundreds of concurrent tiles x up to 8 splits,
+    // repeated; bit-identical to the first run and within the k-order bar of the unsplit plan).  The flag travels through
+    // the (now idle) LDS ring: a second __shared__ object would cost every k-step of the pipeline a full vmcnt drain.
     constexpr int NT = 64 * Cfg::NW;
     constexpr int SC1 = 16;                                  // aux bit of the buffer instructions: sc1
     const int tile = tm * tiles_n + tn;

@@ -234,6 +234,7 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
   h->drop_patch_image();
   if (!blocks) {
     h->h2.clear();
+    h->ffn_exact.assign(h->cfg.depth, 0);
     return ANYLOC_OK;
   }
   ANYLOC_CHECK_ARG(h->cfg.dim % 16 == 0 && h->cfg.ffn_hidden % 16 == 0 && h->cfg.ffn_hidden <= 4096 && h->cfg.dim <= 2048,
@@ -246,29 +247,52 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
                      "vit_attach_h2: block %d: fc1_layout %d (1 needs a SwiGLU model, fc1_b2 and ffn_hidden %% 64 == 0)", i,
                      b.fc1_layout);
   }
-  h->h2.assign(blocks, blocks + h->cfg.depth);
-  // the patch-embedding weights [dim, patch_k_pad] as an operand image of the same GEMM, the contraction zero-padded to
-  // whole 16-element k-blocks (one-off, on the null stream)
-  {
-    const int64_t D = h->cfg.dim, K0 = h->cfg.patch_k_pad, Kp = (K0 + 15) / 16 * 16;
-    float* padded = nullptr;
-    ANYLOC_HIP(hipMalloc(reinterpret_cast<void**>(&padded), sizeof(float) * D * Kp));
-    ANYLOC_HIP(hipMemset(padded, 0, sizeof(float) * D * Kp));
-    ANYLOC_HIP(hipMemcpy2D(padded, sizeof(float) * Kp, h->patch_w, sizeof(float) * K0, sizeof(float) * K0, D, hipMemcpyDeviceToDevice));
-    int rc = ANYLOC_OK;
-    if (hipMalloc(reinterpret_cast<void**>(&h->patch_w2), h2_bytes(D, Kp)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->patch_inv), sizeof(float) * D) != hipSuccess) {
-      set_error("vit_attach_h2: out of device memory for the patch-embedding image");
+  // The patch-embedding weights [dim, patch_k_pad] as an operand image of the same GEMM, the contraction zero-padded to
+  // whole 16-element k-blocks (one-off, on the null stream).  Built FIRST, on the device that owns patch_w (not whatever
+  // device is current), every temporary freed on every path; the handle changes only when all of it succeeded -- a failed
+  // attach leaves the handle as it was before the call, minus the previous patch image (already dropped above, with the
+  // previous h2 blocks detached by the clear() below).
+  h->h2.clear();
+  h->ffn_exact.assign(h->cfg.depth, 0);      // the exact-quantiser switches belong to the weights that are being replaced
+  const int64_t D = h->cfg.dim, K0 = h->cfg.patch_k_pad, Kp = (K0 + 15) / 16 * 16;
+  int prev_dev = -1, w_dev = -1;
+  hipPointerAttribute_t attr;
+  if (hipGetDevice(&prev_dev) == hipSuccess && hipPointerGetAttributes(&attr, h->patch_w) == hipSuccess &&
+      attr.type == hipMemoryTypeDevice)
+    w_dev = attr.device;
+  else
+    (void)hipGetLastError();                 // (an unregistered pointer: stay on the current device)
+  if (w_dev >= 0 && w_dev != prev_dev) ANYLOC_HIP(hipSetDevice(w_dev));
+  float* padded = nullptr;
+  unsigned char* w2 = nullptr;
+  float* winv = nullptr;
+  int rc = ANYLOC_OK;
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == ANYLOC_OK) {
+      set_error("vit_attach_h2: %s: %s", what, hipGetErrorString(e));
       rc = ANYLOC_ERR_HIP;
     }
-    if (rc == ANYLOC_OK) rc = split_h2(padded, Kp, D, Kp, h->patch_w2, h->patch_inv, nullptr);
-    if (rc == ANYLOC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = ANYLOC_ERR_HIP;
-    (void)hipFree(padded);
-    if (rc != ANYLOC_OK) {
-      h->drop_patch_image();
-      return rc;
-    }
+    return e == hipSuccess;
+  };
+  if (hip_ok(hipMalloc(reinterpret_cast<void**>(&padded), sizeof(float) * D * Kp), "hipMalloc (padded patch weights)") &&
+      hip_ok(hipMalloc(reinterpret_cast<void**>(&w2), h2_bytes(D, Kp)), "hipMalloc (patch-embedding image)") &&
+      hip_ok(hipMalloc(reinterpret_cast<void**>(&winv), sizeof(float) * D), "hipMalloc (patch-embedding row scales)") &&
+      hip_ok(hipMemset(padded, 0, sizeof(float) * D * Kp), "hipMemset") &&
+      hip_ok(hipMemcpy2D(padded, sizeof(float) * Kp, h->patch_w, sizeof(float) * K0, sizeof(float) * K0, D, hipMemcpyDeviceToDevice),
+             "hipMemcpy2D")) {
+    rc = split_h2(padded, Kp, D, Kp, w2, winv, nullptr);
+    if (rc == ANYLOC_OK) hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
   }
+  if (padded) (void)hipFree(padded);
+  if (rc != ANYLOC_OK) {
+    if (w2) (void)hipFree(w2);
+    if (winv) (void)hipFree(winv);
+  }
+  if (w_dev >= 0 && w_dev != prev_dev) (void)hipSetDevice(prev_dev);
+  if (rc != ANYLOC_OK) return rc;
+  h->patch_w2 = w2;
+  h->patch_inv = winv;
+  h->h2.assign(blocks, blocks + h->cfg.depth);
   return ANYLOC_OK;
 }
 

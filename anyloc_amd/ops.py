@@ -8,7 +8,7 @@ import json
 
 import torch
 
-from . import _lib, staging
+from . import _lib
 
 VLAD_NORM_DESCS = 1
 VLAD_INTRA_NORM = 2
@@ -17,11 +17,30 @@ FACETS = {"query": 0, "key": 1, "value": 2, "token": 3}
 VIT_USE_CLS, VIT_NORM_TAPS, VIT_NORM_CONCAT, VIT_SPLIT_BF16, VIT_SPLIT_FP16 = 1, 2, 4, 8, 16
 
 
+# ---- host <-> device transfers of the drop-in surface (CPU tensors in -> CPU tensors out) ----
+# The reference's scripts hand CPU tensors to VLAD.generate_multi (scripts/dino_v2_vlad.py:236-260: [n_img, 529, 1536],
+# 3.25 MB per image) and to get_top_k_recall (:372: [n_db, 49 152], 1.97 GB at 10 000 rows) and read CPU tensors back.
+# Measured on the MI355X box (tools/time_staging.py, profiles/r04_staging.log; pageable memory): tensor.to(device) 56 GB/s
+# at 0.8 - 2 GB (the PCIe rate), .cpu() 37 GB/s at 3 MB and 6 - 7 GB/s at >= 0.8 GB (first-touch page faults of the result);
+# a pinned ring + DMA (SURVEY 8(b)'s plan) was built in round 4 and measured 4 - 5x slower (the host memcpy into the ring), so
+# these two functions -- the one place the product moves bytes between host and device -- are plain torch copies.
+def to_device(t, device):
+    """Tensor -> same dtype and shape on ``device`` (asynchronous on the current stream for device sources; a copy from
+    pageable host memory returns once the runtime has staged it)."""
+    device = torch.device(device)
+    return t if t.device == device else t.to(device, non_blocking=True)
+
+
+def to_host(t):
+    """Device tensor -> CPU tensor (complete when the call returns)."""
+    return t if t.device.type == "cpu" else t.cpu()
+
+
 def _f32c(t, device=None):
-    """-> contiguous fp32 tensor (on ``device`` when given; staging.py: the plain copy is at the PCIe rate here); a dtype
-    conversion happens on the device, after the copy."""
+    """-> contiguous fp32 tensor (on ``device`` when given: ``to_device``, at the PCIe rate here); a dtype conversion
+    happens on the device, after the copy."""
     if device is not None and t.device != device:
-        t = staging.to_device(t, device)
+        t = to_device(t, device)
     if t.dtype != torch.float32:
         t = t.to(torch.float32)
     return t.contiguous()
@@ -34,7 +53,7 @@ def to_home(t, home):
     if t.device == home:
         return t
     if home.type == "cpu":
-        return staging.to_host(t)
+        return to_host(t)
     return t.to(home)
 
 

@@ -121,7 +121,7 @@ def gather_rows(local, counts, rank, group, comm):
 
 
 def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_descs=True,
-                   group=None, search_fn=None, counts=None):
+                   group=None, search_fn=None, counts=None, timings=None):
     """Database-sharded retrieval, one process per GPU.
 
     Every rank owns ``db_shard`` (rows ``shard_base ...`` of the global database)
@@ -131,8 +131,22 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
     rank 0 and merge on the host.  Returns (dist, idx) numpy arrays on rank 0,
     (None, None) elsewhere.  ``search_fn`` is injectable for CPU tests of the
     collective / merge logic.  ``counts`` (optional): the query rows of every rank when the caller knows them (static
-    shares, as in bench.py) -- saves the per-call all-gather of the counts and its host sync."""
+    shares, as in bench.py) -- saves the per-call all-gather of the counts and its host sync.  ``timings`` (optional dict):
+    an INSTRUMENTED call -- the device is drained after every leg and the legs' wall times land in it as
+    ``all_gather_ms`` / ``search_ms`` / ``gather_ms`` / ``merge_ms`` (bench.py reports them from an untimed step; the
+    timed steps run without the drains)."""
+    import time
+
     import torch.distributed as dist
+
+    def lap(name, t0):
+        if timings is None:
+            return t0
+        if qu_local.is_cuda:
+            torch.cuda.synchronize(qu_local.device)
+        t1 = time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + (t1 - t0) * 1e3
+        return t1
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     # RCCL moves device tensors over xGMI; a gloo group (CPU tests, single-GPU tests) is staged through the host
@@ -143,23 +157,32 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
         counts = [int(c) for c in cnt.cpu()]
     else:
         counts = [int(c) for c in counts]
-        assert len(counts) == world and counts[rank] == qu_local.shape[0], "counts must list every rank's query rows"
+        if len(counts) != world or counts[rank] != qu_local.shape[0]:
+            # (not an assert: under -O a mismatch would reach the collective and hang or corrupt rows)
+            raise ValueError(f"counts must list every rank's query rows: got {counts} for world size {world}, "
+                             f"rank {rank} holds {qu_local.shape[0]} rows")
+    t0 = lap("setup_ms", time.perf_counter()) if timings is not None else 0.0
     qu_all = gather_rows(qu_local, counts, rank, group, comm)
     if qu_all.device != qu_local.device:
         qu_all = qu_all.to(qu_local.device)
+    t0 = lap("all_gather_ms", t0)
     if search_fn is None:
         d, i = search(db_shard, qu_all, k, method, norm_descs)
         i = torch.where(i >= 0, i + shard_base, i)
     else:
         d, i = search_fn(db_shard, qu_all, k, method, norm_descs, shard_base)
+    t0 = lap("search_ms", t0)
     # ONE gather for both lists: the fp32 distances ride as their bit patterns next to the int64 indices
     packed = torch.cat([d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64), i.to(torch.int64)], dim=1).to(comm)
     out_p = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
     dst = 0 if group is None or group is dist.group.WORLD else dist.get_global_rank(group, 0)
     dist.gather(packed, out_p, dst=dst, group=group)
+    t0 = lap("gather_ms", t0)
     if rank != 0:
         return None, None
     kk = d.shape[1]
     host = [x.cpu() for x in out_p]
-    return merge_shard_topk([x[:, :kk].to(torch.int32).view(torch.float32).numpy() for x in host],
-                            [x[:, kk:].numpy() for x in host], k, "ip" if method == "cosine" else "l2")
+    res = merge_shard_topk([x[:, :kk].to(torch.int32).view(torch.float32).numpy() for x in host],
+                           [x[:, kk:].numpy() for x in host], k, "ip" if method == "cosine" else "l2")
+    lap("merge_ms", t0)
+    return res

@@ -247,7 +247,7 @@ class VLAD:
                        f"{self.cache_dir}/{cache_id}_t.pt")
 
     # images per launch when the descriptors arrive as one CPU tensor (scripts/dino_v2_vlad.py:236-260 hands over
-    # [n_img, 529, 1536]: 3.25 MB per image): bounds the device copy to ~6.6 GB while the pinned staging ring streams it
+    # [n_img, 529, 1536]: 3.25 MB per image): bounds one device copy to ~6.6 GB
     HOST_CHUNK_IMGS = 2048
 
     def _generate_batch(self, multi_query):

@@ -101,6 +101,92 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
     }
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU while the bench runs (make the power-cap argument
+    evidence).  One background thread reads the amdgpu hwmon files of the card -- ``power1_average`` / ``power1_input``
+    (microwatts), ``power1_cap``, ``freq1_input`` (sclk, Hz) -- every ``period`` seconds; where the hwmon files are
+    missing it falls back to one ``rocm-smi --showpower --showmaxpower --json`` call per second.  ``window(t0, t1)``
+    summarises the samples between two ``time.perf_counter()`` stamps.  Cost: three small sysfs reads per sample on a
+    host thread (no GPU work, no stream interaction); the bench's timed region ran within noise with and without it."""
+
+    def __init__(self, device_index=0, period=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.src, self.files, self.cap_w = None, {}, None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        # card order follows the PCI enumeration HIP uses on these boxes; with one visible GPU there is one candidate
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+        if cards:
+            hw = cards[min(device_index, len(cards) - 1)]
+            for key, names in (("power", ("power1_average", "power1_input")), ("cap", ("power1_cap",)), ("sclk", ("freq1_input",))):
+                for n in names:
+                    if os.path.exists(os.path.join(hw, n)):
+                        self.files[key] = os.path.join(hw, n)
+                        break
+            self.src = "hwmon:" + hw
+            cap = self._read(self.files.get("cap"))
+            self.cap_w = cap / 1e6 if cap else None
+        else:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.src = "rocm-smi"
+                self.period = max(period, 1.0)
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        if self.src:
+            self._thread.start()
+
+    @staticmethod
+    def _read(path):
+        if not path:
+            return None
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _smi(self):
+        import subprocess
+        try:
+            raw = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+            card = next(iter(json.loads(raw).values()))
+            pw = next((float(v) for k, v in card.items() if "Power (W)" in k and "Max" not in k), None)
+            cap = next((float(v) for k, v in card.items() if "Max" in k and "Power" in k), None)
+            if cap:
+                self.cap_w = cap
+            return pw
+        except Exception:  # noqa: BLE001
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            if self.src == "rocm-smi":
+                pw, clk = self._smi(), None
+            else:
+                pw = self._read(self.files.get("power"))
+                pw = pw / 1e6 if pw is not None else None
+                clk = self._read(self.files.get("sclk"))
+                clk = clk / 1e6 if clk is not None else None
+            self.samples.append((t, pw, clk))
+            self._stop.wait(self.period)
+
+    def stop(self):
+        self._stop.set()
+
+    def window(self, t0, t1):
+        pw = [p for (t, p, c) in self.samples if t0 <= t <= t1 and p is not None]
+        ck = [c for (t, p, c) in self.samples if t0 <= t <= t1 and c is not None]
+        if not pw:
+            return {"source": self.src, "samples": 0, "avg_w": None, "cap_w": self.cap_w, "sclk_mhz_avg": None}
+        return {"source": self.src, "samples": len(pw), "period_s": self.period, "avg_w": round(sum(pw) / len(pw), 1),
+                "max_w": round(max(pw), 1), "cap_w": self.cap_w,
+                "frac_of_cap": round(sum(pw) / len(pw) / self.cap_w, 3) if self.cap_w else None,
+                "sclk_mhz_avg": round(sum(ck) / len(ck), 0) if ck else None,
+                "sclk_mhz_min": round(min(ck), 0) if ck else None}
+
+
 def pmc_traffic(kernel, gemm):
     """HBM-side traffic of one launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     cannot be read in-process): profiles/pmc_traffic.json, written by tools/pmc_traffic.py from the counter CSVs of the
@@ -189,6 +275,26 @@ def max_over_ranks(elapsed, dist, dev):
     return float(t.item())
 
 
+def rccl_record(dist, world, legs, ms_per_step):
+    """What the first real multi-GPU run needs in one shot: the process group's shape and, from ONE instrumented
+    untimed step (device drained after every leg, retrieval.sharded_search(timings=...)), where a sharded step's time goes."""
+    rec = {"world_size": world, "backend": None, "n_gpus_visible": torch.cuda.device_count(),
+           "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    if dist is None:
+        rec["note"] = "single process, no process group (N = 1): the sharded step runs under `--gpus N` or ANYLOC_DIST_FORCE=1"
+        return rec
+    rec["backend"] = dist.get_backend()
+    if legs:
+        comm = legs.get("all_gather_ms", 0.0) + legs.get("gather_ms", 0.0)
+        rec["legs_ms"] = {k: round(v, 3) for k, v in legs.items()}
+        rec["comm_ms"] = round(comm, 3)
+        rec["comm_frac_of_step"] = round(comm / ms_per_step, 4) if ms_per_step else None
+        rec["legs_note"] = ("rank 0's wall time per leg of one extra, instrumented sharded retrieval (all-gather of the query VLADs "
+                            "over RCCL -> per-shard top-k -> one packed gather of the [Q,k] lists -> host k-way merge), each leg "
+                            "drained before the next starts; the timed steps run without the drains")
+    return rec
+
+
 def main_config3(args):
     """BASELINE.json configs[2]: 10 000 query VLADs against a 1 M-row database sharded 125 000 rows (24.6 GB) per GPU.
     One step = the whole retrieval: query descriptors all-gathered over RCCL, per-shard normalise + top-20 on the HIP
@@ -238,6 +344,9 @@ def main_config3(args):
     ops.profile_enable(False)
     prof = ops.profile_dump()
     elapsed = max_over_ranks(elapsed, dist, dev)
+    legs = {}
+    if dist is not None:                                                   # one instrumented step, every rank (collectives inside)
+        retrieval.sharded_search(db, shard_base, qu, TOPK, group=None, counts=q_counts, timings=legs)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -258,6 +367,7 @@ def main_config3(args):
                    "queries": NQ, "db_rows_per_gpu": NSHARD, "db_rows_total": NSHARD * world, "vlad_dim": KC * D, "k": TOPK,
                    "parallelism": f"db-shard{world}"},
         "planted_neighbours_found": planted_ok, "setup_s": round(t_setup, 1),
+        "rccl": rccl_record(dist, world, legs, elapsed / steps * 1e3),
         "dtype_note": "scores: operands as power-of-two-scaled two-term fp16 splits (22 bits), 3 fp16 MFMA products, fp32 accumulate "
                       "in K chunks of 8192; norms, merge and distances in fp32",
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
@@ -293,6 +403,9 @@ def main():
                     help="timed steps of each of the other GEMM arithmetics (0 = the same --steps as the headline mode)")
     ap.add_argument("--no-stages", action="store_true",
                     help="skip the `stages` block (k-means 5M x 1536, VLAD alone, one config-3 shard, ViT-L 518 two taps)")
+    ap.add_argument("--no-whole-jobs", action="store_true",
+                    help="skip the two whole-job stages (configs[1] as one 11 000-image job, ~35 s; configs[2] whole on one GPU, "
+                         "196.6 GB resident, ~15 s)")
     ap.add_argument("--workload", choices=["config2", "config3"], default="config2",
                     help="config2 (default): BASELINE.json configs[1], the bench line; config3: configs[2], retrieval of "
                          "10 000 queries against a database sharded 125 000 rows per GPU")
@@ -349,6 +462,7 @@ def main():
             if rank == 0:
                 results.append((d, idx))
 
+    sampler = PowerSampler(dev.index or 0) if rank == 0 else None
     for i in range(warm):
         step(i)
     # HIP events around EVERY launch cost the queue ~3 us each (450 per step): the timed region brackets only the launches
@@ -373,11 +487,18 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    elapsed = t_end - t0
+    power_timed = sampler.window(t0, t_end) if sampler is not None else None
     ops.profile_enable(False)
     prof_dom = ops.profile_dump()
     ops.profile_filter(None)
     elapsed = max_over_ranks(elapsed, dist, dev)
+    rccl_legs = {}
+    if dist is not None:                     # one instrumented retrieval of a step's queries, every rank (collectives inside)
+        q_probe = vlad.generate_multi(ext(qu_img[:B]))
+        retrieval.sharded_search(db, shard_base, q_probe, TOPK, group=None, counts=[B] * world, timings=rccl_legs)
+        del q_probe
     timed_results = list(results)            # (the untimed steps below and the `modes` block re-use and clear `results`)
     ops.profile_enable(True)
     ops.profile_reset()
@@ -417,6 +538,8 @@ def main():
         rec = retrieval.recalls_from_indices([1, 5, 10], idx_all, gt_timed)
 
     roofline = roofline_of(prof, args.gemm, value / world, steps)
+    # socket power / shader clock over the timed region (hwmon samples of a host thread): the evidence behind `power_limited`
+    roofline["power"] = power_timed
 
     out = {
         "metric": "images/sec (DINOv2->VLAD->top-k), ViT-G/14 L31 value K=32", "value": round(value, 3),
@@ -433,6 +556,7 @@ def main():
                    "weights": "random-init, hub layout (no checkpoint available offline)",
                    "parallelism": f"dp{world}+db-shard{world}" if dist is not None else "single"},
         "recall": rec, "setup_s": round(t_setup, 1), "roofline": roofline,
+        "rccl": rccl_record(dist, world, rccl_legs, elapsed / steps * 1e3),
     }
 
     # ---------------- CPU baseline + parity on a bounded sample (N=1 only) -----------------
@@ -500,13 +624,31 @@ def main():
     if world == 1 and not args.no_stages:
         # the other BASELINE.json configurations and the HBM-bound kernels, timed by the same process (driver clock)
         check = not args.no_cpu_baseline
-        b1 = stage_b1(ext, qu_img)
+        b1 = stage_b1(ext, qu_img, sampler)
+        # the scripts' DEFAULT image shape (configs.py:141 resize = [480, 640] -> 476 x 630 after the centre crop): T = 1531
+        img_480 = synth.synthetic_places(1, 8, 476, 630, seed=77, device=str(dev))[1]
+        b1_480 = stage_b1(ext, img_480, sampler, label="476x630 (the scripts' default resize [480, 640], centre-cropped)")
+        del img_480
         sp = stage_script_path(ext, vlad, db, qu_img, gt)
         del qu_img
+        full_job = None
+        if not args.no_whole_jobs:
+            del ext                                              # (the job builds its own extractor from the registered weights)
+            ext = None
+            _lib.release_workspaces()
+            torch.cuda.empty_cache()
+            full_job = stage_config2_full_job(dev)
         weights.unregister_state_dict(MODEL)
         out["stages"] = run_stages(dev, vlad, check)
         out["stages"]["vitg_b1"] = b1
+        out["stages"]["vitg_b1_480x640"] = b1_480
         out["stages"]["script_path_vitg"] = sp
+        if full_job is not None:
+            out["stages"]["config2_full_job"] = full_job
+            del db, sd
+            _lib.release_workspaces()
+            torch.cuda.empty_cache()
+            out["stages"]["config3_whole_db"] = stage_config3_whole_db(dev)
         bad = [k for k, v in out["stages"].items() if v.get("oracle_ok") is False]
         if bad and failed is None:
             failed = f"stage oracle spot-check failed: {bad}"
@@ -528,7 +670,8 @@ def main():
         summ["f32_mode"] = {"value": m["value"], "frac": m["frac"], "end_to_end_frac": m["end_to_end_frac"]}
     if "stages" in out:
         st = out["stages"]
-        summ["stages"] = {k: (v.get("images_per_s") or v.get("ms") or v.get("ms_per_image")) for k, v in st.items()}
+        summ["stages"] = {k: (v.get("images_per_s") or v.get("ms") or v.get("ms_per_image") or v.get("seconds_per_retrieval") or v.get("skipped"))
+                          for k, v in st.items()}
     out["roofline"]["checks"] = summ
     print(json.dumps(out), flush=True)
     if dist is not None:
@@ -701,17 +844,22 @@ def _timed(fn, iters, warm=1):
     return el, r, {k: round(v, 4) for k, v in sorted(best.items(), key=lambda kv: -kv[1])}
 
 
-def stage_b1(ext, qu_img):
+def stage_b1(ext, qu_img, sampler=None, label="322x322"):
     """The way the reference's scripts call the extractor (scripts/dino_v2_vlad.py:169-183: one image per call): ViT-g/14
-    322 x 322 at B = 1, tokens on the device: ~225 small launches whose own fill / k-step chain / drain is the time (dispatch
-    timestamps: 98 % inside the kernels, 0.17 us between them -- profiles/r04_b1_kernel_trace_gaps.md)."""
+    at B = 1, tokens on the device: ~225 small launches whose own fill / k-step chain / drain is the time (dispatch
+    timestamps: 98 % inside the kernels, 0.17 us between them -- profiles/r04_b1_kernel_trace_gaps.md).  ``qu_img`` [>=8,3,H,W]:
+    322 x 322 (the bench shape) or 476 x 630 = the scripts' default ``resize=[480, 640]`` (configs.py:141) centre-cropped
+    to multiples of 14 (scripts/dino_v2_vlad.py:173-176): 34 x 45 patches, T = 1531."""
     imgs = [qu_img[i:i + 1] for i in range(8)]
+    n_patch = (qu_img.shape[-2] // 14) * (qu_img.shape[-1] // 14)
     state = {"i": 0}
 
     def one():
         state["i"] = (state["i"] + 1) % len(imgs)
         return ext(imgs[state["i"]])
+    t_a = time.perf_counter()
     el, tok, kern = _timed(one, iters=40, warm=5)
+    t_b = time.perf_counter()
     # the same image as image 0 of a batch gives bitwise the same tokens (per-row arithmetic does not depend on the batch);
     # elsewhere in a batch its rows fall into other GLOBAL 32-row groups of attention_h3's per-tile scales (DESIGN 4.2b): the
     # same arithmetic on a differently grouped quantisation, equal to ~1e-7
@@ -720,14 +868,19 @@ def stage_b1(ext, qu_img):
     batch = ext(qu_img[:8])
     first = float((ext(imgs[0]) - batch[0:1]).abs().max())
     other = float((ext(imgs[3]) - batch[3:4]).abs().max())
-    fl = flops_per_image()
-    return {"workload": "DinoV2ExtractFeatures.__call__ at B=1, ViT-G/14 L31 value, 322x322 (the reference scripts' calling convention)",
-            "ms_per_image": round(el * 1e3, 3), "images_per_s": round(1.0 / el, 1),
-            "bound": "latency inside ~225 small launches (98 % of the time is inside kernels of a few hundred tiles each: fill, "
-                     "per-k-step chain, drain; 0.17 us between dependent launches -- DESIGN.md 4.1d)",
-            "achieved": round(fl / el / 1e12, 1), "unit": "TFLOP/s (algorithmic)", "kernels_ms": kern,
-            "oracle_ok": bool(max(first, other) <= 2e-6), "max_abs_diff_vs_batch_position_0": first,
-            "max_abs_diff_vs_batch_position_3": other}
+    fl = flops_per_image(n_patch=n_patch)
+    res = {"workload": f"DinoV2ExtractFeatures.__call__ at B=1, ViT-G/14 L31 value, {label}, T = {n_patch + 1} "
+                       "(the reference scripts' calling convention)",
+           "ms_per_image": round(el * 1e3, 3), "images_per_s": round(1.0 / el, 1),
+           "bound": "latency inside ~225 small launches (98 % of the time is inside kernels of a few hundred tiles each: fill, "
+                    "per-k-step chain, drain; 0.17 us between dependent launches -- DESIGN.md 4.1d)",
+           "achieved": round(fl / el / 1e12, 1), "unit": "TFLOP/s (algorithmic)",
+           "frac_of_fp16_div3_peak": round(fl / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "kernels_ms": kern,
+           "oracle_ok": bool(max(first, other) <= 2e-6), "max_abs_diff_vs_batch_position_0": first,
+           "max_abs_diff_vs_batch_position_3": other}
+    if sampler is not None:
+        res["power"] = sampler.window(t_a, t_b)
+    return res
 
 
 def stage_script_path(ext, vlad, db, qu_img, gt, n_img=256):
@@ -771,6 +924,24 @@ def stage_script_path(ext, vlad, db, qu_img, gt, n_img=256):
         ret.cpu(); d = time.perf_counter()
         legs["h2d"] += b - a; legs["forward"] += c - b; legs["d2h"] += d - c
     legs = {k: round(v / min(n_img, 64) * 1e3, 3) for k, v in legs.items()}
+    # VLAD.generate_multi on the CPU tensor (reference contract utilities.py:892-926: CPU in -> CPU out), leg by leg, from an
+    # instrumented pass of exactly what anyloc_amd/vlad.py:_generate_batch does: host -> device copy of the 832 MB of patch
+    # descriptors, the fused kernel, the [n_img, 49152] result back; then the call itself a second time (device buffers of
+    # the first call are back in the allocator's pool: what is left is the copy)
+    gm = {}
+    torch.cuda.synchronize(); a = time.perf_counter()
+    x_dev = ops._f32c(full_qu, dev); torch.cuda.synchronize(); b = time.perf_counter()
+    v_dev = ops.vlad(x_dev, vlad._centers_dev()); torch.cuda.synchronize(); c = time.perf_counter()
+    v_host = ops.to_home(v_dev, full_qu.device); d = time.perf_counter()
+    gm.update({"h2d_ms": round((b - a) * 1e3, 2), "h2d_gb_per_s": round(full_qu.numel() * 4 / (b - a) / 1e9, 1),
+               "kernel_call_ms": round((c - b) * 1e3, 2), "d2h_ms": round((d - c) * 1e3, 2),
+               "bytes_in": int(full_qu.numel() * 4), "bytes_out": int(v_host.numel() * 4)})
+    del x_dev, v_dev
+    a = time.perf_counter()
+    again = vlad.generate_multi(full_qu)
+    gm["second_call_total_ms"] = round((time.perf_counter() - a) * 1e3, 2)
+    gm["second_call_equal"] = bool(torch.equal(again, qu_vlads))
+    del again, v_host
     # the same images through the batched device path (what the headline line times).  One image per call runs other GEMM
     # plans than a batch (another summation order over k): tokens agree to ~1e-7, which may flip the cluster id of a token
     # whose two best centres are tied to fp32 rounding -- such a flip (float64 gap of the two centres' cosines < 1e-6) is
@@ -800,7 +971,7 @@ def stage_script_path(ext, vlad, db, qu_img, gt, n_img=256):
             "images_per_s": round(n_img / total, 1), "ms_per_image": round(total / n_img * 1e3, 3),
             "legs_ms": {"extract_loop_per_image": round((t1 - t0) / n_img * 1e3, 3),
                         "generate_multi_total": round((t2 - t1) * 1e3, 2), "get_top_k_recall_total": round((t3 - t2) * 1e3, 2),
-                        "per_image_instrumented": legs},
+                        "per_image_instrumented": legs, "generate_multi_legs": gm},
             "recall": {str(k): v for k, v in recalls.items()},
             "vs_batched_device_path": {"token_max_abs_diff": tok_err, "label_flips": int(flips.sum()),
                                        "largest_float64_gap_of_a_flip": gap, "vlad_max_rel_diff_in_images_without_a_flip": rel,
@@ -984,6 +1155,94 @@ def stage_vitl(dev, check, B=23):
             res.update({"oracle_ok": err <= 2e-5, "oracle_token_max_abs_err": err})
     finally:
         weights.unregister_state_dict(name)
+    torch.cuda.empty_cache()
+    return res
+
+
+def stage_config2_full_job(dev, n_db=10000, n_qu=1000, B=61):
+    """BASELINE.json configs[1] as ONE complete job through the reference's class surface (`utilities`), on the driver's clock:
+    10 000 database + 1 000 query images of 322 x 322 (synthetic places, generated on the device) -> DINOv2 ViT-G/14 layer-31
+    `value` tokens -> vocabulary (`VLAD.fit` on the tokens of every 20th database image) -> K = 32 VLADs of all 11 000 images
+    -> `get_top_k_recall` of the 1 000 x 10 000 x 49 152 search (what scripts/dino_v2_vlad.py:125-303 does, batches of 61
+    instead of one image per call).  Checks: every VLAD unit-norm, every query's top-1 is the place it depicts."""
+    import utilities
+    legs = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        legs[name] = round(time.perf_counter() - t0, 3)
+        return out
+    db_img, qu_img, gt = timed("synthesise_images_s", lambda: synth.synthetic_places(n_db, n_qu, HW, HW, seed=42, device=str(dev)))
+    ext = utilities.DinoV2ExtractFeatures(MODEL, LAYER, FACET, device=str(dev))
+    vl = utilities.VLAD(K_CLUSTERS, desc_dim=None, cache_dir=None)
+
+    def vocabulary():
+        sub = db_img[::20]
+        toks = torch.cat([ext(sub[i:i + B]) for i in range(0, len(sub), B)])
+        np.random.seed(42)
+        vl.fit(toks.reshape(-1, toks.shape[-1]))
+        return int(toks.shape[0] * toks.shape[1])
+
+    def describe(imgs):
+        out = torch.empty(len(imgs), K_CLUSTERS * 1536, dtype=torch.float32, device=dev)
+        for i in range(0, len(imgs), B):
+            out[i:i + B] = vl.generate_multi(ext(imgs[i:i + B]))
+        return out
+    n_tok = timed("vocabulary_s", vocabulary)
+    db_v = timed("database_vlads_s", lambda: describe(db_img))
+    qu_v = timed("query_vlads_s", lambda: describe(qu_img))
+    dists, idx, recalls = timed("get_top_k_recall_s", lambda: utilities.get_top_k_recall([1, 5, 10, TOPK], db_v, qu_v, gt))
+    descr = legs["database_vlads_s"] + legs["query_vlads_s"]
+    job = descr + legs["vocabulary_s"] + legs["get_top_k_recall_s"]
+    unit = bool(torch.allclose(db_v.norm(dim=1), torch.ones(n_db, device=dev), atol=1e-4))
+    idx_np = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
+    top1_ok = all(int(idx_np[i, 0]) in set(int(g) for g in gt[i]) for i in range(n_qu))
+    res = {"workload": f"BASELINE.json configs[1] as one job: {n_db} database + {n_qu} query images 322x322 -> ViT-G/14 L31 value -> "
+                       f"K=32 VLAD -> top-{TOPK} of {n_qu} x {n_db} x {K_CLUSTERS * 1536} (utilities.DinoV2ExtractFeatures / VLAD / "
+                       f"get_top_k_recall, batches of {B})",
+           "seconds": round(job, 2), "legs_s": legs, "vocabulary_tokens": n_tok, "kmeans_iterations": int(vl.kmeans.n_iter_),
+           "describe_images_per_s": round((n_db + n_qu) / descr, 1), "images_per_s": round((n_db + n_qu) / job, 1),
+           "recalls": {str(k): float(v) for k, v in recalls.items()}, "vlads_unit_norm": unit,
+           "every_query_top1_is_its_place": bool(top1_ok), "oracle_ok": bool(unit and top1_ok)}
+    del db_img, qu_img, db_v, qu_v, ext
+    torch.cuda.empty_cache()
+    return res
+
+
+def stage_config3_whole_db(dev, nq=10000, ndb=1_000_000):
+    """BASELINE.json configs[2] WHOLE on one GPU: 10 000 query VLADs against the full 1 M x 49 152 database (196.6 GB) resident
+    in this GPU's HBM, cosine top-20 (what eight GPUs do on 125 000-row shards each; the sharded route is `--workload
+    config3 --gpus N`).  Skipped with a note where the free HBM does not hold it."""
+    dv = K_CLUSTERS * 1536
+    need = ndb * dv * 4 + nq * dv * 4 + (12 << 30)               # database + queries + operand images / score panels / slack
+    free, total = torch.cuda.mem_get_info(dev)
+    if free < need:
+        return {"workload": "BASELINE.json configs[2] whole on one GPU", "skipped": f"free HBM {free / 2**30:.0f} GiB < {need / 2**30:.0f} GiB",
+                "oracle_ok": None}
+    t0 = time.perf_counter()
+    db = synthetic_db(ndb, K_CLUSTERS, 1536, dev, seed=100)
+    qu = synthetic_db(nq, K_CLUSTERS, 1536, dev, seed=500)
+    rows = (torch.arange(64, device=dev) * 15013 + 5) % ndb
+    qu[:64] = 0.9 * db[rows] + 0.1 * qu[:64]
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    retrieval.search(db[:8192], qu[:64], TOPK)                   # warm-up of the kernels / workspaces on a small panel
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d, i = retrieval.search(db, qu, TOPK)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    planted = bool((i[:64, 0] == rows).all())
+    flops = 2.0 * nq * ndb * dv
+    res = {"workload": f"BASELINE.json configs[2] WHOLE on one GPU: {nq} queries x {ndb} rows x {dv}-d resident in HBM ({ndb * dv * 4 / 1e9:.1f} GB), top-{TOPK}",
+           "seconds_per_retrieval": round(el, 3), "queries_per_s": round(nq / el, 1), "generate_db_s": round(t_gen, 1), "bound": "mfma",
+           "achieved": round(flops / el / 1e12, 1), "unit": "TFLOP/s (algorithmic, fp32-equivalent)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
+           "frac": round(flops / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "planted_neighbours_found": planted, "oracle_ok": planted}
+    del db, qu, d, i
+    _lib.release_workspaces()
     torch.cuda.empty_cache()
     return res
 

@@ -58,6 +58,17 @@ def _search_job(rank, world, out_dir):
             np.testing.assert_allclose(d, d_ref.numpy(), atol=1e-5)
         else:
             assert d is None and i is None
+    # static shares (what bench.py passes) with the instrumented legs: the same lists, every leg timed on every rank
+    legs = {}
+    d2, i2 = retrieval.sharded_search(shard, bounds[rank], q_loc, 10, search_fn=search_fn, counts=[4, 7], timings=legs)
+    assert {"all_gather_ms", "search_ms", "gather_ms"} <= set(legs) and all(v >= 0 for v in legs.values())
+    if rank == 0:
+        assert np.array_equal(i2, faiss_flat.flat_search(qu, db, 10, "ip")[1].numpy()) and "merge_ms" in legs
+    # shares that do not describe this rank's rows are refused BEFORE any collective (no assert: survives python -O)
+    with pytest.raises(ValueError):
+        retrieval.sharded_search(shard, bounds[rank], q_loc, 10, search_fn=search_fn, counts=[5, 6])
+    with pytest.raises(ValueError):
+        retrieval.sharded_search(shard, bounds[rank], q_loc, 10, search_fn=search_fn, counts=[11])
     if rank == 0:
         open(os.path.join(out_dir, "search_ok"), "w").write("1")
 

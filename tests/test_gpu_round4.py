@@ -90,9 +90,9 @@ def test_topk_index_identity_on_a_config3_panel():
 
 
 def test_host_device_transfers_round_trip():
-    """staging.to_device / to_host (the product's only host <-> device copies) move bytes unchanged: small and large tensors,
+    """ops.to_device / ops.to_host (the product's only host <-> device copies) move bytes unchanged: small and large tensors,
     non-contiguous sources, other dtypes, pinned sources."""
-    from anyloc_amd import staging
+    from anyloc_amd import ops as staging
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator().manual_seed(0)
     for shape, dtype in (((7, 13), torch.float32), ((3, 322, 322), torch.float32), ((40, 529, 1536), torch.float32),

@@ -208,6 +208,34 @@ def test_small_m_plans_agree_with_the_plain_kernels(batch):
         weights.unregister_state_dict(name)
 
 
+def test_split_k_hand_off_under_load():
+    """The split-K hand-off of gemm_h3_kernel.hpp (write-through sc1 slab stores, every wave drained, ONE relaxed agent-scope
+    ticket, the last arrival reads the slabs back with sc1 loads in split order) under load: a 3-block ViT-g forward at one
+    and at two images with split-K forced on EVERY block GEMM (64 x 64 tiles: up to 1 152 concurrent tiles x 8 splits per
+    launch, 15 launches per forward), 25 forwards per plan.  A stale slab read -- the failure this recipe could have --
+    shows as a run that differs from the first one: every run must be bit-identical, and within the k-order bar of the
+    unsplit plan."""
+    import utilities
+    from anyloc_amd import ops
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 4, device=DEV, depth=3))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
+        ext.dino_model.ffn_check_every = 0
+        for batch in (1, 2):
+            img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(70 + batch)).to(DEV)
+            with ops.options(h3s_cfg=0, h3s_kb=1, h3s_ksplit=1, h3s_stages=3):
+                unsplit = ext(img).clone()
+            for ks, st in ((8, 3), (3, 6), (2, 6)):
+                with ops.options(h3s_cfg=0, h3s_kb=1, h3s_ksplit=ks, h3s_stages=st):
+                    first = ext(img).clone()
+                    assert float((first - unsplit).abs().max()) <= 2e-6, (batch, ks)
+                    for rep in range(25):
+                        assert torch.equal(ext(img), first), (batch, ks, st, rep, "a split-K run differs from the first one")
+    finally:
+        weights.unregister_state_dict(name)
+
+
 def test_ffn_bound_telemetry_switches_a_loose_block_to_the_exact_quantiser():
     """h3 forward: the fused fc1 epilogue quantises the hidden activation against a Cauchy-Schwarz bound.  A weight set
     whose bound is far above the real activations (one fc1 row of huge norm along the direction LayerNorm's output never

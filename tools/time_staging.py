@@ -1,5 +1,5 @@
 """Host <-> device copy rates from pageable memory at the sizes the reference scripts move: one image, one image's tokens,
-256 images' tokens, the 10 000-row VLAD database (what anyloc_amd/staging.py does: plain tensor.to() / .cpu(); the pinned-ring
+256 images' tokens, the 10 000-row VLAD database (what anyloc_amd/ops.py (to_device / to_host) does: plain tensor.to() / .cpu(); the pinned-ring
 variant of round 4 is in profiles/r04_staging.log).     python tools/time_staging.py > gpurun_out/staging.log"""
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from anyloc_amd import staging  # noqa: E402
+from anyloc_amd import ops as staging  # noqa: E402  (the two copies live in ops.py since round 5)
 
 dev = torch.device("cuda", 0)
 for name, shape in (("image 3x322x322", (3, 322, 322)), ("tokens 529x1536", (529, 1536)), ("256 x tokens", (256, 529, 1536)),
