@@ -78,6 +78,7 @@ SIGNATURES = {
     "anyloc_attention_h3_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "anyloc_attention_h3": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vlad_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
+    "anyloc_vlad_auto_parts": (C.c_int, [c_i64, c_i64, c_i64, c_i64]),
     "anyloc_vlad_hard": (C.c_int, [c_f32p, c_i64p, c_i64, c_i64, c_i64, c_f32p, c_i64, C.c_uint,
                                    c_f32p, c_i64p, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vlad_soft": (C.c_int, [c_f32p, c_i64p, c_i64, c_i64, c_i64, c_f32p, c_i64, C.c_float,
@@ -111,7 +112,7 @@ SIGNATURES = {
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),
 }
 
-ABI_VERSION = 5          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
+ABI_VERSION = 6          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
 
 _lib = None
 

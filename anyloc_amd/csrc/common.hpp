@@ -93,6 +93,7 @@ enum Option {
   OPT_H3_PATCH,          // fp16 mode: patch embedding on the two-term fp16 GEMM (1, default) or the fp32 MFMA GEMM (0)
   OPT_TOPK_FEWQ_QDMA,    // few-query scores on fp16 planes: 1 = queries pre-split once, DMA'd into LDS per slab; 0 = split per slab
   OPT_H3S_W12_TALL,      // small-M plan of the w12 / fc1 GEMM of one image: 1 = 192 x 128 tiles (one workgroup per CU), 0 = 128 x 128
+  OPT_VLAD_SHIFT,        // fused VLAD: 1 = shifted accumulation against an 8-bit register-resident centre table (no per-token gather)
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -315,10 +316,56 @@ struct FusedArgs {
   int norm_descs, intra;
   int metric;              // 0 cosine (||chat_k|| = 1), 1 euclidean (chat = 2 c, cbias = -||c||^2): scales fused3's error bound
   int group;               // VLAD: 1 = a token with its predecessor's label reuses that token's centre columns (option vlad_group)
+  int shift;               // VLAD: > 0 = accumulate x^ - c~ against an 8-bit table of the centres (fetched per tile, label-independent),
+                           // exact remainder in the epilogue (option vlad_shift, default) -- the value is the waves per workgroup the
+                           // table in shift_tab was written for (fused3_shift_waves); 0 = gather the fp32 centre columns per token
+  unsigned* shift_tab;     // that table (F3_SHIFT_TAB_BYTES), written by the caller's centre-preparation launch (shift_table_thread)
   int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
   float* part_buf;         // [units, parts, K, D] partial sums
   unsigned* part_tickets;  // [units] arrival counters (zeroed by the launcher)
 };
+constexpr size_t F3_SHIFT_TAB_BYTES = 64 * 1024;
+// columns per lane of fused3_kernel: a wave owns SLICE = D / SW consecutive columns, CW consecutive ones per lane
+__host__ __device__ constexpr int f3_cw(int slice) {
+  int cw = (slice + 63) / 64;
+  while (slice % cw) ++cw;
+  return cw;
+}
+int fused3_shift_waves(int64_t D);
+// The byte table of fused3_kernel's SHIFT mode, once per call (it depends on the centres only).  Thread t = (wave, lane) of a
+// workgroup shaped like fused3's (64 sw threads) owns the CW columns gcol .. gcol + CW - 1 of every centre, as that kernel's
+// lane does: one power-of-two step >= max |c| / 127 over its columns and all clusters, bytes u = round(c / step) + 128
+// (c~ = (u - 128) step exactly), word g of vector j = clusters 4g .. 4g+3 of column j.  Layout: piece i (16 bytes = half a
+// vector) of all threads contiguous -- [2 CW][64 sw] x 16 B, then the steps' bit patterns [64 sw] -- so the per-tile fetch of
+// the kernel is 2 CW loads of whole 1-KiB runs per wave.
+__device__ inline void shift_table_thread(const float* __restrict__ centers, int K, int D, int sw, unsigned* __restrict__ tab, int t) {
+  const int nt = 64 * sw, slice = D / sw, cw = f3_cw(slice), gl = slice / cw, nq4 = 2 * cw;
+  const int lane = t & 63, wave = t >> 6;
+  const int gcol = wave * slice + cw * (lane < gl ? lane : 0);
+  float cm = 0.f;
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < cw; ++j) cm = fmaxf(cm, fabsf(centers[(int64_t)k * D + gcol + j]));
+  cm = fminf(cm, 1.0e30f);                      // (inf / huge centres: step huge, every byte 128, c~ = 0 = the plain sum)
+  // the power of two >= max |c| / 127 (0 -> 1: an all-zero lane quantises to zeros under any step)
+  unsigned sb = (__float_as_uint(cm * (1.0f / 127.0f)) + 0x007fffffu) & 0x7f800000u;
+  if (sb == 0u) sb = 0x3f800000u;
+  const float inv_step = __uint_as_float(0x7f000000u - sb);          // 1 / 2^e, exact
+  for (int j = 0; j < cw; ++j)
+    for (int g = 0; g < 8; ++g) {
+      unsigned word = 0x80808080u;
+      for (int b = 0; b < 4; ++b) {
+        const int k = 4 * g + b;
+        if (k < K) {
+          float v = rintf(centers[(int64_t)k * D + gcol + j] * inv_step);   // |v| <= 127 (NaN -> 0: the byte stays in range)
+          v = v == v ? fminf(fmaxf(v, -127.0f), 127.0f) : 0.0f;
+          word = (word & ~(0xffu << (8 * b))) | ((unsigned)((int)v + 128) << (8 * b));
+        }
+      }
+      const int i = 2 * j + g / 4, e = g % 4;                       // piece, dword within the piece
+      tab[((int64_t)i * nt + t) * 4 + e] = word;
+    }
+  tab[(int64_t)nq4 * nt * 4 + t] = sb;
+}
 bool fused_supported(int64_t D, int64_t K);
 int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream);
 

@@ -405,11 +405,6 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // register file of its SIMD lane, 256 VGPRs + 256 AGPRs).  Per wave at D = 1536: 96 / 192 accumulators + 48 / 96 registers
 // of fp16 centres + 48 / 96 registers of the next tile in flight.  Nothing may spill: a scratch reload waits -- the
 // vector-memory counter retires in order -- for the HBM loads of the next tile.
-constexpr int f3_cw(int slice) {
-  int cw = (slice + 63) / 64;
-  while (slice % cw) ++cw;
-  return cw;
-}
 constexpr int f3_gcd(int x, int y) { return y == 0 ? x : f3_gcd(y, x % y); }
 
 // CW consecutive fp32 columns of a lane as ONE memory instruction (CW = 3: buffer_load_dwordx3 -- a lane's columns start at a
@@ -446,8 +441,22 @@ __device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-template <int NV, int SW, bool KMEANS>
+// SHIFT (VLAD mode, CW <= 3; option vlad_shift, default on -- round 5): no per-token gather of the centre's columns from L2.
+// Sum_n (x^_n - c_k) = Sum_n (x^_n - c~_k) - n_k (c_k - c~_k): the accumulators collect x^ - c~ where c~ is an 8-BIT copy of the
+// centres that lives in REGISTERS (24 per lane at CW = 3: a lane's CW columns of all 32 clusters as bytes under one
+// power-of-two step per lane, step >= max |c| / 127 over the lane's columns, c~ = (u - 128) step exactly), and the exact
+// remainder n_k (c_k - c~_k) is subtracted ONCE in the epilogue from the fp32 centres (one CW-wide load per cluster).  Why not
+// plain Sum x^ - n_k c_k (k-means mode's loop): for a tight cluster the two terms cancel -- |x^ - c| ~ 1e-2 |c| and n_k = 16
+// already loses 6 - 7 of the 24 bits, outside the 1e-5 bar (reference utilities.py:854-861 sums fp32 residuals).  With the
+// 8-bit shift the accumulator holds n_k (c - c~) + Sum (x^ - c): |c - c~| <= step / 2 ~ |c| / 100, and the rounding left is
+// ~1.4e-8 sqrt(n_k) n_k |c - c~| / |Sum (x^ - c)| -- 4e-6 for 529 tokens in ONE cluster at |x^ - c| = 1e-2, 1e-7 at n_k = 16
+// (tests/test_gpu_vlad_topk.py::test_vlad_tight_clusters).  Token order per (cluster, column) as before: deterministic.
+typedef unsigned f3_u32x8 __attribute__((ext_vector_type(8)));
+typedef int f3_i32x2 __attribute__((ext_vector_type(2)));
+
+template <int NV, int SW, bool KMEANS, bool SHIFT = false>
 __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
+  static_assert(!(KMEANS && SHIFT), "the shifted accumulation is a VLAD-mode structure");
   constexpr int D = NV * 128;
   constexpr int LD = D + 4;
   constexpr int NT3 = 64 * SW;
@@ -527,18 +536,27 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   // scoring phase, so the wave's VALU / MFMA work runs while the texture path accepts them (98 KB per tile and CU at
   // 64 B/clk is ~1 500 cycles; issued in one burst, every wave sat in that queue before it scored)
   static_assert(NF == 2 * NKB, "two staged float4 per k-block");
+  // (SHIFT: the staging addresses are rebuilt from an opaque copy of the thread id at every use -- hoisted out of the tile loop
+  // they are six registers that variant does not have, and a spilled loop invariant is reloaded behind the HBM loads in flight)
+  auto opaque_tid = [&]() {
+    int tt = tid;
+    if constexpr (SHIFT) asm volatile("" : "+v"(tt));
+    return tt;
+  };
   auto fetch_pair = [&](int t, auto kbc) {
     const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
+    const int ft = opaque_tid();
     static_for<2>([&](auto h) {
       constexpr int i = 2 * decltype(kbc)::value + decltype(h)::value, r = i % P, j = i / P;
-      const int f = tid + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
+      const int f = ft + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
       stg[j * P + r] = bload16(x_rsrc, (unsigned)((row * D + 4 * c4) * 4), so + (unsigned)(j * RSTEP * D * 4));
     });
   };
   auto stash = [&]() {
+    const int ft = opaque_tid();
 #pragma unroll
     for (int r = 0; r < P; ++r) {
-      const int f = tid + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
+      const int f = ft + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
       float* dst = tile + row * LD + 4 * c4;
 #pragma unroll
       for (int j = 0; j < NF / P; ++j) *reinterpret_cast<f32x4*>(dst + j * RSTEP * LD) = stg[j * P + r];
@@ -553,6 +571,27 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   const int gcol = wave * SLICE + CW * (lane < GL ? lane : 0);
   const __amdgpu_buffer_rsrc_t cen_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<float*>(KMEANS ? a.chat : a.centers)), 0, (KMEANS ? 32 : a.K) * D * 4, 0x00020000);
+
+  // ---- SHIFT: the byte table of the centres (f3_shift_table_kernel wrote it for this very (SW, CW) shape) is fetched from
+  //      L2 ONCE PER TILE, after the assign phase, into registers the scoring / assign temporaries have just left -- it does
+  //      not depend on the labels, so no round trip waits for them; held in registers for the whole kernel instead (24 more
+  //      live registers in the scoring phase) the kernel spilled 29 ----
+  f3_u32x8 qsh[SHIFT ? CW : 1];
+  float sh_step = 1.0f;
+  constexpr int NQ4 = 2 * CW;                   // 16-byte pieces of a lane's table
+  const __amdgpu_buffer_rsrc_t tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<unsigned*>(a.shift_tab)), 0, SHIFT ? (NQ4 * 16 + 4) * NT3 : 0, 0x00020000);
+  auto load_table = [&]() {
+    static_for<NQ4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const u32x4s r = __builtin_amdgcn_raw_buffer_load_b128(tab_rsrc, (unsigned)(tid * 16), (unsigned)(i * NT3 * 16), 0);
+      static_for<4>([&](auto e) { qsh[i / 2][4 * (i % 2) + (int)e] = r[(int)e]; });
+    });
+  };
+  if constexpr (SHIFT) {
+    static_assert(CW <= 3, "shift table: three pinned byte vectors at most");
+    sh_step = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, (unsigned)(tid * 4), (unsigned)(NQ4 * NT3 * 16), 0));
+  }
 
   // scoring coordinates: 16x16x32 fragments -- token / centre = lane & 15, 8 consecutive k at 8 (lane >> 4) of the k-block
   const int fr = lane & 15, fq = lane >> 4;
@@ -691,10 +730,15 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         if (bi == 0x7fffffff) bi = 0;
         amb[row] = close ? mask : 0u;
         lab[row] = live ? bi : -1;
-        if (!KMEANS) nrm[row] = a.norm_descs ? fmaxf(xn, 1e-12f) : 1.0f;
+        // (the INVERSE: one IEEE division per row here instead of one per row and LANE in the gather -- the same value)
+        if (!KMEANS) nrm[row] = a.norm_descs ? 1.0f / fmaxf(xn, 1e-12f) : 1.0f;
         if (live && !close && a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
       }
     }
+    // (issued here, not right after the scoring phase: with the 24 table registers live across the assign phase the kernel
+    // spills four loop invariants, and a spilled invariant is reloaded behind the HBM loads in flight.  The table is 51 KB that
+    // every workgroup reads every tile -- L2-resident; its round trip overlaps the barrier, the resolution and the label reads)
+    if constexpr (SHIFT) load_table();
     lds_barrier();
     // ---- exact resolution: the queued (row, centre) pairs are dealt round-robin to the waves (a close row has 2-3
     //      candidates; dealing whole rows left most waves idle behind the one that had a row), each scored exactly in
@@ -799,6 +843,52 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             if (wave == 0) my_count += (lane == kk[e]) ? 1u : 0u;
           }
         }
+      } else if constexpr (SHIFT) {
+        // x / ||x|| - c~_k with c~ from the register-resident byte table: no memory access but the LDS tile.  Four tokens per
+        // round (labels, inverse norms and columns in one LDS round trip), then per token: ONE region of GPR-index mode
+        // reads the CW words that hold cluster k's bytes (element k >> 2), a bit-field extract and a convert give u,
+        // c~ = u step - 128 step (exact), v = x inv - c~ (one fma), and the register-indexed add as in k-means mode.
+#pragma unroll 1
+        for (int n2 = 0; n2 < TT; n2 += 2) {                  // (two tokens per round: four cost this variant 10 registers it does not have)
+          const f3_i32x2 lq = *reinterpret_cast<const f3_i32x2*>(lab + n2);
+          const f32x2 nq = *reinterpret_cast<const f32x2*>(nrm + n2);
+          float v[2][CW];
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < CW; ++j) v[e][j] = tp[(n2 + e) * LD + j];
+          int kk[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int kq = kk[e] < 0 ? 0 : kk[e];
+            const int g = kq >> 2;
+            const unsigned sh = (unsigned)(kq & 3) * 8u;
+            unsigned w[CW];
+            if constexpr (CW == 1) {
+              asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v216\n\ts_set_gpr_idx_off"
+                           : "=&v"(w[0]) : "s"(g), "{v[216:223]}"(qsh[0]));
+            } else if constexpr (CW == 2) {
+              asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v176\n\tv_mov_b32 %1, v184\n\ts_set_gpr_idx_off"
+                           : "=&v"(w[0]), "=&v"(w[1]) : "s"(g), "{v[176:183]}"(qsh[0]), "{v[184:191]}"(qsh[1]));
+            } else {
+              asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v136\n\tv_mov_b32 %1, v144\n\tv_mov_b32 %2, v152\n\t"
+                           "s_set_gpr_idx_off"
+                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+                           : "s"(g), "{v[136:143]}"(qsh[0]), "{v[144:151]}"(qsh[1]), "{v[152:159]}"(qsh[2]));
+            }
+            float r[CW];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+              // c~ = (u - 128) step: both operations exact (small integers, a power-of-two step)
+              const float ct = ((float)__builtin_amdgcn_ubfe(w[j], sh, 8u) - 128.0f) * sh_step;
+              r[j] = __builtin_fmaf(v[e][j], nq[e], -ct);
+            }
+            add_token(kk[e], r);
+            my_count += (lane == kk[e]) ? 1u : 0u;       // every wave counts (all of them need n_k in the epilogue)
+          }
+        }
       } else {
         // x / ||x|| - c_k.  The centres' CW columns of TG tokens are requested at once -- one CW-wide load per token, TT / TG
         // L2 round trips per tile (round 3: four rounds of four tokens, CW dword loads each, every round waiting for its
@@ -843,7 +933,7 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
               float v[CW];
 #pragma unroll
               for (int j = 0; j < CW; ++j) v[j] = tp[(g0 + n4 + e) * LD + j];
-              const float inv = 1.0f / nq[e];
+              const float inv = nq[e];
 #pragma unroll
               for (int j = 0; j < CW; ++j) v[j] = v[j] * inv - c[n4 + e][j];
               add_token(kk[n4 + e], v);
@@ -857,6 +947,22 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     lds_barrier();
   }
 
+  if constexpr (SHIFT) {
+    // the exact remainder of the shift, once per cluster: acc = Sum (x^ - c~) - n_k (c - c~) = Sum (x^ - c)
+    load_table();                              // (a unit without tiles never loaded it)
+    static_for<32>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k < a.K) {
+        float c[CW];
+        f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)(k * D * 4), c);
+        const float nk = (float)__builtin_amdgcn_readlane((int)my_count, k);
+        static_for<CW>([&](auto j) {
+          const float ct = ((float)((qsh[(int)j][k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f) * sh_step;
+          acc[j][k] = __builtin_fmaf(-nk, c[(int)j] - ct, acc[j][k]);
+        });
+      }
+    });
+  }
   const bool g_live = lane < GL;
   // a lane's CW columns of cluster k travel as one CW-wide buffer access (idle lanes of a 48-lane slice point past the
   // descriptor: their stores are dropped, their loads return zeros)
@@ -976,11 +1082,18 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
 
 #undef x_rsrc
 
-template <int NV, int SW, bool KMEANS>
+template <int NV, int SW, bool KMEANS, bool SHIFT = false>
 int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
   constexpr int D = NV * 128;
+  if constexpr (!KMEANS && !SHIFT && f3_cw(D / SW) <= 3) {
+    if (a.shift == SW && a.shift_tab) return launch_fused3<NV, SW, false, true>(a, units, stream);
+  }
+  if constexpr (SHIFT) {
+    // (the table itself was written by the caller's centre-preparation launch: shift_table_thread, common.hpp)
+    static_assert((2 * f3_cw(D / SW) * 16 + 4) * 64 * SW <= F3_SHIFT_TAB_BYTES, "shift table region");
+  }
   const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32);
-  auto kern = fused3_kernel<NV, SW, KMEANS>;
+  auto kern = fused3_kernel<NV, SW, KMEANS, SHIFT>;
   static bool attr = false;
   if (!attr) {
     ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1023,6 +1136,18 @@ int launch_fused(const FusedArgs& a, int64_t units, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Waves per workgroup of the launch vlad_fused() will make for this width IF it runs the shifted accumulation (the shape the
+// byte table must be written for), 0 where that variant does not apply (option vlad_shift off, another kernel forced, CW > 3).
+int fused3_shift_waves(int64_t D) {
+  if (option(OPT_VLAD_SHIFT) == 0) return 0;
+  const int ver = (int)option(OPT_VLAD_FUSED_V);
+  if (!(ver == 0 || ver >= 3)) return 0;
+  if (!(D == 384 || D == 768 || D == 1024 || D == 1536)) return 0;
+  const int nv = (int)(D / 128);
+  const int sw = (nv % 2 == 0 && ver != 3) ? 8 : 4;
+  return f3_cw((int)(D / sw)) <= 3 ? sw : 0;
+}
 
 bool fused_supported(int64_t D, int64_t K) {
   return K >= 1 && K <= 32 && (D == 384 || D == 768 || D == 1024 || D == 1536);

@@ -207,13 +207,20 @@ def _offsets_for(tokens_list_or_tensor, device):
     return packed, offsets.to(device), n_img, D
 
 
+def vlad_auto_parts(n_img, n_tok_total, D, K):
+    """Workgroups per image the one-pass VLAD kernel would use for a batch of ``n_img`` images (``vlad(parts=...)``)."""
+    return int(_lib.load().anyloc_vlad_auto_parts(int(n_tok_total), int(n_img), int(D), int(K)))
+
+
 def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0,
-         return_labels=False, dist_mode="cosine"):
+         return_labels=False, dist_mode="cosine", parts=0):
     """VLAD descriptors of a batch of images.
 
     tokens: device tensor [n_img, N, D] / [N, D], or a list of [N_i, D] tensors.
     centers: [K, D].  ``dist_mode``: the metric of the hard assignment (the VLAD object's ``dist_mode``; the soft
-    weights are always cosine, as in the reference).  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
+    weights are always cosine, as in the reference).  ``parts`` (hard mode): workgroups per image as the caller's choice
+    (ANYLOC_VLAD_PARTS; 0 = the library's) -- a batch handed over in pieces keeps the bits of the one-call result when every
+    piece passes the whole batch's count.  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
     device = _lib.require_gpu()
     centers = _f32c(centers, device)
     K, D = centers.shape
@@ -227,7 +234,7 @@ def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_te
     if dist_mode not in ("cosine", "euclidean"):
         raise NotImplementedError(f"dist_mode {dist_mode!r}")
     flags = (VLAD_NORM_DESCS if norm_descs else 0) | (VLAD_INTRA_NORM if intra_norm else 0) | \
-        (VLAD_EUCLIDEAN if dist_mode == "euclidean" else 0)
+        (VLAD_EUCLIDEAN if dist_mode == "euclidean" else 0) | ((int(parts) & 0x7f) << 8)
     ws_bytes = lib.anyloc_vlad_workspace_bytes(total, n_img, D, K)
     ws = _lib.workspace(ws_bytes, device, "vlad")
     if mode == "hard":

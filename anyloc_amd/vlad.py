@@ -246,9 +246,11 @@ class VLAD:
             torch.save({"format": LAZY_FORMAT, "tokens": xh.cpu(), "num_clusters": self.num_clusters},
                        f"{self.cache_dir}/{cache_id}_t.pt")
 
-    # images per launch when the descriptors arrive as one CPU tensor (scripts/dino_v2_vlad.py:236-260 hands over
-    # [n_img, 529, 1536]: 3.25 MB per image): bounds one device copy to ~6.6 GB
-    HOST_CHUNK_IMGS = 2048
+    # Descriptors that arrive as ONE CPU tensor (scripts/dino_v2_vlad.py:236-260 hands over [n_img, 529, 1536]: 3.25 MB per image)
+    # go to the device in chunks of ~256 MB: the copy runs at the PCIe rate either way (56 GB/s), but the device buffer of a
+    # chunk is allocated once and reused by the next chunk, where ONE 832 MB buffer for 256 images cost the first call 33 ms
+    # of allocation on top of the 15 ms copy (bench stage script_path_vitg, `generate_multi_legs`)
+    HOST_CHUNK_BYTES = 256 << 20
 
     def _generate_batch(self, multi_query):
         """[n_img,N,D] tensor or list of [N_i,D] -> [n_img, K*D] on the inputs' device."""
@@ -261,9 +263,15 @@ class VLAD:
                   soft_temp=self.soft_temp, dist_mode=self.mode)
         c = self._centers_dev()
         n = len(multi_query)
-        if home.type == "cpu" and n > self.HOST_CHUNK_IMGS:
-            out = torch.cat([ops.vlad(multi_query[s:s + self.HOST_CHUNK_IMGS], c, **kw)
-                             for s in range(0, n, self.HOST_CHUNK_IMGS)])
+        step = n
+        if home.type == "cpu" and isinstance(multi_query, torch.Tensor) and n > 1:
+            per_img = max(1, multi_query[0].numel() * 4)
+            step = max(1, self.HOST_CHUNK_BYTES // per_img)
+        if step < n:
+            # every piece with the workgroups-per-image count of the WHOLE batch: the bits of the one-call result
+            if self.vlad_mode == "hard":
+                kw["parts"] = ops.vlad_auto_parts(n, n * multi_query.shape[1], multi_query.shape[2], c.shape[0])
+            out = torch.cat([ops.vlad(multi_query[s:s + step], c, **kw) for s in range(0, n, step)])
         else:
             out = ops.vlad(multi_query, c, **kw)
         return ops.to_home(out, home)

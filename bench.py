@@ -102,36 +102,53 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
 
 
 class PowerSampler:
-    """Socket power and shader clock of one GPU while the bench runs (make the power-cap argument
-    evidence).  One background thread reads the amdgpu hwmon files of the card -- ``power1_average`` / ``power1_input``
-    (microwatts), ``power1_cap``, ``freq1_input`` (sclk, Hz) -- every ``period`` seconds; where the hwmon files are
-    missing it falls back to one ``rocm-smi --showpower --showmaxpower --json`` call per second.  ``window(t0, t1)``
-    summarises the samples between two ``time.perf_counter()`` stamps.  Cost: three small sysfs reads per sample on a
-    host thread (no GPU work, no stream interaction); the bench's timed region ran within noise with and without it."""
+    """Socket power and shader clock of the bench's GPU while it runs (make the power-cap argument
+    evidence).  One background thread reads the amdgpu hwmon files -- ``power1_average`` / ``power1_input`` (microwatts),
+    ``power1_cap``, ``freq1_input`` (sclk, Hz) -- every ``period`` seconds.  The box exposes the hwmon nodes of ALL its GPUs
+    while the container sees one: the card is the one whose PCI address equals the HIP device's (torch device properties);
+    where that cannot be read every card is sampled and the one that draws the most over the window is reported
+    (``picked_by`` says which rule applied).  No hwmon: one ``rocm-smi --showpower --showmaxpower --json`` call per second.
+    ``window(t0, t1)`` summarises the samples between two ``time.perf_counter()`` stamps.  Cost: a few small sysfs reads
+    per sample on a host thread (no GPU work, no stream interaction)."""
 
     def __init__(self, device_index=0, period=0.02):
         import glob
         import threading
         self.period, self.samples, self._stop = period, [], threading.Event()
-        self.src, self.files, self.cap_w = None, {}, None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        # card order follows the PCI enumeration HIP uses on these boxes; with one visible GPU there is one candidate
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
-        if cards:
-            hw = cards[min(device_index, len(cards) - 1)]
+        self.src, self.cards, self.picked_by = None, [], None
+        nodes = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:  # noqa: BLE001
+            want = None
+        for hw in nodes:
+            files = {}
             for key, names in (("power", ("power1_average", "power1_input")), ("cap", ("power1_cap",)), ("sclk", ("freq1_input",))):
                 for n in names:
                     if os.path.exists(os.path.join(hw, n)):
-                        self.files[key] = os.path.join(hw, n)
+                        files[key] = os.path.join(hw, n)
                         break
-            self.src = "hwmon:" + hw
-            cap = self._read(self.files.get("cap"))
-            self.cap_w = cap / 1e6 if cap else None
+            if "power" in files:
+                pci = os.path.basename(os.path.realpath(os.path.join(hw, "..", ".."))).lower()
+                cap = self._read(files.get("cap"))
+                self.cards.append({"hwmon": hw, "pci": pci, "files": files, "cap_w": cap / 1e6 if cap else None})
+        match = [c for c in self.cards if want and c["pci"].startswith(want)]
+        if match:
+            self.cards, self.picked_by = match[:1], "pci address " + want
+        elif len(self.cards) > 1:
+            self.picked_by = f"highest average power of the box's {len(self.cards)} cards (HIP device pci {want} not found in sysfs)"
+        elif self.cards:
+            self.picked_by = "the only card"
+        if self.cards:
+            self.src = "hwmon"
         else:
             import shutil
             if shutil.which("rocm-smi"):
-                self.src = "rocm-smi"
+                self.src, self.picked_by = "rocm-smi", "first card of rocm-smi"
                 self.period = max(period, 1.0)
+                self.cards = [{"hwmon": None, "pci": None, "files": {}, "cap_w": None}]
         self._thread = threading.Thread(target=self._run, daemon=True)
         if self.src:
             self._thread.start()
@@ -154,7 +171,7 @@ class PowerSampler:
             pw = next((float(v) for k, v in card.items() if "Power (W)" in k and "Max" not in k), None)
             cap = next((float(v) for k, v in card.items() if "Max" in k and "Power" in k), None)
             if cap:
-                self.cap_w = cap
+                self.cards[0]["cap_w"] = cap
             return pw
         except Exception:  # noqa: BLE001
             return None
@@ -163,28 +180,36 @@ class PowerSampler:
         while not self._stop.is_set():
             t = time.perf_counter()
             if self.src == "rocm-smi":
-                pw, clk = self._smi(), None
+                row = [(self._smi(), None)]
             else:
-                pw = self._read(self.files.get("power"))
-                pw = pw / 1e6 if pw is not None else None
-                clk = self._read(self.files.get("sclk"))
-                clk = clk / 1e6 if clk is not None else None
-            self.samples.append((t, pw, clk))
+                row = []
+                for c in self.cards:
+                    pw, clk = self._read(c["files"].get("power")), self._read(c["files"].get("sclk"))
+                    row.append((pw / 1e6 if pw is not None else None, clk / 1e6 if clk is not None else None))
+            self.samples.append((t, row))
             self._stop.wait(self.period)
 
     def stop(self):
         self._stop.set()
 
     def window(self, t0, t1):
-        pw = [p for (t, p, c) in self.samples if t0 <= t <= t1 and p is not None]
-        ck = [c for (t, p, c) in self.samples if t0 <= t <= t1 and c is not None]
-        if not pw:
-            return {"source": self.src, "samples": 0, "avg_w": None, "cap_w": self.cap_w, "sclk_mhz_avg": None}
-        return {"source": self.src, "samples": len(pw), "period_s": self.period, "avg_w": round(sum(pw) / len(pw), 1),
-                "max_w": round(max(pw), 1), "cap_w": self.cap_w,
-                "frac_of_cap": round(sum(pw) / len(pw) / self.cap_w, 3) if self.cap_w else None,
+        rows = [r for (t, r) in self.samples if t0 <= t <= t1]
+        best = None
+        for ci, c in enumerate(self.cards):
+            pw = [r[ci][0] for r in rows if r[ci][0] is not None]
+            ck = [r[ci][1] for r in rows if r[ci][1] is not None]
+            if pw and (best is None or sum(pw) / len(pw) > best[0]):
+                best = (sum(pw) / len(pw), pw, ck, c)
+        if best is None:
+            return {"source": self.src, "samples": 0, "avg_w": None, "cap_w": None, "sclk_mhz_avg": None, "picked_by": self.picked_by}
+        avg, pw, ck, c = best
+        return {"source": self.src, "card": c["hwmon"], "pci": c["pci"], "picked_by": self.picked_by, "samples": len(pw),
+                "period_s": self.period, "avg_w": round(avg, 1), "max_w": round(max(pw), 1), "cap_w": c["cap_w"],
+                "frac_of_cap": round(avg / c["cap_w"], 3) if c["cap_w"] else None,
                 "sclk_mhz_avg": round(sum(ck) / len(ck), 0) if ck else None,
-                "sclk_mhz_min": round(min(ck), 0) if ck else None}
+                "sclk_mhz_max": round(max(ck), 0) if ck else None,
+                "sclk_note": "hwmon freq1_input; under rocm-smi this node reads the ~94 MHz sleep-state marker when the clock is "
+                             "firmware-managed -- the PMC passes (profiles/r04_pmc_summary.md) give the in-kernel clock"}
 
 
 def pmc_traffic(kernel, gemm):
@@ -1060,7 +1085,9 @@ def stage_vlad(dev, vlad, n_img, check):
     el, v, kern = _timed(lambda: ops.vlad(toks, c), iters=20, warm=2)
     per_img = (529 * 1536 + 2 * 32 * 1536) * 4
     k_ms = kern.get("vlad_fused", sum(kern.values()))      # the roofline is the kernel's; the call's wall time alongside
-    res = {"workload": f"fused VLAD kernel, {n_img} images x 529 tokens x 1536, K=32", "kernel_ms": round(k_ms, 4),
+    res = {"workload": f"fused VLAD kernel, {n_img} images x 529 tokens x 1536, K=32 (shifted accumulation against the 8-bit centre "
+                       "table, option vlad_shift = 1: no per-token centre gather)", "kernel_ms": round(k_ms, 4),
+           "call_kernels_ms": round(sum(kern.values()), 4),      # + the centre preparation launch (normalised centres, byte table)
            "call_wall_ms": round(el * 1e3, 4), "bound": "hbm", "algorithmic_bytes": per_img * n_img,
            "achieved": round(per_img * n_img / (k_ms * 1e-3) / 1e12, 3), "peak": PEAK_HBM_TBPS, "unit": "TB/s",
            "frac": round(per_img * n_img / (k_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
@@ -1164,7 +1191,8 @@ def stage_config2_full_job(dev, n_db=10000, n_qu=1000, B=61):
     10 000 database + 1 000 query images of 322 x 322 (synthetic places, generated on the device) -> DINOv2 ViT-G/14 layer-31
     `value` tokens -> vocabulary (`VLAD.fit` on the tokens of every 20th database image) -> K = 32 VLADs of all 11 000 images
     -> `get_top_k_recall` of the 1 000 x 10 000 x 49 152 search (what scripts/dino_v2_vlad.py:125-303 does, batches of 61
-    instead of one image per call).  Checks: every VLAD unit-norm, every query's top-1 is the place it depicts."""
+    instead of one image per call).  Checks: every VLAD unit-norm; indices, distances and recalls of all 1 000 retrievals
+    identical to an exact float64 flat search over the job's own VLADs."""
     import utilities
     legs = {}
 
@@ -1198,15 +1226,21 @@ def stage_config2_full_job(dev, n_db=10000, n_qu=1000, B=61):
     descr = legs["database_vlads_s"] + legs["query_vlads_s"]
     job = descr + legs["vocabulary_s"] + legs["get_top_k_recall_s"]
     unit = bool(torch.allclose(db_v.norm(dim=1), torch.ones(n_db, device=dev), atol=1e-4))
-    idx_np = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
-    top1_ok = all(int(idx_np[i, 0]) in set(int(g) for g in gt[i]) for i in range(n_qu))
+    # every one of the job's retrievals against an exact float64 flat search over its own VLADs (indices, distances, recalls)
+    t_idx = torch.as_tensor(np.asarray(idx.cpu() if torch.is_tensor(idx) else idx), device=dev)
+    t_dst = torch.as_tensor(np.asarray(dists.cpu() if torch.is_tensor(dists) else dists), device=dev)
+    rchk = retrieval_identity([(t_dst, t_idx, qu_v)], db_v, gt)
     res = {"workload": f"BASELINE.json configs[1] as one job: {n_db} database + {n_qu} query images 322x322 -> ViT-G/14 L31 value -> "
                        f"K=32 VLAD -> top-{TOPK} of {n_qu} x {n_db} x {K_CLUSTERS * 1536} (utilities.DinoV2ExtractFeatures / VLAD / "
                        f"get_top_k_recall, batches of {B})",
            "seconds": round(job, 2), "legs_s": legs, "vocabulary_tokens": n_tok, "kmeans_iterations": int(vl.kmeans.n_iter_),
            "describe_images_per_s": round((n_db + n_qu) / descr, 1), "images_per_s": round((n_db + n_qu) / job, 1),
            "recalls": {str(k): float(v) for k, v in recalls.items()}, "vlads_unit_norm": unit,
-           "every_query_top1_is_its_place": bool(top1_ok), "oracle_ok": bool(unit and top1_ok)}
+           "recall_note": "random-init weights: Recall@k says how often a noisy, shifted query finds its own synthetic place, not how "
+                          "good DINOv2 is; the check is identity with the float64 search",
+           "retrieval_vs_float64": {k: rchk[k] for k in ("queries", "index_mismatches", "near_tie_swaps", "max_distance_err",
+                                                         "recall_identical", "ok")},
+           "oracle_ok": bool(unit and rchk["ok"])}
     del db_img, qu_img, db_v, qu_v, ext
     torch.cuda.empty_cache()
     return res

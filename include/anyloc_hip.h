@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 5
+#define ANYLOC_ABI_VERSION 6
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -65,6 +65,9 @@ const char* anyloc_last_error(void);
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
  *   vlad_group (0)                    fused VLAD gather: 1 = a token with its predecessor's label reuses that token's centre columns
+ *   vlad_shift (1)                    fused VLAD: residuals accumulated against an 8-bit copy of the centres held in registers, the exact
+ *                                     remainder n_k (c_k - c~_k) subtracted once per cluster; 0 = the centre's fp32 columns gathered from
+ *                                     L2 per token (round 4)
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
@@ -218,8 +221,17 @@ int anyloc_attention_h3(const float* qkv, void* out_img, float* out_inv, int64_t
 #define ANYLOC_VLAD_NORM_DESCS 1u
 #define ANYLOC_VLAD_INTRA_NORM 2u
 #define ANYLOC_VLAD_EUCLIDEAN 4u   /* labels by the fpk euclidean similarity (VLAD(dist_mode="euclidean")) instead of cosine */
+/* ABI 6: workgroups per image of the one-pass kernel as the CALLER's choice, p in 1..64 (0 = the library's own choice from
+ * the image count, anyloc_vlad_auto_parts).  An image's partial sums are added in part order, so its bits depend on p and
+ * on nothing else: a caller that hands one batch over in several calls (the host surface streams a CPU tensor in
+ * ~256 MB pieces) passes the count the WHOLE batch would have got and receives the bits of the one-call result.  Ignored
+ * where the general two-pass path serves the call.  p must not exceed the count the workspace was sized for
+ * (anyloc_vlad_workspace_bytes sizes for the library's choice at the call's n_img; fewer images -> more parts, so the
+ * whole batch's count always fits a piece's workspace). */
+#define ANYLOC_VLAD_PARTS(p) (((unsigned)(p) & 0x7fu) << 8)
 size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img,
                                    int64_t D, int64_t K);
+int anyloc_vlad_auto_parts(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K);   /* the library's choice (1 where the one-pass kernel does not apply) */
 int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
                      int64_t total_tokens, int64_t D, const float* centers,
                      int64_t K, unsigned flags, float* out, int64_t* labels,

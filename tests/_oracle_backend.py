@@ -43,7 +43,7 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "l2norm_rows", lambda x, eps=1e-12, out=None: F.normalize(x.float(), dim=-1, eps=eps))
 
     def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0, return_labels=False,
-             dist_mode="cosine"):
+             dist_mode="cosine", parts=0):
         parts = list(tokens) if not isinstance(tokens, torch.Tensor) else list(tokens if tokens.ndim == 3 else tokens[None])
         outs, labs = [], []
         for t in parts:
@@ -110,6 +110,7 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "gemm_nt", lambda a, w, bias=None: a.float() @ w.float().t() + (0 if bias is None else bias))
     monkeypatch.setattr(ops, "_f32c", lambda t, device=None: t.detach().to("cpu", torch.float32).contiguous())
     monkeypatch.setattr(ops, "vlad", vlad)
+    monkeypatch.setattr(ops, "vlad_auto_parts", lambda n_img, n_tok, D, K: 1)
     monkeypatch.setattr(ops, "kmeans_step", kmeans_step)
     monkeypatch.setattr(ops, "kmeans_update", kmeans_update)
     monkeypatch.setattr(kmeans, "_local_step", kmeans_step)

@@ -360,3 +360,72 @@ def test_get_top_k_recall_surface():
     assert i.shape == (1, 1)
     with pytest.raises(NotImplementedError):
         utilities.get_top_k_recall([1], db, qu, gt, method="manhattan")
+
+
+def _vlad_f64(x, centers, labels):
+    """The reference expression (utilities.py:959-962, :854-861, :889) evaluated in float64 under a given assignment."""
+    K, D = centers.shape
+    xh = torch.nn.functional.normalize(x.double())
+    out = torch.zeros(K, D, dtype=torch.float64)
+    out.index_add_(0, labels, xh - centers.double()[labels])
+    out = torch.nn.functional.normalize(out, dim=1)
+    return torch.nn.functional.normalize(out.reshape(-1), dim=0)
+
+
+@pytest.mark.parametrize("shift", [1, 0])
+@pytest.mark.parametrize("D,case", [(1536, "random"), (1536, "one_cluster"), (1536, "outlier"), (1024, "random"),
+                                    (768, "one_cluster"), (384, "random")])
+def test_vlad_tight_clusters(D, case, shift):
+    """Tight clusters -- unit tokens 1e-2 away from a unit-norm centre -- on both accumulation structures of the fused kernel
+    (option vlad_shift: 1 = residuals against the 8-bit centre table + exact remainder per cluster, the default; 0 = the fp32
+    centre gathered per token).  The stress amplifies the one rounding every fp32 implementation shares (x^ = x / ||x||, good
+    to ~6e-8: ~6e-6 of a 1e-2 residual), so the yardstick is the reference's own fp32 arithmetic (the oracle): the kernel must
+    be as close to a float64 evaluation as the oracle is (factor 3 + 1e-6) and within 2e-5 of the oracle; a plain
+    sum x^ - n_k c_k would be off by 4e-5 ... 7e-4 here (tests/test_vlad_shift_numerics_cpu.py).  Few images (several
+    workgroups per image, partial sums handed over) and many (one workgroup per image); ids identical."""
+    from anyloc_amd import ops
+    ops.set_option("vlad_shift", shift)
+    K, N = 32, 529
+    g = torch.Generator().manual_seed(D + len(case))
+    c = torch.nn.functional.normalize(torch.randn(K, D, generator=g))
+    if case == "outlier":
+        c[:, 7] += 0.5                                     # a channel that is large in every centre
+        c[3, 100] = -0.9
+        c = torch.nn.functional.normalize(c)
+    for n_img in (3, 140):
+        lab = torch.full((n_img, N), 5, dtype=torch.long) if case == "one_cluster" else torch.randint(0, K, (n_img, N), generator=g)
+        x = c[lab] + (1e-2 / D ** 0.5) * torch.randn(n_img, N, D, generator=g)
+        x = x * (0.5 + 1.5 * torch.rand(n_img, N, 1, generator=g))           # raw tokens: the kernel normalises
+        out, lab_g = ops.vlad(x.to(DEV), c.to(DEV), return_labels=True)
+        assert torch.equal(lab_g.cpu().reshape(n_img, N), lab)
+        worst = 0.0
+        for i in (0, n_img // 2, n_img - 1):
+            v32 = vlad_ref.vlad_hard(x[i], c)[0]
+            v64 = _vlad_f64(x[i], c, lab[i])
+            e_or = float((v32.double() - v64).norm())
+            e_k = float((out[i].cpu().double() - v64).norm())
+            assert e_k <= 3.0 * e_or + 1e-6, (case, D, shift, n_img, i, e_k, e_or)
+            assert l2rel(out[i], v32) <= 2e-5, (case, D, shift, n_img, i, l2rel(out[i], v32))
+            worst = max(worst, e_k / max(e_or, 1e-30))
+        print(f"[tight {case} D={D} shift={shift} n_img={n_img}] kernel / oracle distance to float64: {worst:.2f}")
+
+
+def test_vlad_shift_and_gather_agree_on_ordinary_tokens():
+    """The two accumulation structures on ordinary descriptor-like tokens (the golden-vector regime): both within the 1e-5
+    bar of the oracle (tests above) and within 2e-6 of each other; ragged images, an empty image, K < 32, no intra-norm."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for D, K in ((1536, 32), (1024, 17), (384, 8)):
+        x = synth.clustered_tokens(5, 300, D, n_modes=K + 3, seed=D)
+        c = 0.7 * synth.clustered_tokens(1, K, D, n_modes=K, seed=D + 1)[0] + 0.01 * torch.randn(K, D, generator=g)
+        parts = [x[0], x[1, :0], x[2, :1], x[3, :77], x[4]]
+        for intra in (True, False):
+            with ops.options(vlad_shift=1):
+                a, la = ops.vlad([p.to(DEV) for p in parts], c.to(DEV), intra_norm=intra, return_labels=True)
+            with ops.options(vlad_shift=0):
+                b, lb = ops.vlad([p.to(DEV) for p in parts], c.to(DEV), intra_norm=intra, return_labels=True)
+            assert torch.equal(la, lb)
+            assert float(a[1].abs().max()) == 0.0 and float(b[1].abs().max()) == 0.0
+            for i in (0, 2, 3, 4):
+                assert l2rel(a[i], b[i]) <= 2e-6, (D, K, intra, i, l2rel(a[i], b[i]))
+                assert l2rel(a[i], vlad_ref.vlad_hard(parts[i], c, True, intra)[0]) < VLAD_RTOL

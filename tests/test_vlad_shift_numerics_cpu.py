@@ -1,0 +1,149 @@
+"""CPU emulation (NumPy fp32, operation by operation) of the fused VLAD kernel's SHIFTED accumulation
+(csrc/vlad_fused.hip, SHIFT; table: csrc/common.hpp ``shift_table_thread``) -- no GPU needed.
+
+The kernel does not gather the fp32 centre per token.  It accumulates ``x^ - c~`` where ``c~`` is an 8-bit copy of the
+centres under one power-of-two step per lane (a lane = CW consecutive columns of every cluster), and subtracts the exact
+remainder ``n_k (c_k - c~_k)`` once per cluster: ``sum (x^ - c_k)`` as the reference sums it (utilities.py:854-861), without
+the cancellation of the plain ``sum x^ - n_k c_k``.  This file pins the arithmetic claims the kernel comment makes:
+the table is exact (``c~`` representable, ``|c - c~| <= step / 2``), and the emulated accumulation meets the 1e-5 bar against
+float64 as well as the reference's own fp32 arithmetic does -- on ordinary tokens AND on tight clusters (``|x^ - c| ~ 1e-2``:
+16 tokens per cluster, all 529 tokens in ONE cluster, an outlier channel) -- where the plain-sum formulation demonstrably does
+not.
+"""
+import numpy as np
+import pytest
+
+CW = 3          # D = 1536 on 8 waves: 192 columns per wave, 3 per lane
+
+
+def shift_table(c):
+    """[K, D] fp32 centres -> (c_tilde [K, D] fp32, step [D // CW] fp32): per lane one power of two >= max |c| / 127."""
+    K, D = c.shape
+    lanes = c.reshape(K, D // CW, CW)
+    cm = np.minimum(np.abs(lanes).max(axis=(0, 2)), np.float32(1e30)).astype(np.float32)
+    bits = (cm * np.float32(1.0 / 127.0)).astype(np.float32).view(np.uint32)
+    sb = (bits + np.uint32(0x007FFFFF)) & np.uint32(0x7F800000)
+    sb = np.where(sb == 0, np.uint32(0x3F800000), sb).astype(np.uint32)
+    step = sb.view(np.float32)
+    inv = (np.uint32(0x7F000000) - sb).view(np.float32)
+    q = np.clip(np.rint(lanes * inv[None, :, None]), -127, 127).astype(np.float32)
+    u = (q + 128).astype(np.uint32)
+    assert u.min() >= 1 and u.max() <= 255
+    ct = ((u.astype(np.float32) - np.float32(128.0)) * step[None, :, None]).astype(np.float32)
+    return ct.reshape(K, D), step
+
+
+def vlad_shifted_fp32(x, c, labels):
+    """The kernel's arithmetic for one image, fp32 step by step in token order."""
+    K, D = c.shape
+    ct, _ = shift_table(c)
+    acc = np.zeros((K, D), np.float32)
+    cnt = np.zeros(K, np.float32)
+    for n in range(x.shape[0]):
+        k = labels[n]
+        nrm = np.float32(max(np.sqrt(np.float32((x[n] * x[n]).sum(dtype=np.float32))), np.float32(1e-12)))
+        inv = np.float32(1.0) / nrm
+        r = (x[n].astype(np.float64) * np.float64(inv) - ct[k].astype(np.float64)).astype(np.float32)   # one fma
+        acc[k] = acc[k] + r
+        cnt[k] += 1
+    rem = (c - ct).astype(np.float32)
+    out = (acc.astype(np.float64) - cnt[:, None].astype(np.float64) * rem.astype(np.float64)).astype(np.float32)    # one fma
+    return out
+
+
+def vlad_plain_fp32(x, c, labels):
+    """sum x^ - n_k c_k in fp32: what the shift exists to avoid."""
+    K, D = c.shape
+    acc = np.zeros((K, D), np.float32)
+    cnt = np.zeros(K, np.float32)
+    for n in range(x.shape[0]):
+        k = labels[n]
+        inv = np.float32(1.0) / np.float32(np.sqrt(np.float32((x[n] * x[n]).sum(dtype=np.float32))))
+        acc[k] = acc[k] + x[n] * inv
+        cnt[k] += 1
+    return (acc.astype(np.float64) - cnt[:, None].astype(np.float64) * c.astype(np.float64)).astype(np.float32)
+
+
+def vlad_reference_fp32(x, c, labels):
+    """The reference's own arithmetic (utilities.py:959-960, :854-857): F.normalize (a division), fp32 residuals, fp32 sums."""
+    K, D = c.shape
+    acc = np.zeros((K, D), np.float32)
+    for n in range(x.shape[0]):
+        nrm = np.float32(max(np.sqrt(np.float32((x[n] * x[n]).sum(dtype=np.float32))), np.float32(1e-12)))
+        acc[labels[n]] = acc[labels[n]] + ((x[n] / nrm).astype(np.float32) - c[labels[n]])
+    return acc
+
+
+def vlad_f64(x, c, labels):
+    xh = x.astype(np.float64) / np.linalg.norm(x.astype(np.float64), axis=1, keepdims=True)
+    out = np.zeros(c.shape, np.float64)
+    np.add.at(out, labels, xh - c.astype(np.float64)[labels])
+    return out
+
+
+def block_rel_err(got, ref):
+    """Worst relative L2 error of a cluster block (the VLAD intra-normalises every block: its relative error is what the
+    descriptor sees)."""
+    num = np.linalg.norm(got.astype(np.float64) - ref, axis=1)
+    den = np.linalg.norm(ref, axis=1)
+    used = den > 0
+    return float((num[used] / den[used]).max())
+
+
+def _centres(rng, K, D, outlier=False):
+    c = rng.standard_normal((K, D)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    c *= np.float32(0.8)
+    if outlier:
+        c[:, 7] += np.float32(0.5)          # a channel that is large in every centre (DINOv2-like outlier channel)
+        c[3, 100] = np.float32(-0.9)
+    return c
+
+
+def test_table_is_exact_and_close():
+    rng = np.random.default_rng(0)
+    for outlier in (False, True):
+        c = _centres(rng, 32, 1536, outlier)
+        ct, step = shift_table(c)
+        # powers of two, c~ = integer * step, |c - c~| <= step / 2, step < 2 max|c| / 127 per lane
+        assert np.all(np.log2(step) == np.round(np.log2(step)))
+        lanes_step = np.repeat(step, CW)[None, :]
+        assert np.all(np.abs(c - ct) <= lanes_step / 2 + 1e-12)
+        assert np.all((ct / lanes_step) == np.round(ct / lanes_step))
+        cm = np.abs(c.reshape(32, -1, CW)).max(axis=(0, 2))
+        assert np.all(step >= cm / 127) and np.all(step < 2 * cm / 127 + 1e-30)
+    # an all-zero lane and a zero matrix quantise to zeros
+    z = np.zeros((4, 12), np.float32)
+    ct, step = shift_table(z)
+    assert np.all(ct == 0) and np.all(step == 1)
+
+
+@pytest.mark.parametrize("case", ["ordinary", "tight_16_per_cluster", "tight_one_cluster", "tight_outlier_channel"])
+def test_shifted_accumulation_meets_the_bar_where_the_plain_sum_does_not(case):
+    rng = np.random.default_rng(5)
+    K, D, N = 32, 1536, 529
+    c = _centres(rng, K, D, outlier=case == "tight_outlier_channel")
+    if case == "ordinary":
+        labels = rng.integers(0, K, N)
+        x = c[labels] / 0.8 + (0.9 / np.sqrt(D)) * rng.standard_normal((N, D)).astype(np.float32)
+    else:
+        labels = np.zeros(N, np.int64) + 5 if case == "tight_one_cluster" else rng.integers(0, K, N)
+        ch = c / np.linalg.norm(c, axis=1, keepdims=True)
+        # unit tokens 1e-2 away from a UNIT-norm centre: the residual |x^ - c| ~ 1e-2 of the verdict's stress
+        c = ch.astype(np.float32)
+        x = c[labels] + (1e-2 / np.sqrt(D)) * rng.standard_normal((N, D)).astype(np.float32)
+    x = (x * rng.uniform(0.5, 2.0, (N, 1))).astype(np.float32)        # raw (unnormalised) tokens, as the extractor could hand over
+    ref = vlad_f64(x, c, labels)
+    e_shift = block_rel_err(vlad_shifted_fp32(x, c, labels), ref)
+    e_plain = block_rel_err(vlad_plain_fp32(x, c, labels), ref)
+    e_ref = block_rel_err(vlad_reference_fp32(x, c, labels), ref)
+    print(f"{case}: vs float64 -- shifted {e_shift:.2e}, the reference's own fp32 arithmetic {e_ref:.2e}, plain sum {e_plain:.2e}")
+    # Tight clusters amplify the ONE rounding every fp32 implementation shares -- x^ = x / ||x|| is good to ~6e-8 |x^|, i.e.
+    # ~6e-6 of a residual of 1e-2 -- so the yardstick is the reference's own arithmetic: the shifted accumulation must be as
+    # close to float64 as that is (factor 3 + 1e-6, the bar of tests/test_gpu_fullsize_parity.py), and inside 2e-5 absolutely; the plain sum is an order of magnitude off
+    assert e_shift <= 3.0 * e_ref + 1e-6, (case, e_shift, e_ref)
+    assert e_shift <= 2e-5
+    if case == "ordinary":
+        assert e_shift <= 1e-6
+    else:
+        assert e_plain > 3.0 * e_ref and e_plain > 2e-5, "the plain sum was expected to fail here: the stress no longer stresses"

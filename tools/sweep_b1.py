@@ -2,7 +2,7 @@
 every (tile configuration, k-blocks per ring stage, split-K factor) forced through the h3s_* options; per GEMM kind the
 time per launch from the library's HIP-event scopes, and the tokens' distance from the round-3 kernels (h3s_enable = 0).
 
-    python tools/sweep_b1.py [batches, e.g. 1,2,4] [configurations, e.g. 2,4] > gpurun_out/b1_plan_sweep.log
+    python tools/sweep_b1.py [batches, e.g. 1,2,4] [configurations, e.g. 2,4] [HxW, e.g. 476x630] [depth] > gpurun_out/b1_plan_sweep.log
 """
 import os
 import sys
@@ -17,8 +17,11 @@ import utilities  # noqa: E402
 
 dev = "cuda"
 name = "dinov2_vitg14"
-weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device=dev, depth=32))
-ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device=dev)
+H, W = (int(v) for v in sys.argv[3].split("x")) if len(sys.argv) > 3 else (322, 322)
+DEPTH = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device=dev, depth=DEPTH))
+ext = utilities.DinoV2ExtractFeatures(name, DEPTH - 1, "value", device=dev)
+KSPLITS = (1, 2, 3, 4, 6, 8) if (H, W) != (322, 322) else (1, 2, 3, 4)
 BATCHES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 2, 4)
 TAGS = {"qkv": "vit_qkv_gemm", "proj": "vit_proj_gemm", "fc1": "vit_w12_gemm", "fc2": "vit_fc2_gemm"}
 CFG_NAMES = ["64x64/2w", "64x128/2w(64x64)", "64x128/4w(32x64)", "64x128/2w(32x128)", "128x128/4w", "64x256/4w(64x64)",
@@ -48,7 +51,7 @@ def run(img, n):
 
 
 for B in BATCHES:
-    img = torch.randn(B, 3, 322, 322, device=dev)
+    img = torch.randn(B, 3, H, W, device=dev)
     n = 6
     with ops.options(h3s_enable=0):
         wall0, per0, tok0, other0 = run(img, n)
@@ -61,7 +64,7 @@ for B in BATCHES:
     for cfg in CFGS:
         for kb in (1, 2, 4):
             for st in (3, 6):
-                for ks in (1, 2, 3, 4):
+                for ks in KSPLITS:
                     with ops.options(h3s_cfg=cfg, h3s_kb=kb, h3s_ksplit=ks, h3s_stages=st, h3s_mask=15):
                         try:
                             wall, per, tok, _ = run(img, 4)
