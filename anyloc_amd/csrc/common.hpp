@@ -93,7 +93,7 @@ enum Option {
   OPT_H3_PATCH,          // fp16 mode: patch embedding on the two-term fp16 GEMM (1, default) or the fp32 MFMA GEMM (0)
   OPT_TOPK_FEWQ_QDMA,    // few-query scores on fp16 planes: 1 = queries pre-split once, DMA'd into LDS per slab; 0 = split per slab
   OPT_H3S_W12_TALL,      // small-M plan of the w12 / fc1 GEMM of one image: 1 = 192 x 128 tiles (one workgroup per CU), 0 = 128 x 128
-  OPT_VLAD_SHIFT,        // fused VLAD: 1 = shifted accumulation against an 8-bit register-resident centre table (no per-token gather)
+  OPT_VLAD_SHIFT,        // fused VLAD: 1 = shifted accumulation against an 8-bit centre table (no per-token gather; measured slower, default 0)
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -317,7 +317,7 @@ struct FusedArgs {
   int metric;              // 0 cosine (||chat_k|| = 1), 1 euclidean (chat = 2 c, cbias = -||c||^2): scales fused3's error bound
   int group;               // VLAD: 1 = a token with its predecessor's label reuses that token's centre columns (option vlad_group)
   int shift;               // VLAD: > 0 = accumulate x^ - c~ against an 8-bit table of the centres (fetched per tile, label-independent),
-                           // exact remainder in the epilogue (option vlad_shift, default) -- the value is the waves per workgroup the
+                           // exact remainder in the epilogue (option vlad_shift) -- the value is the waves per workgroup the
                            // table in shift_tab was written for (fused3_shift_waves); 0 = gather the fp32 centre columns per token
   unsigned* shift_tab;     // that table (F3_SHIFT_TAB_BYTES), written by the caller's centre-preparation launch (shift_table_thread)
   int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
@@ -342,27 +342,35 @@ __device__ inline void shift_table_thread(const float* __restrict__ centers, int
   const int nt = 64 * sw, slice = D / sw, cw = f3_cw(slice), gl = slice / cw, nq4 = 2 * cw;
   const int lane = t & 63, wave = t >> 6;
   const int gcol = wave * slice + cw * (lane < gl ? lane : 0);
+  // the lane's cw <= 3 columns of all K <= 32 centres in registers: 96 independent loads in flight, one round trip
+  float c[32][3];
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[k][j] = (k < K && j < cw) ? centers[(int64_t)k * D + gcol + j] : 0.f;
   float cm = 0.f;
-  for (int k = 0; k < K; ++k)
-    for (int j = 0; j < cw; ++j) cm = fmaxf(cm, fabsf(centers[(int64_t)k * D + gcol + j]));
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cm = fmaxf(cm, fabsf(c[k][j]));
   cm = fminf(cm, 1.0e30f);                      // (inf / huge centres: step huge, every byte 128, c~ = 0 = the plain sum)
   // the power of two >= max |c| / 127 (0 -> 1: an all-zero lane quantises to zeros under any step)
   unsigned sb = (__float_as_uint(cm * (1.0f / 127.0f)) + 0x007fffffu) & 0x7f800000u;
   if (sb == 0u) sb = 0x3f800000u;
   const float inv_step = __uint_as_float(0x7f000000u - sb);          // 1 / 2^e, exact
-  for (int j = 0; j < cw; ++j)
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
     for (int g = 0; g < 8; ++g) {
-      unsigned word = 0x80808080u;
+      unsigned word = 0;
+#pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int k = 4 * g + b;
-        if (k < K) {
-          float v = rintf(centers[(int64_t)k * D + gcol + j] * inv_step);   // |v| <= 127 (NaN -> 0: the byte stays in range)
-          v = v == v ? fminf(fmaxf(v, -127.0f), 127.0f) : 0.0f;
-          word = (word & ~(0xffu << (8 * b))) | ((unsigned)((int)v + 128) << (8 * b));
-        }
+        float v = rintf(c[4 * g + b][j] * inv_step);                 // |v| <= 127 (NaN -> 0: the byte stays in range); rows >= K: 0 -> byte 128
+        v = v == v ? fminf(fmaxf(v, -127.0f), 127.0f) : 0.0f;
+        word |= (unsigned)((int)v + 128) << (8 * b);
       }
       const int i = 2 * j + g / 4, e = g % 4;                       // piece, dword within the piece
-      tab[((int64_t)i * nt + t) * 4 + e] = word;
+      if (j < cw) tab[((int64_t)i * nt + t) * 4 + e] = word;
     }
   tab[(int64_t)nq4 * nt * 4 + t] = sb;
 }

@@ -441,16 +441,21 @@ __device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-// SHIFT (VLAD mode, CW <= 3; option vlad_shift, default on -- round 5): no per-token gather of the centre's columns from L2.
-// Sum_n (x^_n - c_k) = Sum_n (x^_n - c~_k) - n_k (c_k - c~_k): the accumulators collect x^ - c~ where c~ is an 8-BIT copy of the
-// centres that lives in REGISTERS (24 per lane at CW = 3: a lane's CW columns of all 32 clusters as bytes under one
-// power-of-two step per lane, step >= max |c| / 127 over the lane's columns, c~ = (u - 128) step exactly), and the exact
-// remainder n_k (c_k - c~_k) is subtracted ONCE in the epilogue from the fp32 centres (one CW-wide load per cluster).  Why not
-// plain Sum x^ - n_k c_k (k-means mode's loop): for a tight cluster the two terms cancel -- |x^ - c| ~ 1e-2 |c| and n_k = 16
-// already loses 6 - 7 of the 24 bits, outside the 1e-5 bar (reference utilities.py:854-861 sums fp32 residuals).  With the
-// 8-bit shift the accumulator holds n_k (c - c~) + Sum (x^ - c): |c - c~| <= step / 2 ~ |c| / 100, and the rounding left is
-// ~1.4e-8 sqrt(n_k) n_k |c - c~| / |Sum (x^ - c)| -- 4e-6 for 529 tokens in ONE cluster at |x^ - c| = 1e-2, 1e-7 at n_k = 16
-// (tests/test_gpu_vlad_topk.py::test_vlad_tight_clusters).  Token order per (cluster, column) as before: deterministic.
+// SHIFT (VLAD mode, CW <= 3; option vlad_shift = 1 -- round 5, built for round 4's verdict item 5): no per-token gather of the
+// centre's columns from L2.  Sum_n (x^_n - c_k) = Sum_n (x^_n - c~_k) - n_k (c_k - c~_k): the accumulators collect x^ - c~
+// where c~ is an 8-BIT copy of the centres (a lane's CW columns of all 32 clusters as bytes under one power-of-two step per
+// lane, step >= max |c| / 127 over the lane's columns, c~ = (u - 128) step exactly; 24 registers at CW = 3, fetched once per
+// tile -- the table does not depend on the labels), and the exact remainder n_k (c_k - c~_k) is subtracted ONCE per cluster in
+// the epilogue from the fp32 centres.  Why not plain Sum x^ - n_k c_k (k-means mode's loop): for a tight cluster the two terms
+// cancel -- |x^ - c| ~ 1e-2 |c| and n_k = 16 lose 6 - 7 of the 24 bits, 4e-5 ... 7e-4 against the 1e-5 bar (the reference sums
+// fp32 residuals, utilities.py:854-861).  With the shift the accumulator holds n_k (c - c~) + Sum (x^ - c), |c - c~| ~ |c| / 100:
+// as close to float64 as the reference's own fp32 arithmetic, factor <= 3.2 for 529 tokens in ONE cluster
+// (tests/test_vlad_shift_numerics_cpu.py, tests/test_gpu_vlad_topk.py::test_vlad_tight_clusters).
+// MEASURED (profiles/r05_vlad_shift_vs_gather.log): correct, and 7 - 10 % SLOWER than the gather at 61 / 256 / 1024 images
+// (0.54 us per tile: the decode costs more vector instructions than the gather's loads, whose L2 round trips two waves per
+// SIMD already hide) -- so the gather stays the default.  What the same measurement exposed instead: 34 tiles cost 250 us and
+// 9 tiles 122 us, i.e. the tile loop ran at the k-means kernel's 5.1 us per tile and ~75 us per workgroup were NOT tiles -- the
+// unrolled epilogue (see there).
 typedef unsigned f3_u32x8 __attribute__((ext_vector_type(8)));
 typedef int f3_i32x2 __attribute__((ext_vector_type(2)));
 
@@ -536,11 +541,12 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   // scoring phase, so the wave's VALU / MFMA work runs while the texture path accepts them (98 KB per tile and CU at
   // 64 B/clk is ~1 500 cycles; issued in one burst, every wave sat in that queue before it scored)
   static_assert(NF == 2 * NKB, "two staged float4 per k-block");
-  // (SHIFT: the staging addresses are rebuilt from an opaque copy of the thread id at every use -- hoisted out of the tile loop
-  // they are six registers that variant does not have, and a spilled loop invariant is reloaded behind the HBM loads in flight)
+  // (VLAD mode: the staging addresses are rebuilt from an opaque copy of the thread id at every use -- hoisted out of the tile
+  // loop they are six registers these variants do not have, and a spilled loop invariant is reloaded behind the HBM loads in
+  // flight)
   auto opaque_tid = [&]() {
     int tt = tid;
-    if constexpr (SHIFT) asm volatile("" : "+v"(tt));
+    if constexpr (!KMEANS) asm volatile("" : "+v"(tt));
     return tt;
   };
   auto fetch_pair = [&](int t, auto kbc) {
@@ -947,137 +953,218 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     lds_barrier();
   }
 
-  if constexpr (SHIFT) {
-    // the exact remainder of the shift, once per cluster: acc = Sum (x^ - c~) - n_k (c - c~) = Sum (x^ - c)
-    load_table();                              // (a unit without tiles never loaded it)
-    static_for<32>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      if (k < a.K) {
-        float c[CW];
-        f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)(k * D * 4), c);
-        const float nk = (float)__builtin_amdgcn_readlane((int)my_count, k);
-        static_for<CW>([&](auto j) {
-          const float ct = ((float)((qsh[(int)j][k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f) * sh_step;
-          acc[j][k] = __builtin_fmaf(-nk, c[(int)j] - ct, acc[j][k]);
-        });
-      }
-    });
-  }
   const bool g_live = lane < GL;
   // a lane's CW columns of cluster k travel as one CW-wide buffer access (idle lanes of a 48-lane slice point past the
   // descriptor: their stores are dropped, their loads return zeros)
   const int64_t kd = (int64_t)a.K * D;
   const unsigned col_off = g_live ? (unsigned)(gcol * 4) : 0x7fffff00u;
-  auto cols_of = [&](auto kc, float (&v)[CW]) { static_for<CW>([&](auto j) { v[(int)j] = acc[j][(int)kc]; }); };
-  if (KMEANS) {
+  if constexpr (KMEANS) {
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out + unit * kd), 0, (int)(kd * 4), 0x00020000);
     static_for<32>([&](auto k) {
       if (k < a.K) {
         float v[CW];
-        cols_of(k, v);
+        static_for<CW>([&](auto j) { v[(int)j] = acc[j][(int)k]; });
         f3_store_cols<CW>(o_rsrc, col_off, (unsigned)((int)k * D * 4), v);
       }
     });
     if (wave == 0 && lane < a.K) a.cnt_part[unit * a.K + lane] = my_count;
     return;
-  }
-  if (a.parts > 1) {
-    // (the hand-off of vlad_fused_kernel: partial sums -> workspace, last ticket reduces in part order)
-    {
-      const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          uniform_ptr(a.part_buf + (unit * a.parts + part_id) * kd), 0, (int)(kd * 4), 0x00020000);
-      static_for<32>([&](auto k) {
-        if (k < a.K) {
-          float v[CW];
-          cols_of(k, v);
-          f3_store_cols<CW>(p_rsrc, col_off, (unsigned)((int)k * D * 4), v);
-        }
-      });
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned ticket = __hip_atomic_fetch_add(a.part_tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = ticket == (unsigned)(a.parts - 1);
-      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      lab[0] = last;
-    }
-    __syncthreads();
-    if (!lab[0]) return;
-    // the parts' sums of a cluster, added in part order; all parts' loads of a cluster are in flight together (<= 8 parts:
-    // 8 CW registers) and CW-wide -- round 3 issued parts x 32 x CW dword loads one behind the other: 39 us for the 784 KB of
-    // 61 images x 4 parts
-    const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(a.part_buf + unit * a.parts * kd), 0, (int)imin64((int64_t)a.parts * kd * 4, 0x7fffffff), 0x00020000);
-    // (four clusters x up to eight parts = 32 CW-wide loads per lane in flight: one workgroup pulls the parts x K x D x 4 bytes
-    // -- 784 KB at 61 images -- through its CU's load path, so what counts is how many requests are outstanding)
-    static_for<8>([&](auto kg) {
-      constexpr int k0 = 4 * decltype(kg)::value;
-      float sum[4][CW];
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-        for (int j = 0; j < CW; ++j) sum[c4][j] = 0.f;
-      for (int q0 = 0; q0 < a.parts; q0 += 8) {              // (more than 8 parts only through option vlad_parts)
-        float pv[4][8][CW];
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (k0 + c4 < a.K && q0 + q < a.parts)
-              f3_load_cols<CW>(q_rsrc, col_off, (unsigned)(((q0 + q) * kd + (k0 + c4) * D) * 4), pv[c4][q]);
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (k0 + c4 < a.K && q0 + q < a.parts)
-#pragma unroll
-              for (int j = 0; j < CW; ++j) sum[c4][j] += pv[c4][q][j];
+  } else {
+    // ---- VLAD epilogue (round 5): RUNTIME loops over the clusters, the accumulators read and written through the GPR index
+    // (cluster id in an SGPR), a few hundred instructions.  Rounds 2-4 unrolled every step over the 32 compile-time cluster
+    // ids -- 10 300 of the kernel's 12 800 instructions, ~80 KB of straight-line code that every workgroup executes ONCE, cold
+    // (the tile loop is 2 000 instructions; the k-means kernel is 1 950 in all).  Measured before this change: 34 tiles cost
+    // 250 us and 9 tiles 122 us -- 5.1 us per tile, the k-means kernel's rate, plus ~75 us per workgroup that is not tiles.
+    // The arithmetic per element (operations and their order) is what it was: the same bits.
+    const int Kc = __builtin_amdgcn_readfirstlane(a.K);
+    auto acc_get = [&](int k, float (&v)[CW]) {
+      if constexpr (CW == 1) {
+        asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v224\n\ts_set_gpr_idx_off" : "=&v"(v[0]) : "s"(k), "{v[224:255]}"(acc[0]));
+      } else if constexpr (CW == 2) {
+        asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v224\n\ts_set_gpr_idx_off"
+                     : "=&v"(v[0]), "=&v"(v[1]) : "s"(k), "{v[192:223]}"(acc[0]), "{v[224:255]}"(acc[1]));
+      } else if constexpr (CW == 3) {
+        asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v160\n\tv_mov_b32 %1, v192\n\tv_mov_b32 %2, v224\n\ts_set_gpr_idx_off"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                     : "s"(k), "{v[160:191]}"(acc[0]), "{v[192:223]}"(acc[1]), "{v[224:255]}"(acc[2]));
+      } else if constexpr (CW == 4) {
+        asm volatile("s_set_gpr_idx_on %4, 0x1\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v160\n\tv_mov_b32 %2, v192\n\tv_mov_b32 %3, v224\n\t"
+                     "s_set_gpr_idx_off"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                     : "s"(k), "{v[128:159]}"(acc[0]), "{v[160:191]}"(acc[1]), "{v[192:223]}"(acc[2]), "{v[224:255]}"(acc[3]));
+      } else {
+        static_for<CW>([&](auto j) { v[(int)j] = acc[j][k]; });
       }
-      static_for<4>([&](auto c4) {
-        static_for<CW>([&](auto j) { acc[j][k0 + (int)c4] = sum[(int)c4][(int)j]; });
-      });
-    });
-  }
-  // intra-norm of each cluster block (its columns are spread over the SW waves), then the global norm
-  if (a.intra) {
-    static_for<32>([&](auto k) {
-      float ss = 0.f;
-      static_for<CW>([&](auto j) { ss += acc[j][(int)k] * acc[j][(int)k]; });
-      ss = wave_sum(g_live ? ss : 0.f);
-      if (lane == 0) red[wave * 32 + k] = ss;
-    });
-    __syncthreads();
-    static_for<32>([&](auto k) {
-      float tot = 0.f;
+    };
+    auto acc_set = [&](int k, const float (&v)[CW]) {
+      if constexpr (CW == 1) {
+        asm volatile("s_set_gpr_idx_on %2, 0x8\n\tv_mov_b32 v224, %1\n\ts_set_gpr_idx_off" : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
+      } else if constexpr (CW == 2) {
+        asm volatile("s_set_gpr_idx_on %4, 0x8\n\tv_mov_b32 v192, %2\n\tv_mov_b32 v224, %3\n\ts_set_gpr_idx_off"
+                     : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
+      } else if constexpr (CW == 3) {
+        asm volatile("s_set_gpr_idx_on %6, 0x8\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
+                     : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
+      } else if constexpr (CW == 4) {
+        asm volatile("s_set_gpr_idx_on %8, 0x8\n\tv_mov_b32 v128, %4\n\tv_mov_b32 v160, %5\n\tv_mov_b32 v192, %6\n\tv_mov_b32 v224, %7\n\t"
+                     "s_set_gpr_idx_off"
+                     : "+{v[128:159]}"(acc[0]), "+{v[160:191]}"(acc[1]), "+{v[192:223]}"(acc[2]), "+{v[224:255]}"(acc[3])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k));
+      } else {
+        static_for<CW>([&](auto j) { acc[j][k] = v[(int)j]; });
+      }
+    };
+
+    if constexpr (SHIFT) {
+      // the exact remainder of the shift, once per cluster: acc = Sum (x^ - c~) - n_k (c - c~) = Sum (x^ - c).  Eight clusters'
+      // fp32 columns in flight per round (a centre row past K lies beyond the descriptor and reads as zeros; its n_k is 0)
+      load_table();                              // (a unit without tiles never loaded it)
+#pragma unroll 1
+      for (int k0 = 0; k0 < Kc; k0 += 8) {
+        float c[8][CW];
 #pragma unroll
-      for (int w2 = 0; w2 < SW; ++w2) tot += red[w2 * 32 + k];
-      const float kn = fmaxf(sqrtf(tot), 1e-12f);
-      static_for<CW>([&](auto j) { acc[j][(int)k] /= kn; });
-    });
-    __syncthreads();
-  }
-  float ss = 0.f;
-  static_for<32>([&](auto k) {
-    if (k < a.K) static_for<CW>([&](auto j) { ss += acc[j][(int)k] * acc[j][(int)k]; });
-  });
-  ss = wave_sum(g_live ? ss : 0.f);
-  if (lane == 0) red[wave] = ss;
-  __syncthreads();
-  float tot = 0.f;
+        for (int e = 0; e < 8; ++e) f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((k0 + e) * D * 4), c[e]);
 #pragma unroll
-  for (int w2 = 0; w2 < SW; ++w2) tot += red[w2];
-  const float gn = fmaxf(sqrtf(tot), 1e-12f);
-  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out + unit * kd), 0, (int)(kd * 4), 0x00020000);
-  static_for<32>([&](auto k) {
-    if (k < a.K) {
-      float v[CW];
-      static_for<CW>([&](auto j) { v[(int)j] = acc[j][(int)k] / gn; });
-      f3_store_cols<CW>(o_rsrc, col_off, (unsigned)((int)k * D * 4), v);
+        for (int e = 0; e < 8; ++e) {
+          const int k = k0 + e;
+          const float nk = (float)__builtin_amdgcn_readlane((int)my_count, k);
+          const int g = k >> 2;
+          const unsigned sh = (unsigned)(k & 3) * 8u;
+          unsigned w[CW];
+          if constexpr (CW == 1) {
+            asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v216\n\ts_set_gpr_idx_off"
+                         : "=&v"(w[0]) : "s"(g), "{v[216:223]}"(qsh[0]));
+          } else if constexpr (CW == 2) {
+            asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v176\n\tv_mov_b32 %1, v184\n\ts_set_gpr_idx_off"
+                         : "=&v"(w[0]), "=&v"(w[1]) : "s"(g), "{v[176:183]}"(qsh[0]), "{v[184:191]}"(qsh[1]));
+          } else {
+            asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v136\n\tv_mov_b32 %1, v144\n\tv_mov_b32 %2, v152\n\t"
+                         "s_set_gpr_idx_off"
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+                         : "s"(g), "{v[136:143]}"(qsh[0]), "{v[144:151]}"(qsh[1]), "{v[152:159]}"(qsh[2]));
+          }
+          float v[CW];
+          acc_get(k, v);
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            const float ct = ((float)__builtin_amdgcn_ubfe(w[j], sh, 8u) - 128.0f) * sh_step;
+            v[j] = __builtin_fmaf(-nk, c[e][j] - ct, v[j]);
+          }
+          acc_set(k, v);
+        }
+      }
     }
-  });
+
+    if (a.parts > 1) {
+      // (the hand-off of vlad_fused_kernel: partial sums -> workspace, last ticket reduces in part order)
+      {
+        const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(a.part_buf + (unit * a.parts + part_id) * kd), 0, (int)(kd * 4), 0x00020000);
+#pragma unroll 1
+        for (int k = 0; k < Kc; ++k) {
+          float v[CW];
+          acc_get(k, v);
+          f3_store_cols<CW>(p_rsrc, col_off, (unsigned)(k * D * 4), v);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(a.part_tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (unsigned)(a.parts - 1);
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        lab[0] = last;
+      }
+      __syncthreads();
+      if (!lab[0]) return;
+      // the parts' sums of a cluster, added in part order; four clusters x up to eight parts = 32 CW-wide loads per lane in
+      // flight per round (one workgroup pulls the parts x K x D x 4 bytes -- 784 KB at 61 images x 4 parts -- through its CU's
+      // load path, so what counts is how many requests are outstanding)
+      const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.part_buf + unit * a.parts * kd), 0, (int)imin64((int64_t)a.parts * kd * 4, 0x7fffffff), 0x00020000);
+#pragma unroll 1
+      for (int k0 = 0; k0 < Kc; k0 += 4) {
+        float sum[4][CW];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+          for (int j = 0; j < CW; ++j) sum[c4][j] = 0.f;
+        for (int q0 = 0; q0 < a.parts; q0 += 8) {              // (more than 8 parts only through option vlad_parts)
+          float pv[4][8][CW];
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (k0 + c4 < Kc && q0 + q < a.parts)
+                f3_load_cols<CW>(q_rsrc, col_off, (unsigned)(((q0 + q) * kd + (k0 + c4) * D) * 4), pv[c4][q]);
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (k0 + c4 < Kc && q0 + q < a.parts)
+#pragma unroll
+                for (int j = 0; j < CW; ++j) sum[c4][j] += pv[c4][q][j];
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+          if (k0 + c4 < Kc) acc_set(k0 + c4, sum[c4]);
+      }
+    }
+    // intra-norm of each cluster block (its columns are spread over the SW waves), then the global norm
+    if (a.intra) {
+#pragma unroll 1
+      for (int k = 0; k < Kc; ++k) {
+        float v[CW];
+        acc_get(k, v);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) ss += v[j] * v[j];
+        ss = wave_sum(g_live ? ss : 0.f);
+        if (lane == 0) red[wave * 32 + k] = ss;
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int k = 0; k < Kc; ++k) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < SW; ++w2) tot += red[w2 * 32 + k];
+        const float kn = fmaxf(sqrtf(tot), 1e-12f);
+        float v[CW];
+        acc_get(k, v);
+#pragma unroll
+        for (int j = 0; j < CW; ++j) v[j] /= kn;
+        acc_set(k, v);
+      }
+      __syncthreads();
+    }
+    float ss = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < Kc; ++k) {
+      float v[CW];
+      acc_get(k, v);
+#pragma unroll
+      for (int j = 0; j < CW; ++j) ss += v[j] * v[j];
+    }
+    ss = wave_sum(g_live ? ss : 0.f);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < SW; ++w2) tot += red[w2];
+    const float gn = fmaxf(sqrtf(tot), 1e-12f);
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out + unit * kd), 0, (int)(kd * 4), 0x00020000);
+#pragma unroll 1
+    for (int k = 0; k < Kc; ++k) {
+      float v[CW];
+      acc_get(k, v);
+#pragma unroll
+      for (int j = 0; j < CW; ++j) v[j] = v[j] / gn;
+      f3_store_cols<CW>(o_rsrc, col_off, (unsigned)(k * D * 4), v);
+    }
+  }
 }
 
 #undef x_rsrc

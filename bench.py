@@ -1085,8 +1085,7 @@ def stage_vlad(dev, vlad, n_img, check):
     el, v, kern = _timed(lambda: ops.vlad(toks, c), iters=20, warm=2)
     per_img = (529 * 1536 + 2 * 32 * 1536) * 4
     k_ms = kern.get("vlad_fused", sum(kern.values()))      # the roofline is the kernel's; the call's wall time alongside
-    res = {"workload": f"fused VLAD kernel, {n_img} images x 529 tokens x 1536, K=32 (shifted accumulation against the 8-bit centre "
-                       "table, option vlad_shift = 1: no per-token centre gather)", "kernel_ms": round(k_ms, 4),
+    res = {"workload": f"fused VLAD kernel, {n_img} images x 529 tokens x 1536, K=32", "kernel_ms": round(k_ms, 4),
            "call_kernels_ms": round(sum(kern.values()), 4),      # + the centre preparation launch (normalised centres, byte table)
            "call_wall_ms": round(el * 1e3, 4), "bound": "hbm", "algorithmic_bytes": per_img * n_img,
            "achieved": round(per_img * n_img / (k_ms * 1e-3) / 1e12, 3), "peak": PEAK_HBM_TBPS, "unit": "TB/s",

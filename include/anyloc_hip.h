@@ -65,9 +65,10 @@ const char* anyloc_last_error(void);
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
  *   vlad_group (0)                    fused VLAD gather: 1 = a token with its predecessor's label reuses that token's centre columns
- *   vlad_shift (1)                    fused VLAD: residuals accumulated against an 8-bit copy of the centres held in registers, the exact
- *                                     remainder n_k (c_k - c~_k) subtracted once per cluster; 0 = the centre's fp32 columns gathered from
- *                                     L2 per token (round 4)
+ *   vlad_shift (0)                    fused VLAD, 1: no per-token gather of the centre -- residuals are accumulated against an 8-bit copy
+ *                                     of the centres (one power-of-two step per lane; fetched per tile, label-independent) and the exact
+ *                                     remainder n_k (c_k - c~_k) is subtracted once per cluster.  Built for round 4's verdict item 5;
+ *                                     measured 7 - 10 % SLOWER than the gather (profiles/r05_vlad_shift_vs_gather.log), so not the default
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
