@@ -124,6 +124,19 @@ Plan choose(const H3Problem& p, int epilogue) {
       pl = Plan{7, 1, 1};
       pl.stages = 6;
     }
+  } else if (p.M <= 1700) {
+    // One 476 x 630 image = 1531 token rows: the reference scripts' DEFAULT shape (configs.py:141 resize [480, 640], centre crop
+    // scripts/dino_v2_vlad.py:173-176) -- and three 322 x 322 images.  Round 5 sweep at that shape (tools/sweep_b1.py 1 ... 476x630,
+    // profiles/r05_b1_480x640_plan_sweep.log; time per launch inside a B = 1 forward): the 128 x 128 default is within 1 - 3 % of
+    // the best plan for qkv (70.6 us) and w12 (103.7 us); the two narrow GEMMs are not --
+    //   fc2  (K = 4096, N = 1536): 144 tiles of 128 x 128 on 256 CUs; 64 x 128 four-wave tiles with split-K 2: 88.6 -> 76.3 us
+    //   proj (K = 1536, N = 1536): 64 x 128 four-wave tiles, 6-deep ring:                                   40.1 -> 37.4 us
+    if (p.N <= 2048 && p.K16 >= 192) {
+      pl = Plan{2, 1, 2};
+    } else if (p.N <= 2048) {
+      pl = Plan{2, 1, 1};
+      pl.stages = 6;
+    }
   }
   const int64_t mask = option(OPT_H3S_MASK);
   const int bit = p.kind == H3_KIND_QKV ? 1 : p.kind == H3_KIND_PROJ ? 2 : p.kind == H3_KIND_FC1 ? 4 : p.kind == H3_KIND_FC2 ? 8 : 16;

@@ -114,7 +114,7 @@ class PowerSampler:
     def __init__(self, device_index=0, period=0.02):
         import glob
         import threading
-        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.period, self.samples, self._stop, self._active = period, [], threading.Event(), threading.Event()
         self.src, self.cards, self.picked_by = None, [], None
         nodes = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
         want = None
@@ -176,8 +176,17 @@ class PowerSampler:
         except Exception:  # noqa: BLE001
             return None
 
+    def resume(self):
+        """Sample from now on (the thread idles between ``pause()`` and ``resume()``: no sysfs reads, no SMU queries)."""
+        self._active.set()
+
+    def pause(self):
+        self._active.clear()
+
     def _run(self):
         while not self._stop.is_set():
+            if not self._active.wait(0.2):
+                continue
             t = time.perf_counter()
             if self.src == "rocm-smi":
                 row = [(self._smi(), None)]
@@ -428,6 +437,9 @@ def main():
                     help="timed steps of each of the other GEMM arithmetics (0 = the same --steps as the headline mode)")
     ap.add_argument("--no-stages", action="store_true",
                     help="skip the `stages` block (k-means 5M x 1536, VLAD alone, one config-3 shard, ViT-L 518 two taps)")
+    ap.add_argument("--power-steps", type=int, default=8,
+                    help="extra untimed steps after the timed region over which socket power / shader clock are sampled (0 = off)")
+    ap.add_argument("--power-period", type=float, default=0.05, help="seconds between power samples")
     ap.add_argument("--no-whole-jobs", action="store_true",
                     help="skip the two whole-job stages (configs[1] as one 11 000-image job, ~35 s; configs[2] whole on one GPU, "
                          "196.6 GB resident, ~15 s)")
@@ -487,7 +499,6 @@ def main():
             if rank == 0:
                 results.append((d, idx))
 
-    sampler = PowerSampler(dev.index or 0) if rank == 0 else None
     for i in range(warm):
         step(i)
     # HIP events around EVERY launch cost the queue ~3 us each (450 per step): the timed region brackets only the launches
@@ -514,7 +525,6 @@ def main():
         dist.barrier()
     t_end = time.perf_counter()
     elapsed = t_end - t0
-    power_timed = sampler.window(t0, t_end) if sampler is not None else None
     ops.profile_enable(False)
     prof_dom = ops.profile_dump()
     ops.profile_filter(None)
@@ -525,6 +535,25 @@ def main():
         retrieval.sharded_search(db, shard_base, q_probe, TOPK, group=None, counts=[B] * world, timings=rccl_legs)
         del q_probe
     timed_results = list(results)            # (the untimed steps below and the `modes` block re-use and clear `results`)
+    # Socket power / shader clock: sampled over EXTRA, untimed steps identical to the timed ones, right after them -- the
+    # sampler reads the GPU's own hwmon nodes (an SMU query each), so it never runs while `value` is being measured
+    sampler, power_timed = None, None
+    if rank == 0 and args.power_steps > 0:
+        sampler = PowerSampler(dev.index or 0, period=args.power_period)
+        torch.cuda.synchronize()
+        sampler.resume()
+        t_p0 = time.perf_counter()
+        for i in range(args.power_steps):
+            step(warm + i)
+        torch.cuda.synchronize()
+        t_p1 = time.perf_counter()
+        sampler.pause()
+        power_timed = sampler.window(t_p0, t_p1)
+        power_timed["steps"] = args.power_steps
+        power_timed["ms_per_step_while_sampling"] = round((t_p1 - t_p0) / args.power_steps * 1e3, 3)
+        power_timed["note"] = ("sampled over extra untimed steps right after the timed region (same workload); "
+                               "`ms_per_step_while_sampling` against `ms_per_step` shows what the sampling itself costs")
+        results.clear()
     ops.profile_enable(True)
     ops.profile_reset()
     for i in range(2):
@@ -882,9 +911,7 @@ def stage_b1(ext, qu_img, sampler=None, label="322x322"):
     def one():
         state["i"] = (state["i"] + 1) % len(imgs)
         return ext(imgs[state["i"]])
-    t_a = time.perf_counter()
     el, tok, kern = _timed(one, iters=40, warm=5)
-    t_b = time.perf_counter()
     # the same image as image 0 of a batch gives bitwise the same tokens (per-row arithmetic does not depend on the batch);
     # elsewhere in a batch its rows fall into other GLOBAL 32-row groups of attention_h3's per-tile scales: the
     # same arithmetic on a differently grouped quantisation, equal to ~1e-7
@@ -903,8 +930,16 @@ def stage_b1(ext, qu_img, sampler=None, label="322x322"):
            "frac_of_fp16_div3_peak": round(fl / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "kernels_ms": kern,
            "oracle_ok": bool(max(first, other) <= 2e-6), "max_abs_diff_vs_batch_position_0": first,
            "max_abs_diff_vs_batch_position_3": other}
-    if sampler is not None:
+    if sampler is not None:                 # (a separate, untimed loop: the sampler idles while `el` is measured)
+        sampler.resume()
+        t_a = time.perf_counter()
+        for _ in range(40):
+            one()
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        sampler.pause()
         res["power"] = sampler.window(t_a, t_b)
+        res["power"]["ms_per_image_while_sampling"] = round((t_b - t_a) / 40 * 1e3, 3)
     return res
 
 

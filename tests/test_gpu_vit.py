@@ -175,7 +175,7 @@ def test_small_batch_kernels_are_bitwise_the_plain_ones(batch, monkeypatch):
         weights.unregister_state_dict(name)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 5])
+@pytest.mark.parametrize("batch", [1, 2, 3, 5])
 def test_small_m_plans_agree_with_the_plain_kernels(batch):
     """The small-M plans of csrc/gemm_h3s.hip (other tile shapes, several k-blocks per ring stage, split-K with a
     deterministic split-order reduction) change the summation order over k, nothing else: every plan -- the table's choice
