@@ -72,7 +72,6 @@ enum Option {
   OPT_ATTN_CFG,          // fp32-MFMA attention: workgroup shape (micro-benchmarks)
   OPT_ATTN_X6,           // anyloc_attention: 1 = split-bf16 products for every call, 0 = never, -1 = as the caller asks
   OPT_VLAD_PARTS,        // workgroups per image of the fused VLAD kernel (0 = chosen from the image count)
-  OPT_VLAD_GROUP,        // fused VLAD gather: 1 = label-grouped centre loads (runs of equal labels load once), 0 = one load per token
   OPT_VLAD_TWO_PASS,     // 1 = force the general two-pass VLAD path
   OPT_VLAD_FUSED_V,      // fused VLAD kernel: 0 = default choice, 1 = exact-score kernel, 3 / 4 = screening kernel with 4 / 8 waves
   OPT_KMEANS_FUSED_V,    // the same for the k-means step
@@ -315,7 +314,6 @@ struct FusedArgs {
   int64_t* lab64;          // optional [total] labels
   int norm_descs, intra;
   int metric;              // 0 cosine (||chat_k|| = 1), 1 euclidean (chat = 2 c, cbias = -||c||^2): scales fused3's error bound
-  int group;               // VLAD: 1 = a token with its predecessor's label reuses that token's centre columns (option vlad_group)
   int shift;               // VLAD: > 0 = accumulate x^ - c~ against an 8-bit table of the centres (fetched per tile, label-independent),
                            // exact remainder in the epilogue (option vlad_shift) -- the value is the waves per workgroup the
                            // table in shift_tab was written for (fused3_shift_waves); 0 = gather the fp32 centre columns per token

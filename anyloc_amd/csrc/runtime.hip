@@ -47,7 +47,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gemm_f32_cfg", 0},      {"x6_cfg", 0},          {"h3_cfg", 0},        {"h3_group_m", 8},   {"h3_tiny_max", 256},
     {"h3_deep_max", 320},     {"h3_deep2_max", 500},  {"h3_epi_lds", 1},    {"ln_rows_per_wave", 0}, {"ln_small_rows", 4096}, {"ln_waves", 8}, {"ln_direct_rows", 1200}, {"h3_fuse", 1},
     {"x6_fuse", 1},           {"h3_min_rows", 0},     {"x6_min_rows", 1600}, {"attn_cfg", 0},    {"attn_x6", -1},
-    {"vlad_parts", 0},    {"vlad_group", 0}, {"vlad_two_pass", 0}, {"vlad_fused_v", 0},
+    {"vlad_parts", 0},    {"vlad_two_pass", 0}, {"vlad_fused_v", 0},
     {"kmeans_fused_v", 0},    {"kmeans_max_chunks", 0}, {"h3_mfma16", -1}, {"h3_swiglu_t", 1}, {"h3_fast_silu", 1}, {"topk_fewq_x6", 2}, {"topk_h3", -1},
     {"h3s_cfg", -1}, {"h3s_ksplit", 0}, {"h3s_kb", 0}, {"h3s_stages", 0}, {"h3s_mask", 31}, {"h3s_enable", 1}, {"h3_patch", 1}, {"topk_fewq_qdma", 1},
     {"h3s_w12_tall", 1},      {"vlad_shift", 0},

@@ -514,7 +514,6 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     fa.norm_descs = (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0;
     fa.intra = (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0;
     fa.parts = parts; fa.part_buf = w.part_buf; fa.part_tickets = w.tickets;
-    fa.group = option(OPT_VLAD_GROUP) != 0;
     fa.shift = shift_waves;
     fa.shift_tab = w.shift_tab;
     return vlad_fused(fa, n_img, false, stream);

@@ -897,11 +897,14 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         }
       } else {
         // x / ||x|| - c_k.  The centres' CW columns of TG tokens are requested at once -- one CW-wide load per token, TT / TG
-        // L2 round trips per tile (round 3: four rounds of four tokens, CW dword loads each, every round waiting for its
-        // own round trip) -- and the tokens are then added in order while their columns come from the LDS tile.  The
-        // order of additions per (cluster, column) is the token order, as before: bitwise the same sums.
-        // TG tokens per round (option of the build: 16 = the whole tile needs 16 CW registers more than this kernel has at
-        // D = 1536; 8 = two round trips per tile instead of four)
+        // L2 round trips per tile -- and the tokens are then added in order while their columns come from the LDS tile.  The
+        // order of additions per (cluster, column) is the token order: bitwise the same sums as every earlier structure.
+        // Round 5: the tile columns come from LDS two tokens at a time, one pair ahead of the adds -- rounds 3-4 read each
+        // token's three floats right before its adds, sixteen exposed LDS round trips per tile and wave; tokens-per-image
+        // sweeps (tools/probe_vlad_fixed.py) put VLAD mode at 6.5 us per tile against 4.3 us for the k-means loop with BOTH
+        // accumulation structures, i.e. the difference was never the centre gather.  Rows past the unit (label -1, zeros in
+        // the tile) add an exact zero to cluster 0 instead of taking a branch per token.
+        // TG tokens per round (16 = the whole tile needs 16 CW registers more than this kernel has at D = 1536)
         constexpr int TG = 8;
 #pragma unroll 1
         for (int g0 = 0; g0 < TT; g0 += TG) {
@@ -913,36 +916,34 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             for (int e = 0; e < 4; ++e) kk[n4 + e] = __builtin_amdgcn_readfirstlane(lq[e]);
           }
           float c[TG][CW];
-          if (a.group) {
-            // label-grouped (option vlad_group): a token whose label equals its predecessor's in the round reuses that
-            // token's centre columns instead of requesting them again -- patch tokens are spatially coherent, neighbours in
-            // raster order mostly share a cluster; the additions and their order do not change (wave-uniform branches)
 #pragma unroll
-            for (int e = 0; e < TG; ++e) {
-              if (e > 0 && kk[e] == kk[e - 1]) {
+          for (int e = 0; e < TG; ++e)
+            f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
+          // (software-pipelined by token pairs: the LDS reads of pair p + 1 are in flight while pair p is added -- one exposed
+          // LDS round trip per round instead of one per token; four tokens at once spill four loop invariants)
+          float v[2][2][CW];
+          f32x2 nq[2];
+          auto read_pair = [&](int buf, int p2) {
+            nq[buf] = *reinterpret_cast<const f32x2*>(nrm + g0 + 2 * p2);
 #pragma unroll
-                for (int j = 0; j < CW; ++j) c[e][j] = c[e - 1][j];
-              } else {
-                f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int j = 0; j < CW; ++j) v[buf][e][j] = tp[(g0 + 2 * p2 + e) * LD + j];
+          };
+          read_pair(0, 0);
+#pragma unroll
+          for (int p2 = 0; p2 < TG / 2; ++p2) {
+            const int buf = p2 & 1;
+            if (p2 + 1 < TG / 2) read_pair(buf ^ 1, p2 + 1);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int k = kk[2 * p2 + e];
+#pragma unroll
+              for (int j = 0; j < CW; ++j) {
+                const float r = v[buf][e][j] * nq[buf][e] - c[2 * p2 + e][j];
+                v[buf][e][j] = k < 0 ? 0.0f : r;
               }
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < TG; ++e)
-              f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((kk[e] < 0 ? 0 : kk[e]) * D * 4), c[e]);
-          }
-#pragma unroll
-          for (int n4 = 0; n4 < TG; n4 += 4) {
-            const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + g0 + n4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v[CW];
-#pragma unroll
-              for (int j = 0; j < CW; ++j) v[j] = tp[(g0 + n4 + e) * LD + j];
-              const float inv = nq[e];
-#pragma unroll
-              for (int j = 0; j < CW; ++j) v[j] = v[j] * inv - c[n4 + e][j];
-              add_token(kk[n4 + e], v);
+              add_token(k < 0 ? 0 : k, v[buf][e]);
             }
           }
         }

@@ -64,7 +64,6 @@ const char* anyloc_last_error(void);
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
- *   vlad_group (0)                    fused VLAD gather: 1 = a token with its predecessor's label reuses that token's centre columns
  *   vlad_shift (0)                    fused VLAD, 1: no per-token gather of the centre -- residuals are accumulated against an 8-bit copy
  *                                     of the centres (one power-of-two step per lane; fetched per tile, label-independent) and the exact
  *                                     remainder n_k (c_k - c~_k) is subtracted once per cluster.  Built for round 4's verdict item 5;
