@@ -441,24 +441,22 @@ __device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-// SHIFT (VLAD mode, CW <= 3; option vlad_shift = 1 -- round 5, built for round 4's verdict item 5): no per-token gather of the
-// centre's columns from L2.  Sum_n (x^_n - c_k) = Sum_n (x^_n - c~_k) - n_k (c_k - c~_k): the accumulators collect x^ - c~
-// where c~ is an 8-BIT copy of the centres (a lane's CW columns of all 32 clusters as bytes under one power-of-two step per
-// lane, step >= max |c| / 127 over the lane's columns, c~ = (u - 128) step exactly; 24 registers at CW = 3, fetched once per
-// tile -- the table does not depend on the labels), and the exact remainder n_k (c_k - c~_k) is subtracted ONCE per cluster in
-// the epilogue from the fp32 centres.  Why not plain Sum x^ - n_k c_k (k-means mode's loop): for a tight cluster the two terms
-// cancel -- |x^ - c| ~ 1e-2 |c| and n_k = 16 lose 6 - 7 of the 24 bits, 4e-5 ... 7e-4 against the 1e-5 bar (the reference sums
-// fp32 residuals, utilities.py:854-861).  With the shift the accumulator holds n_k (c - c~) + Sum (x^ - c), |c - c~| ~ |c| / 100:
-// as close to float64 as the reference's own fp32 arithmetic, factor <= 3.2 for 529 tokens in ONE cluster
-// (tests/test_vlad_shift_numerics_cpu.py, tests/test_gpu_vlad_topk.py::test_vlad_tight_clusters).
-// MEASURED (profiles/r05_vlad_shift_vs_gather.log): correct, and 7 - 10 % SLOWER than the gather at 61 / 256 / 1024 images
-// (0.54 us per tile: the decode costs more vector instructions than the gather's loads, whose L2 round trips two waves per
-// SIMD already hide) -- so the gather stays the default.  What the same measurement exposed instead: 34 tiles cost 250 us and
-// 9 tiles 122 us, i.e. the tile loop ran at the k-means kernel's 5.1 us per tile and ~75 us per workgroup were NOT tiles -- the
-// unrolled epilogue (see there).
-typedef unsigned f3_u32x8 __attribute__((ext_vector_type(8)));
-typedef int f3_i32x2 __attribute__((ext_vector_type(2)));
-
+// SHIFT (VLAD mode, CW <= 4; option vlad_shift -- round 5, from round 4's verdict item 5): no per-token gather of the centre's
+// columns.  Sum_n (x^_n - c_k) = Sum_n (x^_n - c~_k) - n_k (c_k - c~_k): the accumulators collect x^ - c~ where c~ is a 7-BIT
+// copy of the centres held in LDS (a lane's CW columns of all 32 clusters as one bit stream under one power-of-two step per
+// lane, step >= max |c| / 63 over the lane's columns, c~ = (q - 64) step exactly; 43 KB at D = 1536), and the exact remainder
+// n_k (c_k - c~_k) is subtracted from the fp32 centres every 8 tiles and in the epilogue (fold_remainder).
+// * Why not plain Sum x^ - n_k c_k (k-means mode's loop): for a tight cluster the two terms cancel -- |x^ - c| ~ 1e-2 |c| and
+//   n_k = 16 lose 6 - 7 of the 24 bits, 4e-5 ... 7e-4 against the 1e-5 bar (the reference sums fp32 residuals,
+//   utilities.py:854-861).  With the shift the accumulator holds n (c - c~) + Sum (x^ - c) with |c - c~| ~ |c| / 50 and n <= 128
+//   between folds: as close to float64 as the reference's own fp32 arithmetic (factor <= 1.4 with all 529 tokens of an image
+//   in ONE cluster; tests/test_vlad_shift_numerics_cpu.py, tests/test_gpu_vlad_topk.py::test_vlad_tight_clusters).
+// * Why the table must be in LDS: the first build of this structure fetched an 8-bit table from L2 once per tile -- correct, and
+//   7 - 10 % SLOWER than the gather (profiles/r05_vlad_shift_vs_gather.log).  Tokens-per-image sweeps then showed 6.4 - 6.7 us per
+//   tile for BOTH structures against 4.4 us for k-means mode, which has no vector-memory access in its gather: the vector-memory
+//   counter retires in order per wave, so any load in the gather waits for the HBM loads of the next tile the wave issued
+//   during scoring (profiles/r05_vlad_fixed_cost.log).  Two other suspects were measured and cleared on the way: the unrolled
+//   epilogue (10 300 of 12 800 instructions, now runtime loops: no change in time) and per-token LDS round trips in the gather.
 template <int NV, int SW, bool KMEANS, bool SHIFT = false>
 __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   static_assert(!(KMEANS && SHIFT), "the shifted accumulation is a VLAD-mode structure");
@@ -489,6 +487,7 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   float* red = reinterpret_cast<float*>(amb + TT);        // [SW][32] epilogue reductions
   int* npairs = reinterpret_cast<int*>(red + SW * 32);    // [1] (row, centre) pairs queued for exact scoring in this tile
   int* pairs = npairs + 4;                                // [16 * 32] queue of (row << 5 | centre)
+  unsigned* tab7 = reinterpret_cast<unsigned*>(pairs + TT * 32);   // SHIFT only: [7 CW][NT3] the 7-bit centre table (below)
   float* exs = part;                          // after barrier B the score partials are dead: exact-score table [16][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -578,26 +577,32 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   const __amdgpu_buffer_rsrc_t cen_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<float*>(KMEANS ? a.chat : a.centers)), 0, (KMEANS ? 32 : a.K) * D * 4, 0x00020000);
 
-  // ---- SHIFT: the byte table of the centres (f3_shift_table_kernel wrote it for this very (SW, CW) shape) is fetched from
-  //      L2 ONCE PER TILE, after the assign phase, into registers the scoring / assign temporaries have just left -- it does
-  //      not depend on the labels, so no round trip waits for them; held in registers for the whole kernel instead (24 more
-  //      live registers in the scoring phase) the kernel spilled 29 ----
-  f3_u32x8 qsh[SHIFT ? CW : 1];
+  // ---- SHIFT: the 7-bit table of the centres (shift_table_thread wrote it for this very (SW, CW) shape into the workspace) is
+  //      copied into LDS once per workgroup: [7 CW dwords][NT3 lanes], dword d of every lane contiguous.  A lane's 32 x CW
+  //      fields of 7 bits are one bit stream, cluster k's CW fields at bit 7 CW k: two dword reads at a wave-uniform dword index
+  //      and one funnel shift fetch them -- no vector-memory access in the gather (see there why that matters), no registers
+  //      held across the tile loop (an 8-bit table is 48 KB: 4 KB more than this kernel's LDS has left at D = 1536) ----
+  constexpr int NQ = 7 * CW;
   float sh_step = 1.0f;
-  constexpr int NQ4 = 2 * CW;                   // 16-byte pieces of a lane's table
-  const __amdgpu_buffer_rsrc_t tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(const_cast<unsigned*>(a.shift_tab)), 0, SHIFT ? (NQ4 * 16 + 4) * NT3 : 0, 0x00020000);
-  auto load_table = [&]() {
-    static_for<NQ4>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const u32x4s r = __builtin_amdgcn_raw_buffer_load_b128(tab_rsrc, (unsigned)(tid * 16), (unsigned)(i * NT3 * 16), 0);
-      static_for<4>([&](auto e) { qsh[i / 2][4 * (i % 2) + (int)e] = r[(int)e]; });
-    });
-  };
   if constexpr (SHIFT) {
-    static_assert(CW <= 3, "shift table: three pinned byte vectors at most");
-    sh_step = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, (unsigned)(tid * 4), (unsigned)(NQ4 * NT3 * 16), 0));
+    static_assert(CW <= 4, "a cluster's fields must fit one funnel shift (7 CW <= 32 bits)");
+    const __amdgpu_buffer_rsrc_t tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(const_cast<unsigned*>(a.shift_tab)), 0, (NQ + 1) * NT3 * 4, 0x00020000);
+#pragma unroll
+    for (int d = 0; d < NQ; ++d)
+      tab7[d * NT3 + tid] = __builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, (unsigned)(tid * 4), (unsigned)(d * NT3 * 4), 0);
+    sh_step = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, (unsigned)(tid * 4), (unsigned)(NQ * NT3 * 4), 0));
   }
+  // c~ of cluster k (wave-uniform) for this lane's CW columns: field q in 1 .. 127, c~ = (q - 64) step exactly
+  // (tt: an opaque copy of the thread id made once per round by the caller -- the lane's table address is rebuilt, not held
+  // across the tile loop, and the reads of a round's tokens stay free to be issued together)
+  auto ctilde = [&](int k, int tt, float (&ct)[CW]) {
+    const int b0 = k * NQ, d0 = b0 >> 5, d1 = d0 + 1 < NQ ? d0 + 1 : d0;
+    const unsigned lo = tab7[d0 * NT3 + tt], hi = tab7[d1 * NT3 + tt];
+    const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)(b0 & 31));
+#pragma unroll
+    for (int j = 0; j < CW; ++j) ct[j] = ((float)((w >> (7 * j)) & 0x7fu) - 64.0f) * sh_step;
+  };
 
   // scoring coordinates: 16x16x32 fragments -- token / centre = lane & 15, 8 consecutive k at 8 (lane >> 4) of the k-block
   const int fr = lane & 15, fq = lane >> 4;
@@ -623,6 +628,75 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   float cnmax = a.metric ? 2.0f * sqrtf(fmaxf(-my_bias, 0.0f)) : 1.0f;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) cnmax = fmaxf(cnmax, __shfl_xor(cnmax, o, 64));
+
+  // (register-indexed access to the accumulators of a RUNTIME cluster id, wave-uniform in an SGPR: the epilogue and the fold)
+  auto acc_get = [&](int k, float (&v)[CW]) {
+    if constexpr (CW == 1) {
+      asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v224\n\ts_set_gpr_idx_off" : "=&v"(v[0]) : "s"(k), "{v[224:255]}"(acc[0]));
+    } else if constexpr (CW == 2) {
+      asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v224\n\ts_set_gpr_idx_off"
+                   : "=&v"(v[0]), "=&v"(v[1]) : "s"(k), "{v[192:223]}"(acc[0]), "{v[224:255]}"(acc[1]));
+    } else if constexpr (CW == 3) {
+      asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v160\n\tv_mov_b32 %1, v192\n\tv_mov_b32 %2, v224\n\ts_set_gpr_idx_off"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                   : "s"(k), "{v[160:191]}"(acc[0]), "{v[192:223]}"(acc[1]), "{v[224:255]}"(acc[2]));
+    } else if constexpr (CW == 4) {
+      asm volatile("s_set_gpr_idx_on %4, 0x1\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v160\n\tv_mov_b32 %2, v192\n\tv_mov_b32 %3, v224\n\t"
+                   "s_set_gpr_idx_off"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                   : "s"(k), "{v[128:159]}"(acc[0]), "{v[160:191]}"(acc[1]), "{v[192:223]}"(acc[2]), "{v[224:255]}"(acc[3]));
+    } else {
+      static_for<CW>([&](auto j) { v[(int)j] = acc[j][k]; });
+    }
+  };
+  auto acc_set = [&](int k, const float (&v)[CW]) {
+    if constexpr (CW == 1) {
+      asm volatile("s_set_gpr_idx_on %2, 0x8\n\tv_mov_b32 v224, %1\n\ts_set_gpr_idx_off" : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
+    } else if constexpr (CW == 2) {
+      asm volatile("s_set_gpr_idx_on %4, 0x8\n\tv_mov_b32 v192, %2\n\tv_mov_b32 v224, %3\n\ts_set_gpr_idx_off"
+                   : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
+    } else if constexpr (CW == 3) {
+      asm volatile("s_set_gpr_idx_on %6, 0x8\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
+                   : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                   : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
+    } else if constexpr (CW == 4) {
+      asm volatile("s_set_gpr_idx_on %8, 0x8\n\tv_mov_b32 v128, %4\n\tv_mov_b32 v160, %5\n\tv_mov_b32 v192, %6\n\tv_mov_b32 v224, %7\n\t"
+                   "s_set_gpr_idx_off"
+                   : "+{v[128:159]}"(acc[0]), "+{v[160:191]}"(acc[1]), "+{v[192:223]}"(acc[2]), "+{v[224:255]}"(acc[3])
+                   : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k));
+    } else {
+      static_for<CW>([&](auto j) { acc[j][k] = v[(int)j]; });
+    }
+  };
+
+  // SHIFT: the exact remainder of the shift, acc_k -= n_k (c_k - c~_k) for the n_k tokens since the last fold, so that
+  // acc = Sum (x^ - c~) - n (c - c~) = Sum (x^ - c).  Run every 8 tiles and in the epilogue: between folds an accumulator
+  // carries at most 128 tokens' worth of (c - c~), which bounds the rounding of the 7-bit shift -- all 529 tokens of an image
+  // in ONE tight cluster: 1.4 x the reference's own fp32 arithmetic instead of 5.5 x (tests/test_vlad_shift_numerics_cpu.py).
+  // Eight clusters' fp32 columns in flight per round (a centre row past K lies beyond the descriptor and reads as zeros;
+  // its n_k is 0).  These are the only vector-memory loads of the structure inside the tile loop: one stall behind the HBM
+  // prefetch per 8 tiles instead of one per tile.
+  auto fold_remainder = [&]() {
+    const int Kf = __builtin_amdgcn_readfirstlane(a.K);
+#pragma unroll 1
+    for (int k0 = 0; k0 < Kf; k0 += 8) {
+      float c[8][CW];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((k0 + e) * D * 4), c[e]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        const float nk = (float)__builtin_amdgcn_readlane((int)my_count, k);
+        float ct[CW], v[CW];
+        ctilde(k, tid, ct);
+        acc_get(k, v);
+#pragma unroll
+        for (int j = 0; j < CW; ++j) v[j] = __builtin_fmaf(-nk, c[e][j] - ct[j], v[j]);
+        acc_set(k, v);
+      }
+    }
+    my_count = 0;
+  };
 
   if (ntiles > 0) {
     fetch(0);
@@ -741,10 +815,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         if (live && !close && a.lab64) a.lab64[n0 + (int64_t)t * TT + row] = bi;
       }
     }
-    // (issued here, not right after the scoring phase: with the 24 table registers live across the assign phase the kernel
-    // spills four loop invariants, and a spilled invariant is reloaded behind the HBM loads in flight.  The table is 51 KB that
-    // every workgroup reads every tile -- L2-resident; its round trip overlaps the barrier, the resolution and the label reads)
-    if constexpr (SHIFT) load_table();
     lds_barrier();
     // ---- exact resolution: the queued (row, centre) pairs are dealt round-robin to the waves (a close row has 2-3
     //      candidates; dealing whole rows left most waves idle behind the one that had a row), each scored exactly in
@@ -850,48 +920,39 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
           }
         }
       } else if constexpr (SHIFT) {
-        // x / ||x|| - c~_k with c~ from the register-resident byte table: no memory access but the LDS tile.  Four tokens per
-        // round (labels, inverse norms and columns in one LDS round trip), then per token: ONE region of GPR-index mode
-        // reads the CW words that hold cluster k's bytes (element k >> 2), a bit-field extract and a convert give u,
-        // c~ = u step - 128 step (exact), v = x inv - c~ (one fma), and the register-indexed add as in k-means mode.
+        // x / ||x|| - c~_k with c~ from the LDS table: the gather touches LDS and registers only, like k-means mode's.  That is
+        // the point: the vector-memory counter retires IN ORDER per wave, so the first L2 load of a gather (the fp32 centre
+        // columns of the other structure, or a table fetch) cannot complete before the HBM loads of the NEXT tile this wave
+        // issued during scoring -- the gather waited for HBM every tile.  Tokens-per-image sweeps: 6.4 - 6.7 us per tile for
+        // both vector-memory structures against 4.4 us for k-means mode (profiles/r05_vlad_fixed_cost.log).
+        // Four tokens per round (labels, inverse norms, columns and table words in one LDS round trip), then per token: a
+        // funnel shift + bit-field extracts give the fields, c~ = (q - 64) step (exact), v = x inv - c~ (one fma), and the
+        // register-indexed add.  Rows past the unit (label -1, zeros in the tile) add an exact zero to cluster 0.
 #pragma unroll 1
-        for (int n2 = 0; n2 < TT; n2 += 2) {                  // (two tokens per round: four cost this variant 10 registers it does not have)
-          const f3_i32x2 lq = *reinterpret_cast<const f3_i32x2*>(lab + n2);
-          const f32x2 nq = *reinterpret_cast<const f32x2*>(nrm + n2);
-          float v[2][CW];
+        for (int n4 = 0; n4 < TT; n4 += 4) {
+          const i32x4_t lq = *reinterpret_cast<const i32x4_t*>(lab + n4);
+          const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + n4);
+          float v[4][CW];
 #pragma unroll
-          for (int e = 0; e < 2; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int j = 0; j < CW; ++j) v[e][j] = tp[(n2 + e) * LD + j];
-          int kk[2];
+            for (int j = 0; j < CW; ++j) v[e][j] = tp[(n4 + e) * LD + j];
+          int kk[4];
 #pragma unroll
-          for (int e = 0; e < 2; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
+          for (int e = 0; e < 4; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
+          float ct[4][CW];
+          int tt = tid;
+          asm volatile("" : "+v"(tt));
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int kq = kk[e] < 0 ? 0 : kk[e];
-            const int g = kq >> 2;
-            const unsigned sh = (unsigned)(kq & 3) * 8u;
-            unsigned w[CW];
-            if constexpr (CW == 1) {
-              asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v216\n\ts_set_gpr_idx_off"
-                           : "=&v"(w[0]) : "s"(g), "{v[216:223]}"(qsh[0]));
-            } else if constexpr (CW == 2) {
-              asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v176\n\tv_mov_b32 %1, v184\n\ts_set_gpr_idx_off"
-                           : "=&v"(w[0]), "=&v"(w[1]) : "s"(g), "{v[176:183]}"(qsh[0]), "{v[184:191]}"(qsh[1]));
-            } else {
-              asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v136\n\tv_mov_b32 %1, v144\n\tv_mov_b32 %2, v152\n\t"
-                           "s_set_gpr_idx_off"
-                           : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
-                           : "s"(g), "{v[136:143]}"(qsh[0]), "{v[144:151]}"(qsh[1]), "{v[152:159]}"(qsh[2]));
-            }
-            float r[CW];
+          for (int e = 0; e < 4; ++e) ctilde(kk[e] < 0 ? 0 : kk[e], tt, ct[e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
-              // c~ = (u - 128) step: both operations exact (small integers, a power-of-two step)
-              const float ct = ((float)__builtin_amdgcn_ubfe(w[j], sh, 8u) - 128.0f) * sh_step;
-              r[j] = __builtin_fmaf(v[e][j], nq[e], -ct);
+              const float r = __builtin_fmaf(v[e][j], nq[e], -ct[e][j]);
+              v[e][j] = kk[e] < 0 ? 0.0f : r;
             }
-            add_token(kk[e], r);
+            add_token(kk[e] < 0 ? 0 : kk[e], v[e]);
             my_count += (lane == kk[e]) ? 1u : 0u;       // every wave counts (all of them need n_k in the epilogue)
           }
         }
@@ -949,6 +1010,9 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         }
       }
     }
+    if constexpr (SHIFT) {
+      if ((t & 7) == 7 && t + 1 < ntiles) fold_remainder();
+    }
     lds_barrier();
     if (t + 1 < ntiles) stash();
     lds_barrier();
@@ -978,84 +1042,7 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     // 250 us and 9 tiles 122 us -- 5.1 us per tile, the k-means kernel's rate, plus ~75 us per workgroup that is not tiles.
     // The arithmetic per element (operations and their order) is what it was: the same bits.
     const int Kc = __builtin_amdgcn_readfirstlane(a.K);
-    auto acc_get = [&](int k, float (&v)[CW]) {
-      if constexpr (CW == 1) {
-        asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v224\n\ts_set_gpr_idx_off" : "=&v"(v[0]) : "s"(k), "{v[224:255]}"(acc[0]));
-      } else if constexpr (CW == 2) {
-        asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v224\n\ts_set_gpr_idx_off"
-                     : "=&v"(v[0]), "=&v"(v[1]) : "s"(k), "{v[192:223]}"(acc[0]), "{v[224:255]}"(acc[1]));
-      } else if constexpr (CW == 3) {
-        asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v160\n\tv_mov_b32 %1, v192\n\tv_mov_b32 %2, v224\n\ts_set_gpr_idx_off"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                     : "s"(k), "{v[160:191]}"(acc[0]), "{v[192:223]}"(acc[1]), "{v[224:255]}"(acc[2]));
-      } else if constexpr (CW == 4) {
-        asm volatile("s_set_gpr_idx_on %4, 0x1\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v160\n\tv_mov_b32 %2, v192\n\tv_mov_b32 %3, v224\n\t"
-                     "s_set_gpr_idx_off"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                     : "s"(k), "{v[128:159]}"(acc[0]), "{v[160:191]}"(acc[1]), "{v[192:223]}"(acc[2]), "{v[224:255]}"(acc[3]));
-      } else {
-        static_for<CW>([&](auto j) { v[(int)j] = acc[j][k]; });
-      }
-    };
-    auto acc_set = [&](int k, const float (&v)[CW]) {
-      if constexpr (CW == 1) {
-        asm volatile("s_set_gpr_idx_on %2, 0x8\n\tv_mov_b32 v224, %1\n\ts_set_gpr_idx_off" : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
-      } else if constexpr (CW == 2) {
-        asm volatile("s_set_gpr_idx_on %4, 0x8\n\tv_mov_b32 v192, %2\n\tv_mov_b32 v224, %3\n\ts_set_gpr_idx_off"
-                     : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
-      } else if constexpr (CW == 3) {
-        asm volatile("s_set_gpr_idx_on %6, 0x8\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
-                     : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
-                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
-      } else if constexpr (CW == 4) {
-        asm volatile("s_set_gpr_idx_on %8, 0x8\n\tv_mov_b32 v128, %4\n\tv_mov_b32 v160, %5\n\tv_mov_b32 v192, %6\n\tv_mov_b32 v224, %7\n\t"
-                     "s_set_gpr_idx_off"
-                     : "+{v[128:159]}"(acc[0]), "+{v[160:191]}"(acc[1]), "+{v[192:223]}"(acc[2]), "+{v[224:255]}"(acc[3])
-                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k));
-      } else {
-        static_for<CW>([&](auto j) { acc[j][k] = v[(int)j]; });
-      }
-    };
-
-    if constexpr (SHIFT) {
-      // the exact remainder of the shift, once per cluster: acc = Sum (x^ - c~) - n_k (c - c~) = Sum (x^ - c).  Eight clusters'
-      // fp32 columns in flight per round (a centre row past K lies beyond the descriptor and reads as zeros; its n_k is 0)
-      load_table();                              // (a unit without tiles never loaded it)
-#pragma unroll 1
-      for (int k0 = 0; k0 < Kc; k0 += 8) {
-        float c[8][CW];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((k0 + e) * D * 4), c[e]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int k = k0 + e;
-          const float nk = (float)__builtin_amdgcn_readlane((int)my_count, k);
-          const int g = k >> 2;
-          const unsigned sh = (unsigned)(k & 3) * 8u;
-          unsigned w[CW];
-          if constexpr (CW == 1) {
-            asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v216\n\ts_set_gpr_idx_off"
-                         : "=&v"(w[0]) : "s"(g), "{v[216:223]}"(qsh[0]));
-          } else if constexpr (CW == 2) {
-            asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v176\n\tv_mov_b32 %1, v184\n\ts_set_gpr_idx_off"
-                         : "=&v"(w[0]), "=&v"(w[1]) : "s"(g), "{v[176:183]}"(qsh[0]), "{v[184:191]}"(qsh[1]));
-          } else {
-            asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v136\n\tv_mov_b32 %1, v144\n\tv_mov_b32 %2, v152\n\t"
-                         "s_set_gpr_idx_off"
-                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
-                         : "s"(g), "{v[136:143]}"(qsh[0]), "{v[144:151]}"(qsh[1]), "{v[152:159]}"(qsh[2]));
-          }
-          float v[CW];
-          acc_get(k, v);
-#pragma unroll
-          for (int j = 0; j < CW; ++j) {
-            const float ct = ((float)__builtin_amdgcn_ubfe(w[j], sh, 8u) - 128.0f) * sh_step;
-            v[j] = __builtin_fmaf(-nk, c[e][j] - ct, v[j]);
-          }
-          acc_set(k, v);
-        }
-      }
-    }
+    if constexpr (SHIFT) fold_remainder();    // (what the last tiles added since the last fold; a unit without tiles: n_k = 0)
 
     if (a.parts > 1) {
       // (the hand-off of vlad_fused_kernel: partial sums -> workspace, last ticket reduces in part order)
@@ -1173,14 +1160,15 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
 template <int NV, int SW, bool KMEANS, bool SHIFT = false>
 int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
   constexpr int D = NV * 128;
-  if constexpr (!KMEANS && !SHIFT && f3_cw(D / SW) <= 3) {
+  if constexpr (!KMEANS && !SHIFT && f3_cw(D / SW) <= 4) {
     if (a.shift == SW && a.shift_tab) return launch_fused3<NV, SW, false, true>(a, units, stream);
   }
-  if constexpr (SHIFT) {
-    // (the table itself was written by the caller's centre-preparation launch: shift_table_thread, common.hpp)
-    static_assert((2 * f3_cw(D / SW) * 16 + 4) * 64 * SW <= F3_SHIFT_TAB_BYTES, "shift table region");
-  }
-  const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32);
+  // (SHIFT: the table itself was written by the caller's centre-preparation launch -- shift_table_thread, common.hpp)
+  static_assert(!SHIFT || (7 * f3_cw(D / SW) + 1) * 64 * SW * 4 <= (int)F3_SHIFT_TAB_BYTES, "shift table region");
+  const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32 +
+                                      (SHIFT ? 7 * f3_cw(D / SW) * 64 * SW : 0));
+  static_assert(sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32 +
+                                 (SHIFT ? 7 * f3_cw(D / SW) * 64 * SW : 0)) <= 160 * 1024, "LDS of one CU");
   auto kern = fused3_kernel<NV, SW, KMEANS, SHIFT>;
   static bool attr = false;
   if (!attr) {
@@ -1234,7 +1222,7 @@ int fused3_shift_waves(int64_t D) {
   if (!(D == 384 || D == 768 || D == 1024 || D == 1536)) return 0;
   const int nv = (int)(D / 128);
   const int sw = (nv % 2 == 0 && ver != 3) ? 8 : 4;
-  return f3_cw((int)(D / sw)) <= 3 ? sw : 0;
+  return f3_cw((int)(D / sw)) <= 4 ? sw : 0;
 }
 
 bool fused_supported(int64_t D, int64_t K) {

@@ -377,8 +377,8 @@ def _vlad_f64(x, centers, labels):
                                     (768, "one_cluster"), (384, "random")])
 def test_vlad_tight_clusters(D, case, shift):
     """Tight clusters -- unit tokens 1e-2 away from a unit-norm centre -- on both accumulation structures of the fused kernel
-    (option vlad_shift: 1 = residuals against the 8-bit centre table + exact remainder per cluster; 0 = the fp32 centre
-    gathered per token, the default).  The stress amplifies the one rounding every fp32 implementation shares (x^ = x / ||x||, good
+    (option vlad_shift: 1 = residuals against the 7-bit centre table in LDS + the exact remainder folded in every 8 tiles,
+    the default; 0 = the fp32 centre gathered per token).  The stress amplifies the one rounding every fp32 implementation shares (x^ = x / ||x||, good
     to ~6e-8: ~6e-6 of a 1e-2 residual), so the yardstick is the reference's own fp32 arithmetic (the oracle): the kernel must
     be as close to a float64 evaluation as the oracle is (factor 3 + 1e-6) and within 2e-5 of the oracle; a plain
     sum x^ - n_k c_k would be off by 4e-5 ... 7e-4 here (tests/test_vlad_shift_numerics_cpu.py).  Few images (several
@@ -404,8 +404,7 @@ def test_vlad_tight_clusters(D, case, shift):
             v64 = _vlad_f64(x[i], c, lab[i])
             e_or = float((v32.double() - v64).norm())
             e_k = float((out[i].cpu().double() - v64).norm())
-            # (the shifted accumulation with ALL 529 tokens in one cluster: 3.2 x measured, 2.7 x in the CPU emulation)
-            assert e_k <= (4.0 if shift else 3.0) * e_or + 1e-6, (case, D, shift, n_img, i, e_k, e_or)
+            assert e_k <= 3.0 * e_or + 1e-6, (case, D, shift, n_img, i, e_k, e_or)
             assert l2rel(out[i], v32) <= 2e-5, (case, D, shift, n_img, i, l2rel(out[i], v32))
             worst = max(worst, e_k / max(e_or, 1e-30))
         print(f"[tight {case} D={D} shift={shift} n_img={n_img}] kernel / oracle distance to float64: {worst:.2f}")

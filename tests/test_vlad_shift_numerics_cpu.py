@@ -1,7 +1,7 @@
 """CPU emulation (NumPy fp32, operation by operation) of the fused VLAD kernel's SHIFTED accumulation
 (csrc/vlad_fused.hip, SHIFT; table: csrc/common.hpp ``shift_table_thread``) -- no GPU needed.
 
-The kernel does not gather the fp32 centre per token.  It accumulates ``x^ - c~`` where ``c~`` is an 8-bit copy of the
+The kernel does not gather the fp32 centre per token.  It accumulates ``x^ - c~`` where ``c~`` is a 7-bit copy of the
 centres under one power-of-two step per lane (a lane = CW consecutive columns of every cluster), and subtracts the exact
 remainder ``n_k (c_k - c~_k)`` once per cluster: ``sum (x^ - c_k)`` as the reference sums it (utilities.py:854-861), without
 the cancellation of the plain ``sum x^ - n_k c_k``.  This file pins the arithmetic claims the kernel comment makes:
@@ -17,28 +17,39 @@ CW = 3          # D = 1536 on 8 waves: 192 columns per wave, 3 per lane
 
 
 def shift_table(c):
-    """[K, D] fp32 centres -> (c_tilde [K, D] fp32, step [D // CW] fp32): per lane one power of two >= max |c| / 127."""
+    """[K, D] fp32 centres -> (c_tilde [K, D] fp32, step [D // CW] fp32): per lane one power of two >= max |c| / 63 (7-bit fields)."""
     K, D = c.shape
     lanes = c.reshape(K, D // CW, CW)
     cm = np.minimum(np.abs(lanes).max(axis=(0, 2)), np.float32(1e30)).astype(np.float32)
-    bits = (cm * np.float32(1.0 / 127.0)).astype(np.float32).view(np.uint32)
+    bits = (cm * np.float32(1.0 / 63.0)).astype(np.float32).view(np.uint32)
     sb = (bits + np.uint32(0x007FFFFF)) & np.uint32(0x7F800000)
     sb = np.where(sb == 0, np.uint32(0x3F800000), sb).astype(np.uint32)
     step = sb.view(np.float32)
     inv = (np.uint32(0x7F000000) - sb).view(np.float32)
-    q = np.clip(np.rint(lanes * inv[None, :, None]), -127, 127).astype(np.float32)
-    u = (q + 128).astype(np.uint32)
-    assert u.min() >= 1 and u.max() <= 255
-    ct = ((u.astype(np.float32) - np.float32(128.0)) * step[None, :, None]).astype(np.float32)
+    q = np.clip(np.rint(lanes * inv[None, :, None]), -63, 63).astype(np.float32)
+    u = (q + 64).astype(np.uint32)
+    assert u.min() >= 1 and u.max() <= 127
+    ct = ((u.astype(np.float32) - np.float32(64.0)) * step[None, :, None]).astype(np.float32)
     return ct.reshape(K, D), step
 
 
-def vlad_shifted_fp32(x, c, labels):
-    """The kernel's arithmetic for one image, fp32 step by step in token order."""
+FOLD_TOKENS = 128          # the kernel folds the exact remainder into the accumulators every 8 tiles of 16 tokens
+
+
+def vlad_shifted_fp32(x, c, labels, fold=FOLD_TOKENS):
+    """The kernel's arithmetic for one image, fp32 step by step in token order: x^ - c~ accumulated, the exact remainder
+    n_k (c_k - c~_k) of the tokens since the last fold subtracted every ``fold`` tokens and at the end."""
     K, D = c.shape
     ct, _ = shift_table(c)
     acc = np.zeros((K, D), np.float32)
     cnt = np.zeros(K, np.float32)
+    rem = (c - ct).astype(np.float32)
+
+    def fold_now():
+        nonlocal acc
+        acc = (acc.astype(np.float64) - cnt[:, None].astype(np.float64) * rem.astype(np.float64)).astype(np.float32)    # one fma
+        cnt[:] = 0
+
     for n in range(x.shape[0]):
         k = labels[n]
         nrm = np.float32(max(np.sqrt(np.float32((x[n] * x[n]).sum(dtype=np.float32))), np.float32(1e-12)))
@@ -46,9 +57,10 @@ def vlad_shifted_fp32(x, c, labels):
         r = (x[n].astype(np.float64) * np.float64(inv) - ct[k].astype(np.float64)).astype(np.float32)   # one fma
         acc[k] = acc[k] + r
         cnt[k] += 1
-    rem = (c - ct).astype(np.float32)
-    out = (acc.astype(np.float64) - cnt[:, None].astype(np.float64) * rem.astype(np.float64)).astype(np.float32)    # one fma
-    return out
+        if fold and (n + 1) % fold == 0:
+            fold_now()
+    fold_now()
+    return acc
 
 
 def vlad_plain_fp32(x, c, labels):
@@ -111,7 +123,7 @@ def test_table_is_exact_and_close():
         assert np.all(np.abs(c - ct) <= lanes_step / 2 + 1e-12)
         assert np.all((ct / lanes_step) == np.round(ct / lanes_step))
         cm = np.abs(c.reshape(32, -1, CW)).max(axis=(0, 2))
-        assert np.all(step >= cm / 127) and np.all(step < 2 * cm / 127 + 1e-30)
+        assert np.all(step >= cm / 63) and np.all(step < 2 * cm / 63 + 1e-30)
     # an all-zero lane and a zero matrix quantise to zeros
     z = np.zeros((4, 12), np.float32)
     ct, step = shift_table(z)
