@@ -92,7 +92,6 @@ enum Option {
   OPT_H3_PATCH,          // fp16 mode: patch embedding on the two-term fp16 GEMM (1, default) or the fp32 MFMA GEMM (0)
   OPT_TOPK_FEWQ_QDMA,    // few-query scores on fp16 planes: 1 = queries pre-split once, DMA'd into LDS per slab; 0 = split per slab
   OPT_H3S_W12_TALL,      // small-M plan of the w12 / fc1 GEMM of one image: 1 = 192 x 128 tiles (one workgroup per CU), 0 = 128 x 128
-  OPT_VLAD_SHIFT,        // fused VLAD: 1 = shifted accumulation against a 7-bit centre table in LDS (no vector memory in the gather), 0 = L2 gather
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -314,74 +313,10 @@ struct FusedArgs {
   int64_t* lab64;          // optional [total] labels
   int norm_descs, intra;
   int metric;              // 0 cosine (||chat_k|| = 1), 1 euclidean (chat = 2 c, cbias = -||c||^2): scales fused3's error bound
-  int shift;               // VLAD: > 0 = accumulate x^ - c~ against a 7-bit table of the centres held in LDS,
-                           // exact remainder folded in every 8 tiles (option vlad_shift) -- the value is the waves per workgroup the
-                           // table in shift_tab was written for (fused3_shift_waves); 0 = gather the fp32 centre columns per token
-  unsigned* shift_tab;     // that table (F3_SHIFT_TAB_BYTES), written by the caller's centre-preparation launch (shift_table_thread)
   int parts;               // VLAD: workgroups per image (1 = one each); > 1 needs the two buffers below
   float* part_buf;         // [units, parts, K, D] partial sums
   unsigned* part_tickets;  // [units] arrival counters (zeroed by the launcher)
 };
-constexpr size_t F3_SHIFT_TAB_BYTES = 64 * 1024;
-// columns per lane of fused3_kernel: a wave owns SLICE = D / SW consecutive columns, CW consecutive ones per lane
-__host__ __device__ constexpr int f3_cw(int slice) {
-  int cw = (slice + 63) / 64;
-  while (slice % cw) ++cw;
-  return cw;
-}
-int fused3_shift_waves(int64_t D);
-// The 7-bit table of fused3_kernel's SHIFT mode, once per call (it depends on the centres only).  Thread t = (wave, lane) of a
-// workgroup shaped like fused3's (64 sw threads) owns the CW columns gcol .. gcol + CW - 1 of every centre, as that kernel's
-// lane does: one power-of-two step >= max |c| / 63 over its columns and all clusters, fields q = round(c / step) + 64 in
-// 1 .. 127 (c~ = (q - 64) step exactly), packed as ONE bit stream per lane -- cluster k's CW fields at bit 7 CW k, 7 CW dwords in
-// all.  Layout: dword d of all threads contiguous -- [7 CW][64 sw] dwords, then the steps' bit patterns [64 sw].
-template <int CW>
-__device__ inline void shift_table_lane(const float* __restrict__ centers, int K, int D, int nt, int gcol, unsigned* __restrict__ tab, int t) {
-  // the lane's CW columns of all K <= 32 centres in registers: independent loads, one round trip
-  float c[32][CW];
-#pragma unroll
-  for (int k = 0; k < 32; ++k)
-#pragma unroll
-    for (int j = 0; j < CW; ++j) c[k][j] = k < K ? centers[(int64_t)k * D + gcol + j] : 0.f;
-  float cm = 0.f;
-#pragma unroll
-  for (int k = 0; k < 32; ++k)
-#pragma unroll
-    for (int j = 0; j < CW; ++j) cm = fmaxf(cm, fabsf(c[k][j]));
-  cm = fminf(cm, 1.0e30f);                      // (inf / huge centres: step huge, every field 64, c~ = 0 = the plain sum)
-  // the power of two >= max |c| / 63 (0 -> 1: an all-zero lane quantises to zeros under any step)
-  unsigned sb = (__float_as_uint(cm * (1.0f / 63.0f)) + 0x007fffffu) & 0x7f800000u;
-  if (sb == 0u) sb = 0x3f800000u;
-  const float inv_step = __uint_as_float(0x7f000000u - sb);          // 1 / 2^e, exact
-  unsigned word[7 * CW];
-#pragma unroll
-  for (int d = 0; d < 7 * CW; ++d) word[d] = 0u;
-#pragma unroll
-  for (int k = 0; k < 32; ++k)
-#pragma unroll
-    for (int j = 0; j < CW; ++j) {
-      float v = rintf(c[k][j] * inv_step);                           // |v| <= 63 (NaN -> 0: the field stays in range); rows >= K: 0 -> 64
-      v = v == v ? fminf(fmaxf(v, -63.0f), 63.0f) : 0.0f;
-      const unsigned q = (unsigned)((int)v + 64);
-      const int bit = 7 * (k * CW + j), d = bit >> 5, sh = bit & 31;  // (compile-time after unrolling)
-      word[d] |= q << sh;
-      if (sh > 25) word[d + 1] |= q >> (32 - sh);
-    }
-#pragma unroll
-  for (int d = 0; d < 7 * CW; ++d) tab[(int64_t)d * nt + t] = word[d];
-  tab[(int64_t)7 * CW * nt + t] = sb;
-}
-__device__ inline void shift_table_thread(const float* __restrict__ centers, int K, int D, int sw, unsigned* __restrict__ tab, int t) {
-  const int nt = 64 * sw, slice = D / sw, cw = f3_cw(slice), gl = slice / cw;
-  const int lane = t & 63, wave = t >> 6;
-  const int gcol = wave * slice + cw * (lane < gl ? lane : 0);
-  switch (cw) {
-    case 1: shift_table_lane<1>(centers, K, D, nt, gcol, tab, t); break;
-    case 2: shift_table_lane<2>(centers, K, D, nt, gcol, tab, t); break;
-    case 3: shift_table_lane<3>(centers, K, D, nt, gcol, tab, t); break;
-    default: shift_table_lane<4>(centers, K, D, nt, gcol, tab, t); break;
-  }
-}
 bool fused_supported(int64_t D, int64_t K);
 int vlad_fused(const FusedArgs& a, int64_t units, bool kmeans, hipStream_t stream);
 

@@ -43,17 +43,10 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 
 // mode 0 (cosine): chat = c / (||c|| + 1e-8), cb = 0
 // mode 1 (euclid): chat = 2 c,                cb = -||c||^2   (argmax of 2ab - b^2; -a^2 is per-row constant)
-// blocks kpad .. (tab != null): the 8-bit centre table of the fused kernel's shifted accumulation (common.hpp), 256 threads each
 __global__ __launch_bounds__(256) void center_prep_kernel(const float* __restrict__ c, float* __restrict__ chat,
-                                                          float* __restrict__ cb, int K, int D, int mode, int kpad,
-                                                          unsigned* __restrict__ tab, int tab_waves) {
+                                                          float* __restrict__ cb, int K, int D, int mode) {
   __shared__ float red[4];
   const int k = blockIdx.x;
-  if (k >= kpad) {
-    const int t = (k - kpad) * 256 + (int)threadIdx.x;
-    if (tab && t < 64 * tab_waves) shift_table_thread(c, K, D, tab_waves, tab, t);
-    return;
-  }
   float* dst = chat + (int64_t)k * D;
   if (k >= K) {
     for (int i = threadIdx.x; i < D; i += 256) dst[i] = 0.f;
@@ -413,7 +406,6 @@ struct VladWs {
   int* lab32;
   float* part_buf;
   unsigned* tickets;
-  unsigned* shift_tab;     // fused kernel, option vlad_shift: the 8-bit centre table (vlad_fused.hip)
   size_t bytes;
 };
 VladWs carve(void* ws, size_t cap, int64_t n, int64_t D, int64_t K, int64_t n_img = 0, int parts = 1) {
@@ -426,7 +418,6 @@ VladWs carve(void* ws, size_t cap, int64_t n, int64_t D, int64_t K, int64_t n_im
   w.rowsq = a.take<float>(n > 0 ? n : 1);
   w.nrm = a.take<float>(n > 0 ? n : 1);
   w.lab32 = a.take<int>(n > 0 ? n : 1);
-  w.shift_tab = a.take<unsigned>(F3_SHIFT_TAB_BYTES / sizeof(unsigned));
   w.part_buf = nullptr;
   w.tickets = nullptr;
   if (parts > 1) {
@@ -499,11 +490,9 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   // The fused kernel wherever it applies (K <= 32, the ViT widths); option vlad_two_pass = 1 selects the general path.
   if (fused) {
     // single-pass fused kernel (vlad_fused.hip): tokens are read from HBM once
-    const int shift_waves = fused3_shift_waves(D);       // > 0: the launch below accumulates against the 8-bit centre table
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
-      hipLaunchKernelGGL(center_prep_kernel, dim3(kp + (shift_waves * 64 + 255) / 256), dim3(256), 0, stream, centers, w.chat, w.cb,
-                         (int)K, (int)D, metric, kp, shift_waves ? w.shift_tab : nullptr, shift_waves);
+      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, metric);
       ANYLOC_TRY(launch_status("center_prep_kernel"));
     }
     FusedArgs fa{};
@@ -514,15 +503,12 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
     fa.norm_descs = (flags & ANYLOC_VLAD_NORM_DESCS) ? 1 : 0;
     fa.intra = (flags & ANYLOC_VLAD_INTRA_NORM) ? 1 : 0;
     fa.parts = parts; fa.part_buf = w.part_buf; fa.part_tickets = w.tickets;
-    fa.shift = shift_waves;
-    fa.shift_tab = w.shift_tab;
     return vlad_fused(fa, n_img, false, stream);
   }
   if (total_tokens > 0) {
     {
       ProfScope prof("vlad_center_prep", stream, 3.0 * K * D, 8.0 * K * D);
-      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, metric, kp,
-                         static_cast<unsigned*>(nullptr), 0);
+      hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, metric);
       ANYLOC_TRY(launch_status("center_prep_kernel"));
     }
     ANYLOC_TRY(run_scores(tokens, total_tokens, D, w, K, metric == 1, stream, "vlad_scores_gemm"));
@@ -751,8 +737,7 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
   unsigned* cnt_part = tail.take<unsigned>(chunks * K);
   const int kp = (int)kpad_of(K);
 
-  hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, mode, kp,
-                     static_cast<unsigned*>(nullptr), 0);
+  hipLaunchKernelGGL(center_prep_kernel, dim3(kp), dim3(256), 0, stream, centers, w.chat, w.cb, (int)K, (int)D, mode);
   ANYLOC_TRY(launch_status("center_prep_kernel"));
   if (fused_supported(D, K) && !two_pass_forced()) {
     FusedArgs fa{};

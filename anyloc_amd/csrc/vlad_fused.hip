@@ -405,6 +405,11 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // register file of its SIMD lane, 256 VGPRs + 256 AGPRs).  Per wave at D = 1536: 96 / 192 accumulators + 48 / 96 registers
 // of fp16 centres + 48 / 96 registers of the next tile in flight.  Nothing may spill: a scratch reload waits -- the
 // vector-memory counter retires in order -- for the HBM loads of the next tile.
+constexpr int f3_cw(int slice) {
+  int cw = (slice + 63) / 64;
+  while (slice % cw) ++cw;
+  return cw;
+}
 constexpr int f3_gcd(int x, int y) { return y == 0 ? x : f3_gcd(y, x % y); }
 
 // CW consecutive fp32 columns of a lane as ONE memory instruction (CW = 3: buffer_load_dwordx3 -- a lane's columns start at a
@@ -441,25 +446,8 @@ __device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-// SHIFT (VLAD mode, CW <= 4; option vlad_shift -- round 5, from round 4's verdict item 5): no per-token gather of the centre's
-// columns.  Sum_n (x^_n - c_k) = Sum_n (x^_n - c~_k) - n_k (c_k - c~_k): the accumulators collect x^ - c~ where c~ is a 7-BIT
-// copy of the centres held in LDS (a lane's CW columns of all 32 clusters as one bit stream under one power-of-two step per
-// lane, step >= max |c| / 63 over the lane's columns, c~ = (q - 64) step exactly; 43 KB at D = 1536), and the exact remainder
-// n_k (c_k - c~_k) is subtracted from the fp32 centres every 8 tiles and in the epilogue (fold_remainder).
-// * Why not plain Sum x^ - n_k c_k (k-means mode's loop): for a tight cluster the two terms cancel -- |x^ - c| ~ 1e-2 |c| and
-//   n_k = 16 lose 6 - 7 of the 24 bits, 4e-5 ... 7e-4 against the 1e-5 bar (the reference sums fp32 residuals,
-//   utilities.py:854-861).  With the shift the accumulator holds n (c - c~) + Sum (x^ - c) with |c - c~| ~ |c| / 50 and n <= 128
-//   between folds: as close to float64 as the reference's own fp32 arithmetic (factor <= 1.4 with all 529 tokens of an image
-//   in ONE cluster; tests/test_vlad_shift_numerics_cpu.py, tests/test_gpu_vlad_topk.py::test_vlad_tight_clusters).
-// * Why the table must be in LDS: the first build of this structure fetched an 8-bit table from L2 once per tile -- correct, and
-//   7 - 10 % SLOWER than the gather (profiles/r05_vlad_shift_vs_gather.log).  Tokens-per-image sweeps then showed 6.4 - 6.7 us per
-//   tile for BOTH structures against 4.4 us for k-means mode, which has no vector-memory access in its gather: the vector-memory
-//   counter retires in order per wave, so any load in the gather waits for the HBM loads of the next tile the wave issued
-//   during scoring (profiles/r05_vlad_fixed_cost.log).  Two other suspects were measured and cleared on the way: the unrolled
-//   epilogue (10 300 of 12 800 instructions, now runtime loops: no change in time) and per-token LDS round trips in the gather.
-template <int NV, int SW, bool KMEANS, bool SHIFT = false>
+template <int NV, int SW, bool KMEANS>
 __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
-  static_assert(!(KMEANS && SHIFT), "the shifted accumulation is a VLAD-mode structure");
   constexpr int D = NV * 128;
   constexpr int LD = D + 4;
   constexpr int NT3 = 64 * SW;
@@ -487,7 +475,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   float* red = reinterpret_cast<float*>(amb + TT);        // [SW][32] epilogue reductions
   int* npairs = reinterpret_cast<int*>(red + SW * 32);    // [1] (row, centre) pairs queued for exact scoring in this tile
   int* pairs = npairs + 4;                                // [16 * 32] queue of (row << 5 | centre)
-  unsigned* tab7 = reinterpret_cast<unsigned*>(pairs + TT * 32);   // SHIFT only: [7 CW][NT3] the 7-bit centre table (below)
   float* exs = part;                          // after barrier B the score partials are dead: exact-score table [16][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -548,21 +535,27 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     if constexpr (!KMEANS) asm volatile("" : "+v"(tt));
     return tt;
   };
+  // (the tile is contiguous in memory: float4 slot f = tid + NT3 r sits at byte 16 f -- (row D + 4 c4) 4 = 16 f -- so the load
+  // address is one shift of the thread id plus constants: no division, nothing to hoist or to recompute)
   auto fetch_pair = [&](int t, auto kbc) {
     const unsigned so = (unsigned)t * (unsigned)(TT * D * 4);
-    const int ft = opaque_tid();
     static_for<2>([&](auto h) {
       constexpr int i = 2 * decltype(kbc)::value + decltype(h)::value, r = i % P, j = i / P;
-      const int f = ft + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
-      stg[j * P + r] = bload16(x_rsrc, (unsigned)((row * D + 4 * c4) * 4), so + (unsigned)(j * RSTEP * D * 4));
+      stg[j * P + r] = bload16(x_rsrc, (unsigned)(tid * 16), so + (unsigned)(NT3 * r * 16 + j * RSTEP * D * 4));
     });
   };
   auto stash = [&]() {
     const int ft = opaque_tid();
 #pragma unroll
     for (int r = 0; r < P; ++r) {
-      const int f = ft + NT3 * r, row = f / (D / 4), c4 = f - row * (D / 4);
-      float* dst = tile + row * LD + 4 * c4;
+      // row = (ft + NT3 r) / (D / 4) by compares: ft < NT3, so the quotient is the constant (NT3 r) / (D / 4) plus the number
+      // of row boundaries below ft -- one or two compile-time thresholds instead of a division sequence per address
+      constexpr int Q = D / 4;
+      const int f = ft + NT3 * r;
+      int row = (NT3 * r) / Q;
+#pragma unroll
+      for (int m = 1; ((NT3 * r) / Q + m) * Q - NT3 * r < NT3; ++m) row += ft >= ((NT3 * r) / Q + m) * Q - NT3 * r ? 1 : 0;
+      float* dst = tile + 4 * f + 4 * row;        // = tile + row LD + 4 (f - row Q): the padded row adds 4 floats per row
 #pragma unroll
       for (int j = 0; j < NF / P; ++j) *reinterpret_cast<f32x4*>(dst + j * RSTEP * LD) = stg[j * P + r];
     }
@@ -576,33 +569,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   const int gcol = wave * SLICE + CW * (lane < GL ? lane : 0);
   const __amdgpu_buffer_rsrc_t cen_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<float*>(KMEANS ? a.chat : a.centers)), 0, (KMEANS ? 32 : a.K) * D * 4, 0x00020000);
-
-  // ---- SHIFT: the 7-bit table of the centres (shift_table_thread wrote it for this very (SW, CW) shape into the workspace) is
-  //      copied into LDS once per workgroup: [7 CW dwords][NT3 lanes], dword d of every lane contiguous.  A lane's 32 x CW
-  //      fields of 7 bits are one bit stream, cluster k's CW fields at bit 7 CW k: two dword reads at a wave-uniform dword index
-  //      and one funnel shift fetch them -- no vector-memory access in the gather (see there why that matters), no registers
-  //      held across the tile loop (an 8-bit table is 48 KB: 4 KB more than this kernel's LDS has left at D = 1536) ----
-  constexpr int NQ = 7 * CW;
-  float sh_step = 1.0f;
-  if constexpr (SHIFT) {
-    static_assert(CW <= 4, "a cluster's fields must fit one funnel shift (7 CW <= 32 bits)");
-    const __amdgpu_buffer_rsrc_t tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        uniform_ptr(const_cast<unsigned*>(a.shift_tab)), 0, (NQ + 1) * NT3 * 4, 0x00020000);
-#pragma unroll
-    for (int d = 0; d < NQ; ++d)
-      tab7[d * NT3 + tid] = __builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, (unsigned)(tid * 4), (unsigned)(d * NT3 * 4), 0);
-    sh_step = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, (unsigned)(tid * 4), (unsigned)(NQ * NT3 * 4), 0));
-  }
-  // c~ of cluster k (wave-uniform) for this lane's CW columns: field q in 1 .. 127, c~ = (q - 64) step exactly
-  // (tt: an opaque copy of the thread id made once per round by the caller -- the lane's table address is rebuilt, not held
-  // across the tile loop, and the reads of a round's tokens stay free to be issued together)
-  auto ctilde = [&](int k, int tt, float (&ct)[CW]) {
-    const int b0 = k * NQ, d0 = b0 >> 5, d1 = d0 + 1 < NQ ? d0 + 1 : d0;
-    const unsigned lo = tab7[d0 * NT3 + tt], hi = tab7[d1 * NT3 + tt];
-    const unsigned w = __builtin_amdgcn_alignbit(hi, lo, (unsigned)(b0 & 31));
-#pragma unroll
-    for (int j = 0; j < CW; ++j) ct[j] = ((float)((w >> (7 * j)) & 0x7fu) - 64.0f) * sh_step;
-  };
 
   // scoring coordinates: 16x16x32 fragments -- token / centre = lane & 15, 8 consecutive k at 8 (lane >> 4) of the k-block
   const int fr = lane & 15, fq = lane >> 4;
@@ -667,35 +633,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     } else {
       static_for<CW>([&](auto j) { acc[j][k] = v[(int)j]; });
     }
-  };
-
-  // SHIFT: the exact remainder of the shift, acc_k -= n_k (c_k - c~_k) for the n_k tokens since the last fold, so that
-  // acc = Sum (x^ - c~) - n (c - c~) = Sum (x^ - c).  Run every 8 tiles and in the epilogue: between folds an accumulator
-  // carries at most 128 tokens' worth of (c - c~), which bounds the rounding of the 7-bit shift -- all 529 tokens of an image
-  // in ONE tight cluster: 1.4 x the reference's own fp32 arithmetic instead of 5.5 x (tests/test_vlad_shift_numerics_cpu.py).
-  // Eight clusters' fp32 columns in flight per round (a centre row past K lies beyond the descriptor and reads as zeros;
-  // its n_k is 0).  These are the only vector-memory loads of the structure inside the tile loop: one stall behind the HBM
-  // prefetch per 8 tiles instead of one per tile.
-  auto fold_remainder = [&]() {
-    const int Kf = __builtin_amdgcn_readfirstlane(a.K);
-#pragma unroll 1
-    for (int k0 = 0; k0 < Kf; k0 += 8) {
-      float c[8][CW];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f3_load_cols<CW>(cen_rsrc, (unsigned)(gcol * 4), (unsigned)((k0 + e) * D * 4), c[e]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = k0 + e;
-        const float nk = (float)__builtin_amdgcn_readlane((int)my_count, k);
-        float ct[CW], v[CW];
-        ctilde(k, tid, ct);
-        acc_get(k, v);
-#pragma unroll
-        for (int j = 0; j < CW; ++j) v[j] = __builtin_fmaf(-nk, c[e][j] - ct[j], v[j]);
-        acc_set(k, v);
-      }
-    }
-    my_count = 0;
   };
 
   if (ntiles > 0) {
@@ -919,52 +856,14 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             if (wave == 0) my_count += (lane == kk[e]) ? 1u : 0u;
           }
         }
-      } else if constexpr (SHIFT) {
-        // x / ||x|| - c~_k with c~ from the LDS table: the gather touches LDS and registers only, like k-means mode's.  That is
-        // the point: the vector-memory counter retires IN ORDER per wave, so the first L2 load of a gather (the fp32 centre
-        // columns of the other structure, or a table fetch) cannot complete before the HBM loads of the NEXT tile this wave
-        // issued during scoring -- the gather waited for HBM every tile.  Tokens-per-image sweeps: 6.4 - 6.7 us per tile for
-        // both vector-memory structures against 4.4 us for k-means mode (profiles/r05_vlad_fixed_cost.log).
-        // Four tokens per round (labels, inverse norms, columns and table words in one LDS round trip), then per token: a
-        // funnel shift + bit-field extracts give the fields, c~ = (q - 64) step (exact), v = x inv - c~ (one fma), and the
-        // register-indexed add.  Rows past the unit (label -1, zeros in the tile) add an exact zero to cluster 0.
-#pragma unroll 1
-        for (int n4 = 0; n4 < TT; n4 += 4) {
-          const i32x4_t lq = *reinterpret_cast<const i32x4_t*>(lab + n4);
-          const f32x4 nq = *reinterpret_cast<const f32x4*>(nrm + n4);
-          float v[4][CW];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < CW; ++j) v[e][j] = tp[(n4 + e) * LD + j];
-          int kk[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) kk[e] = __builtin_amdgcn_readfirstlane(lq[e]);
-          float ct[4][CW];
-          int tt = tid;
-          asm volatile("" : "+v"(tt));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ctilde(kk[e] < 0 ? 0 : kk[e], tt, ct[e]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int j = 0; j < CW; ++j) {
-              const float r = __builtin_fmaf(v[e][j], nq[e], -ct[e][j]);
-              v[e][j] = kk[e] < 0 ? 0.0f : r;
-            }
-            add_token(kk[e] < 0 ? 0 : kk[e], v[e]);
-            my_count += (lane == kk[e]) ? 1u : 0u;       // every wave counts (all of them need n_k in the epilogue)
-          }
-        }
       } else {
         // x / ||x|| - c_k.  The centres' CW columns of TG tokens are requested at once -- one CW-wide load per token, TT / TG
         // L2 round trips per tile -- and the tokens are then added in order while their columns come from the LDS tile.  The
-        // order of additions per (cluster, column) is the token order: bitwise the same sums as every earlier structure.
+        // order of additions per (cluster, column) is the token order (deterministic); x inv - c is one fused multiply-add.
         // Round 5: the tile columns come from LDS two tokens at a time, one pair ahead of the adds -- rounds 3-4 read each
         // token's three floats right before its adds, sixteen exposed LDS round trips per tile and wave; tokens-per-image
         // sweeps (tools/probe_vlad_fixed.py) put VLAD mode at 6.5 us per tile against 4.3 us for the k-means loop with BOTH
-        // accumulation structures, i.e. the difference was never the centre gather.  Rows past the unit (label -1, zeros in
-        // the tile) add an exact zero to cluster 0 instead of taking a branch per token.
+        // structures tried, i.e. the difference was never the centre gather: the tile loop is bound by vector-instruction issue.
         // TG tokens per round (16 = the whole tile needs 16 CW registers more than this kernel has at D = 1536)
         constexpr int TG = 8;
 #pragma unroll 1
@@ -998,20 +897,13 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             if (p2 + 1 < TG / 2) read_pair(buf ^ 1, p2 + 1);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              const int k = kk[2 * p2 + e];
 #pragma unroll
-              for (int j = 0; j < CW; ++j) {
-                const float r = v[buf][e][j] * nq[buf][e] - c[2 * p2 + e][j];
-                v[buf][e][j] = k < 0 ? 0.0f : r;
-              }
-              add_token(k < 0 ? 0 : k, v[buf][e]);
+              for (int j = 0; j < CW; ++j) v[buf][e][j] = __builtin_fmaf(v[buf][e][j], nq[buf][e], -c[2 * p2 + e][j]);   // x^ - c, one rounding
+              add_token(kk[2 * p2 + e], v[buf][e]);     // (label -1 = a row past the unit: skipped by a wave-uniform branch)
             }
           }
         }
       }
-    }
-    if constexpr (SHIFT) {
-      if ((t & 7) == 7 && t + 1 < ntiles) fold_remainder();
     }
     lds_barrier();
     if (t + 1 < ntiles) stash();
@@ -1042,8 +934,6 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
     // 250 us and 9 tiles 122 us -- 5.1 us per tile, the k-means kernel's rate, plus ~75 us per workgroup that is not tiles.
     // The arithmetic per element (operations and their order) is what it was: the same bits.
     const int Kc = __builtin_amdgcn_readfirstlane(a.K);
-    if constexpr (SHIFT) fold_remainder();    // (what the last tiles added since the last fold; a unit without tiles: n_k = 0)
-
     if (a.parts > 1) {
       // (the hand-off of vlad_fused_kernel: partial sums -> workspace, last ticket reduces in part order)
       {
@@ -1157,19 +1047,11 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
 
 #undef x_rsrc
 
-template <int NV, int SW, bool KMEANS, bool SHIFT = false>
+template <int NV, int SW, bool KMEANS>
 int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
   constexpr int D = NV * 128;
-  if constexpr (!KMEANS && !SHIFT && f3_cw(D / SW) <= 4) {
-    if (a.shift == SW && a.shift_tab) return launch_fused3<NV, SW, false, true>(a, units, stream);
-  }
-  // (SHIFT: the table itself was written by the caller's centre-preparation launch -- shift_table_thread, common.hpp)
-  static_assert(!SHIFT || (7 * f3_cw(D / SW) + 1) * 64 * SW * 4 <= (int)F3_SHIFT_TAB_BYTES, "shift table region");
-  const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32 +
-                                      (SHIFT ? 7 * f3_cw(D / SW) * 64 * SW : 0));
-  static_assert(sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32 +
-                                 (SHIFT ? 7 * f3_cw(D / SW) * 64 * SW : 0)) <= 160 * 1024, "LDS of one CU");
-  auto kern = fused3_kernel<NV, SW, KMEANS, SHIFT>;
+  const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32);
+  auto kern = fused3_kernel<NV, SW, KMEANS>;
   static bool attr = false;
   if (!attr) {
     ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1212,18 +1094,6 @@ int launch_fused(const FusedArgs& a, int64_t units, hipStream_t stream) {
 }
 
 }  // namespace
-
-// Waves per workgroup of the launch vlad_fused() will make for this width IF it runs the shifted accumulation (the shape the
-// byte table must be written for), 0 where that variant does not apply (option vlad_shift off, another kernel forced, CW > 3).
-int fused3_shift_waves(int64_t D) {
-  if (option(OPT_VLAD_SHIFT) == 0) return 0;
-  const int ver = (int)option(OPT_VLAD_FUSED_V);
-  if (!(ver == 0 || ver >= 3)) return 0;
-  if (!(D == 384 || D == 768 || D == 1024 || D == 1536)) return 0;
-  const int nv = (int)(D / 128);
-  const int sw = (nv % 2 == 0 && ver != 3) ? 8 : 4;
-  return f3_cw((int)(D / sw)) <= 4 ? sw : 0;
-}
 
 bool fused_supported(int64_t D, int64_t K) {
   return K >= 1 && K <= 32 && (D == 384 || D == 768 || D == 1024 || D == 1536);

@@ -64,9 +64,6 @@ const char* anyloc_last_error(void);
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
- *   vlad_shift (1)                    fused VLAD: no per-token gather of the centre -- residuals are accumulated against a 7-bit copy of
- *                                     the centres held in LDS (one power-of-two step per lane) and the exact remainder n_k (c_k - c~_k) is
- *                                     folded in every 8 tiles; 0 = the centre's fp32 columns gathered from L2 per token (rounds 3-4)
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)

@@ -1,5 +1,4 @@
-"""rocprofv3 --pmc / --kernel-trace target: the fused VLAD launch (anyloc_vlad_hard) at 256 and at 61 images of 529 x 1536 tokens,
-K = 32, with the shifted accumulation (option vlad_shift = 1, default) and with the per-token centre gather (0)."""
+"""rocprofv3 --pmc / --kernel-trace target: the fused VLAD launch (anyloc_vlad_hard) at 256 and at 61 images of 529 x 1536 tokens, K = 32."""
 import os
 import sys
 
@@ -12,9 +11,7 @@ dev = "cuda"
 c = 0.8 * synth.clustered_tokens(1, 32, 1536, n_modes=32, seed=3, device=dev)[0]
 for n_img in (256, 61):
     toks = synth.clustered_tokens(n_img, 529, 1536, n_modes=32, seed=11, noise=0.6, device=dev)
-    for shift in (1, 0):
-        with ops.options(vlad_shift=shift):
-            for _ in range(4):
-                ops.vlad(toks, c)
+    for _ in range(4):
+        ops.vlad(toks, c)
     torch.cuda.synchronize()
 print("ok")

@@ -38,22 +38,20 @@ for n_img in (256, 1024):
             for _ in range(2):
                 ops.vlad(toks, c)
             v = kernel_us(lambda: ops.vlad(toks, c), "vlad_fused")
-            with ops.options(vlad_shift=1):
-                vs = kernel_us(lambda: ops.vlad(toks, c), "vlad_fused")
         flat = toks.reshape(-1, 1536)
         with ops.options(kmeans_max_chunks=n_img):
             for _ in range(2):
                 ops.kmeans_step(flat, c, "cosine", False)
             k = kernel_us(lambda: ops.kmeans_step(flat, c, "cosine", False), "kmeans_fused")
         tiles = (N + 15) // 16
-        rows.append((n_img, N, tiles, v, vs, k))
-        print(f"{n_img:5d} images x {N:5d} tokens ({tiles:4d} tiles per workgroup): VLAD gather {v:8.1f} us, VLAD shift {vs:8.1f} us, "
+        rows.append((n_img, N, tiles, v, k))
+        print(f"{n_img:5d} images x {N:5d} tokens ({tiles:4d} tiles per workgroup): VLAD mode {v:8.1f} us, "
               f"k-means mode ({n_img} chunks) {k:8.1f} us", flush=True)
 for n_img in (256, 1024):
     r = [x for x in rows if x[0] == n_img]
     if len(r) >= 2:
         (t0, t1) = (r[1], r[-1])
-        for name, i in (("VLAD gather", 3), ("VLAD shift", 4), ("k-means mode", 5)):
+        for name, i in (("VLAD mode", 3), ("k-means mode", 4)):
             slope = (t1[i] - t0[i]) / (t1[2] - t0[2])
             print(f"{n_img} images, {name}: {slope:.2f} us per tile, intercept {t0[i] - slope * t0[2]:.1f} us "
                   f"(from {t0[2]} and {t1[2]} tiles)")
