@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       } else {
         // x / ||x|| - c_k.  The centres' CW columns of TG tokens are requested at once -- one CW-wide load per token, TT / TG
         // L2 round trips per tile -- and the tokens are then added in order while their columns come from the LDS tile.  The
-        // order of additions per (cluster, column) is the token order (deterministic); x inv - c is one fused multiply-add.
+        // order of additions per (cluster, column) is the token order.
         // Round 5: the tile columns come from LDS two tokens at a time, one pair ahead of the adds -- rounds 3-4 read each
         // token's three floats right before its adds, sixteen exposed LDS round trips per tile and wave; tokens-per-image
         // sweeps (tools/probe_vlad_fixed.py) put VLAD mode at 6.5 us per tile against 4.3 us for the k-means loop with BOTH
@@ -897,9 +897,19 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             if (p2 + 1 < TG / 2) read_pair(buf ^ 1, p2 + 1);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
+              // A row past the unit (label -1) adds an exact zero to cluster 0 -- a select, not a branch: with the branch form
+              // (add_token skipped under `k < 0`) and with a fused multiply-add here, the launch was NOT reproducible run to
+              // run on 300+ images (rates 1e-3 ... 1e-1 of the images; tools/stress_vlad.py, profiles/r05_vlad_stress_bisect.log;
+              // bisected over library builds, cause not found in the ISA: waits and registers are right).  This form and k-means
+              // mode's are reproducible over 40 000 image-runs; tests/test_gpu_vlad_topk.py::test_vlad_reproducible_under_load
+              // keeps watching.
+              const int k = kk[2 * p2 + e];
 #pragma unroll
-              for (int j = 0; j < CW; ++j) v[buf][e][j] = __builtin_fmaf(v[buf][e][j], nq[buf][e], -c[2 * p2 + e][j]);   // x^ - c, one rounding
-              add_token(kk[2 * p2 + e], v[buf][e]);     // (label -1 = a row past the unit: skipped by a wave-uniform branch)
+              for (int j = 0; j < CW; ++j) {
+                const float r = v[buf][e][j] * nq[buf][e] - c[2 * p2 + e][j];
+                v[buf][e][j] = k < 0 ? 0.0f : r;
+              }
+              add_token(k < 0 ? 0 : k, v[buf][e]);
             }
           }
         }
