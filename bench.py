@@ -538,15 +538,18 @@ def main():
     # Socket power / shader clock: sampled over EXTRA, untimed steps identical to the timed ones, right after them -- the
     # sampler reads the GPU's own hwmon nodes (an SMU query each), so it never runs while `value` is being measured
     sampler, power_timed = None, None
-    if rank == 0 and args.power_steps > 0:
-        sampler = PowerSampler(dev.index or 0, period=args.power_period)
+    if args.power_steps > 0:                 # (every rank runs the steps -- a sharded step holds collectives; rank 0 samples)
+        if rank == 0:
+            sampler = PowerSampler(dev.index or 0, period=args.power_period)
         torch.cuda.synchronize()
-        sampler.resume()
+        if sampler is not None:
+            sampler.resume()
         t_p0 = time.perf_counter()
         for i in range(args.power_steps):
             step(warm + i)
         torch.cuda.synchronize()
         t_p1 = time.perf_counter()
+    if sampler is not None:
         sampler.pause()
         power_timed = sampler.window(t_p0, t_p1)
         power_timed["steps"] = args.power_steps
