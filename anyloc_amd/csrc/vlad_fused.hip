@@ -861,9 +861,9 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         // L2 round trips per tile -- and the tokens are then added in order while their columns come from the LDS tile.  The
         // order of additions per (cluster, column) is the token order.
         // Round 5: the tile columns come from LDS two tokens at a time, one pair ahead of the adds -- rounds 3-4 read each
-        // token's three floats right before its adds, sixteen exposed LDS round trips per tile and wave; tokens-per-image
-        // sweeps (tools/probe_vlad_fixed.py) put VLAD mode at 6.5 us per tile against 4.3 us for the k-means loop with BOTH
-        // structures tried, i.e. the difference was never the centre gather: the tile loop is bound by vector-instruction issue.
+        // token's three floats right before its adds, sixteen exposed LDS round trips per tile and wave.  Tokens-per-image
+        // sweeps (tools/probe_vlad_fixed.py) put VLAD mode at 6.2 - 6.3 us per tile against 5.2 us for the k-means loop; two
+        // structures WITHOUT this gather (8-bit / 7-bit centre tables) measured 6.7 and 7.4 us.
         // TG tokens per round (16 = the whole tile needs 16 CW registers more than this kernel has at D = 1536)
         constexpr int TG = 8;
 #pragma unroll 1

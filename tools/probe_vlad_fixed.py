@@ -1,7 +1,8 @@
 """Where does the fused VLAD launch spend the time that is not tiles?  256 images (one workgroup each, parts forced to 1) of
 N tokens x 1536, N = 16 ... 4232: kernel time against the number of 16-token tiles per workgroup -> slope (us per tile)
-and intercept (us per workgroup); the same rows through the k-means step with 256 chunks (the same kernel in k-means
-mode, no per-image epilogue) for comparison.
+and intercept (us per workgroup); the same rows through the k-means step (the same kernel in k-means mode, no per-image
+epilogue) for comparison -- a k-means chunk has at least 1 024 rows, so only N >= 1 058 gives it the same tiles per workgroup
+and its slope is taken from those points.
 
     python tools/probe_vlad_fixed.py > gpurun_out/vlad_fixed_cost.log"""
 import os
@@ -50,8 +51,11 @@ for n_img in (256, 1024):
 for n_img in (256, 1024):
     r = [x for x in rows if x[0] == n_img]
     if len(r) >= 2:
-        (t0, t1) = (r[1], r[-1])
-        for name, i in (("VLAD mode", 3), ("k-means mode", 4)):
+        for name, i, lo in (("VLAD mode", 3, 144), ("VLAD mode", 3, 1058), ("k-means mode", 4, 1058)):
+            pts = [x for x in r if x[1] >= lo]
+            if len(pts) < 2:
+                continue
+            (t0, t1) = (pts[0], pts[-1])
             slope = (t1[i] - t0[i]) / (t1[2] - t0[2])
             print(f"{n_img} images, {name}: {slope:.2f} us per tile, intercept {t0[i] - slope * t0[2]:.1f} us "
-                  f"(from {t0[2]} and {t1[2]} tiles)")
+                  f"(from {t0[2]} and {t1[2]} tiles per workgroup)")
