@@ -778,6 +778,12 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   const int QB = (qgroups + 3) / 4;                         // workgroups (of four 32-query groups) per image and head
   ANYLOC_CHECK_ARG((int64_t)QB * heads * batch < (1ll << 31), "attention_h3: grid too large");
   const dim3 grid((unsigned)((int64_t)QB * heads * batch));
+  // option attn_h3_qg = 2 (A/B): two waves of 64 queries per workgroup -- a wave's K / V fragments serve 64 queries (half the
+  // LDS reads, DMA issues and barriers per unit of work) at one wave per SIMD and workgroup
+  if (option(OPT_ATTN_H3_QG) == 2) {
+    hipLaunchKernelGGL((attention_h3_kernel<2, 2>), grid, dim3(128), lds, stream, planes, inv, T, heads, G, out2, out_inv, R, QB);
+    return launch_status("attention_h3_kernel<2,2>");
+  }
   hipLaunchKernelGGL((attention_h3_kernel<1, 4>), grid, dim3(256), lds, stream, planes, inv, T, heads, G, out2, out_inv, R, QB);
   return launch_status("attention_h3_kernel");
 }

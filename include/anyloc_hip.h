@@ -64,6 +64,8 @@ const char* anyloc_last_error(void);
  *   h3_fuse (1) x6_fuse (1)           activations stay in fp16 / bf16 planes between kernels
  *   h3_min_rows (0) x6_min_rows (1600) token rows below which a split-mode forward uses the fp32-MFMA kernels
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
+ *   attn_h3_qg (1)                    attention of the two-term fp16 forward: 1 = four waves of 32 queries per workgroup, 2 = two waves of
+ *                                     64 queries (A/B: measured slower, profiles/r05_attention_qg2.log)
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)
