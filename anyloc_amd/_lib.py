@@ -64,6 +64,8 @@ SIGNATURES = {
     "anyloc_resize_bicubic": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32p,
                                         C.c_void_p]),
     "anyloc_pool_tokens": (C.c_int, [c_f32p, C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    "anyloc_pca_gram_f64": (C.c_int, [c_f32p, c_i64, c_i64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "anyloc_pca_axes_f64": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "anyloc_x3_bytes": (C.c_size_t, [c_i64, c_i64]),
     "anyloc_split_x3": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
     "anyloc_gemm_nt_x6": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p]),
@@ -112,7 +114,7 @@ SIGNATURES = {
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),
 }
 
-ABI_VERSION = 6          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
+ABI_VERSION = 7          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
 
 _lib = None
 

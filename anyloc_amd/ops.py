@@ -336,6 +336,38 @@ def pool(tokens, method="average", gem_p=3.0):
     return out
 
 
+def pca_gram_f64(x, mean64, side):
+    """The symmetric matrix of the centred data in float64 (reference utilities.py:561-564, the SVD inside sklearn's
+    PCA): side 0 -> Xc Xc^T [n, n], side 1 -> Xc^T Xc [f, f]; Xc = x.double() - mean64, formed on the way into LDS."""
+    device = _lib.require_gpu()
+    x = _f32c(x, device)
+    n, f = x.shape
+    mean64 = mean64.to(device=device, dtype=torch.float64).contiguous()
+    if mean64.shape != (f,):
+        raise ValueError(f"mean of {tuple(mean64.shape)} for data of {tuple(x.shape)}")
+    m = n if side == 0 else f
+    out = torch.empty(m, m, dtype=torch.float64, device=device)
+    _lib.check(_lib.load().anyloc_pca_gram_f64(_lib.ptr(x), n, f, _lib.ptr(mean64), int(side), _lib.ptr(out),
+                                               _lib.stream_ptr()), "anyloc_pca_gram_f64")
+    return out
+
+
+def pca_axes_f64(vec, k, x, mean64):
+    """U^T Xc [k, f] in float64: U = the first k columns of ``vec`` [n, >= k] (float64, any strides -- torch.linalg.eigh
+    returns its eigenvectors column-major), Xc = x.double() - mean64."""
+    device = _lib.require_gpu()
+    x = _f32c(x, device)
+    n, f = x.shape
+    vec = vec.to(device=device, dtype=torch.float64)
+    if vec.dim() != 2 or vec.shape[0] != n or vec.shape[1] < k or min(vec.stride()) < 1:
+        raise ValueError(f"eigenvectors of {tuple(vec.shape)} (strides {vec.stride()}) for {n} samples, k = {k}")
+    mean64 = mean64.to(device=device, dtype=torch.float64).contiguous()
+    out = torch.empty(k, f, dtype=torch.float64, device=device)
+    _lib.check(_lib.load().anyloc_pca_axes_f64(_lib.ptr(vec), vec.stride(0), vec.stride(1), int(k), _lib.ptr(x), n, f, _lib.ptr(mean64),
+                                               _lib.ptr(out), _lib.stream_ptr()), "anyloc_pca_axes_f64")
+    return out
+
+
 def kmeans_step(x, centers, mode="cosine", want_labels=False):
     """One assign + accumulate pass: returns (sums [K,D], counts [K], labels|None)."""
     _need_cuda(x, centers)

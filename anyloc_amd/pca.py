@@ -8,10 +8,11 @@ Here the decomposition is reduced to GEMMs + one symmetric eigenproblem on the d
 run on the fp32 MFMA GEMM of the library (``anyloc_gemm_nt``):
 
 * fit:  centre on the device; the smaller of the Gram matrix  Xc Xc^T [n, n]  and the scatter matrix
-  Xc^T Xc [f, f]  is one GEMM (float64 library GEMM by default, see ``precise``); its symmetric
-  eigendecomposition (float64, ``torch.linalg.eigh`` -- a dense-solver library call, not a kernel of this
-  package) gives the singular values and one side of the SVD; for the Gram side the principal axes follow
-  from one more GEMM, V^T = diag(1/s) U^T Xc.
+  Xc^T Xc [f, f]  is one GEMM (in float64 on the double-precision matrix cores by default -- ``anyloc_pca_gram_f64``,
+  csrc/pca_f64.hip -- see ``precise``); its symmetric eigendecomposition (float64, ``torch.linalg.eigh`` -- a
+  dense-solver library call, the one step of the fit that is not a kernel of this package) gives the singular values
+  and one side of the SVD; for the Gram side the principal axes follow from one more GEMM,
+  V^T = diag(1/s) U^T Xc (``anyloc_pca_axes_f64``).
   Signs follow sklearn's ``svd_flip``: by default the rule of the sklearn installed next to this package (what the
   reference's own call would produce here): u-based (largest-magnitude entry of every U column positive) for the
   versions the reference pins, v-based from sklearn 1.5 on; ``sign_convention="u"`` / ``"v"`` force one.
@@ -66,8 +67,8 @@ class PCA:
         self.whiten = bool(whiten)
         # The Gram / scatter matrix squares the condition number: formed with fp32 sums, the axes whose variance is
         # below ~1e-6 x the largest are noise (measured on the MI355X: axis 64 of a 0.9^k spectrum off by 1e-3).
-        # `precise` (default) forms that one symmetric matrix, and the k x f back-projection, in float64 with
-        # torch.matmul -- a plain library GEMM -- which brings the fit to the accuracy of the reference's float32
+        # `precise` (default) forms that one symmetric matrix, and the k x f back-projection, in float64 on
+        # v_mfma_f64_16x16x4_f64 (csrc/pca_f64.hip), which brings the fit to the accuracy of the reference's float32
         # LAPACK SVD or better; precise=False keeps everything on the fp32 MFMA kernel (fine for leading axes).
         self.precise = bool(precise)
 
@@ -82,18 +83,22 @@ class PCA:
         if not 1 <= k <= min(n, f):
             raise ValueError(f"n_components={k} must be between 1 and min(n_samples, n_features)={min(n, f)} "
                              f"with svd_solver='full'")
-        mean64 = X.mean(dim=0, dtype=torch.float64)
+        mean64 = torch.zeros(f, dtype=torch.float64, device=device)
+        rows = max(1, (64 << 20) // (8 * f))                   # float64 column sums over row blocks: bounded temporaries
+        for r0 in range(0, n, rows):
+            mean64 += X[r0:r0 + rows].sum(dim=0, dtype=torch.float64)
+        mean64 /= n
         self.mean_ = mean64.to(torch.float32)
-        xc = X - self.mean_
-        # precise: centre, form the symmetric matrix and back-project in float64 (library GEMMs); the fp32 copy `xc` is
-        # then only used for the sign rule
-        xw = (X.double() - mean64) if self.precise else xc
+        # precise: the symmetric matrix and the back-projection are formed in float64 by the library's own kernel on the
+        # double-precision matrix cores (csrc/pca_f64.hip), which centres the fp32 data with the float64 mean on the way into
+        # LDS -- neither a float64 nor a centred fp32 copy of X is made (10 000 x 49 152: 3.9 + 2.0 GB)
+        xc = None if self.precise else X - self.mean_
         if n <= f:
-            gram = xw @ xw.t() if self.precise else _gemm(xc, xc)            # [n, n] = Xc Xc^T
+            gram = ops.pca_gram_f64(X, mean64, 0) if self.precise else _gemm(xc, xc)         # [n, n] = Xc Xc^T
             lam, vec = self._eigh_desc(gram)
             s = lam.clamp_min(0).sqrt()
             if self.precise:
-                axes = (vec[:, :k].t() @ xw) / s[:k].clamp_min(1e-300)[:, None]               # [k, f] = U^T Xc / s
+                axes = ops.pca_axes_f64(vec, k, X, mean64) / s[:k].clamp_min(1e-300)[:, None]  # [k, f] = U^T Xc / s
                 axes = axes.to(torch.float32)
             else:
                 u_t = vec[:, :k].t().to(torch.float32).contiguous()            # [k, n]
@@ -101,14 +106,13 @@ class PCA:
                 axes = axes / s[:k].to(torch.float32).clamp_min(torch.finfo(torch.float32).tiny)[:, None]
         else:
             if self.precise:
-                scatter = xw.t() @ xw                                      # [f, f] = Xc^T Xc
+                scatter = ops.pca_gram_f64(X, mean64, 1)                   # [f, f] = Xc^T Xc
             else:
                 xt = xc.t().contiguous()
                 scatter = _gemm(xt, xt)
             lam, vec = self._eigh_desc(scatter)
             s = lam.clamp_min(0).sqrt()
             axes = vec[:, :k].t().to(torch.float32).contiguous()
-        del xw
         # axes of (numerically) zero variance -- rank-deficient data, e.g. n_components == n_samples after centring -- carry
         # no direction: U^T Xc / s would divide noise by ~0.  They are set to zero (every projection onto them is 0,
         # also under whitening) instead of being blown up to inf / NaN.
@@ -128,7 +132,10 @@ class PCA:
             piv = axes.abs().argmax(dim=1)
             sign = torch.sign(axes[torch.arange(k, device=device), piv])
         else:
-            u = _gemm(xc, axes.contiguous())                               # [n, k] = U diag(s): same signs as U
+            if xc is None:                                                 # Xc V = X V - mean V: the mean as a bias row
+                u = _gemm(X, axes.contiguous(), -(axes.double() * mean64).sum(dim=1).to(torch.float32))
+            else:
+                u = _gemm(xc, axes.contiguous())                           # [n, k] = U diag(s): same signs as U
             sign = torch.sign(u[u.abs().argmax(dim=0), torch.arange(k, device=device)])
         sign = torch.where(sign == 0, torch.ones_like(sign), sign)
         self.components_ = (axes * sign[:, None]).contiguous()
@@ -154,7 +161,7 @@ class PCA:
                 scale = self.explained_variance_.sqrt().clamp_min(torch.finfo(torch.float32).eps)
                 w = w / scale[:, None]                                      # (dead axes are zero rows: 0 / eps = 0)
             w = w.contiguous()
-            self._w = (w, -(w.double() @ self.mean_.double()).to(torch.float32))
+            self._w = (w, -(w.double() * self.mean_.double()).sum(dim=1).to(torch.float32))
         return self._w
 
     def transform(self, X):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 6
+#define ANYLOC_ABI_VERSION 7
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -171,6 +171,23 @@ int anyloc_gemm_nt_h3(const void* a2, const float* a_inv, const void* w2,
 int anyloc_pool_tokens(const float* tokens, const int64_t* offsets, int64_t n_img,
                        int64_t n_tok, int64_t D, int mode, float p, float* out,
                        void* stream);
+
+/* ------------------------------------------------------------ PCA fit ----
+ * reference utilities.py:522-586 (called at scripts/dino_v2_vlad.py:357-369): sklearn PCA(lower_dim,
+ * svd_solver='full') = a LAPACK SVD of the centred [n, f] descriptor matrix.  The host (anyloc_amd/pca.py)
+ * reduces it to the smaller symmetric matrix of the centred data, a symmetric eigenproblem, and -- from
+ * the Gram side -- one back-projection; both products are formed in FLOAT64 on v_mfma_f64_16x16x4_f64
+ * (they square the condition number), reading the fp32 data where it lies and centring it on the way:
+ *   Xc = (double) X[n, f] - mean[f]   (mean: float64, NULL = no centring)
+ *   anyloc_pca_gram_f64  side 0: out[n, n] = Xc Xc^T (Gram);  side 1: out[f, f] = Xc^T Xc (scatter)
+ *   anyloc_pca_axes_f64  out[k, f] = U^T Xc,  U[c, i] = vec[c * sample_stride + i * axis_stride] (float64): component
+ *                        c (a sample) of eigenvector i of the Gram matrix, in either storage order
+ * ABI 7. */
+int anyloc_pca_gram_f64(const float* X, int64_t n, int64_t f, const double* mean, int side,
+                        double* out, void* stream);
+int anyloc_pca_axes_f64(const double* vec, int64_t sample_stride, int64_t axis_stride, int64_t k,
+                        const float* X, int64_t n, int64_t f, const double* mean, double* out,
+                        void* stream);
 
 /* ------------------------------------------------------------- matmul ----
  * C[M,N] = A[M,K] * W[N,K]^T (+ bias[N] when bias != NULL): the exact-fp32 MFMA GEMM

@@ -109,6 +109,13 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "pool", pool)
     monkeypatch.setattr(ops, "gemm_nt", lambda a, w, bias=None: a.float() @ w.float().t() + (0 if bias is None else bias))
     monkeypatch.setattr(ops, "_f32c", lambda t, device=None: t.detach().to("cpu", torch.float32).contiguous())
+
+    def pca_gram_f64(x, mean64, side):                       # csrc/pca_f64.hip: the fit's symmetric matrix in float64
+        xw = x.double() - mean64.double()
+        return xw @ xw.t() if side == 0 else xw.t() @ xw
+
+    monkeypatch.setattr(ops, "pca_gram_f64", pca_gram_f64)
+    monkeypatch.setattr(ops, "pca_axes_f64", lambda vec, k, x, mean64: vec[:, :k].double().t() @ (x.double() - mean64.double()))
     monkeypatch.setattr(ops, "vlad", vlad)
     monkeypatch.setattr(ops, "vlad_auto_parts", lambda n_img, n_tok, D, K: 1)
     monkeypatch.setattr(ops, "kmeans_step", kmeans_step)

@@ -419,6 +419,62 @@ static void case_vit(hipStream_t stream, int ffn_kind, const char* name) {
 }
 
 /* ---------------------------------------------------------------- errors */
+/* ------------------------------------------------------------------- PCA fit products (float64 matrix cores) */
+static void case_pca(hipStream_t stream, int64_t n, int64_t f, int64_t k, const char* name) {
+  float* x = (float*)malloc(sizeof(float) * (size_t)(n * f));
+  double* mean = (double*)calloc((size_t)f, sizeof(double));
+  double* vec = (double*)malloc(sizeof(double) * (size_t)(n * n));
+  for (int64_t i = 0; i < n * f; ++i) x[i] = 25.0f + 2.0f * rng_normal();      /* a common offset the centring has to remove */
+  for (int64_t i = 0; i < n; ++i) for (int64_t j = 0; j < f; ++j) mean[j] += (double)x[i * f + j] / (double)n;
+  for (int64_t i = 0; i < n * n; ++i) vec[i] = rng_normal();
+  float* d_x = (float*)dev_from(x, sizeof(float) * (size_t)(n * f));
+  double* d_mean = (double*)dev_from(mean, sizeof(double) * (size_t)f);
+  double* d_vec = (double*)dev_from(vec, sizeof(double) * (size_t)(n * n));
+  double* d_gram = (double*)dev_alloc(sizeof(double) * (size_t)(n * n));
+  double* d_scat = (double*)dev_alloc(sizeof(double) * (size_t)(f * f));
+  double* d_axes = (double*)dev_alloc(sizeof(double) * (size_t)(k * f));
+  ANYLOC_OK_OR_FAIL(anyloc_pca_gram_f64(d_x, n, f, d_mean, 0, d_gram, stream));
+  ANYLOC_OK_OR_FAIL(anyloc_pca_gram_f64(d_x, n, f, d_mean, 1, d_scat, stream));
+  ANYLOC_OK_OR_FAIL(anyloc_pca_axes_f64(d_vec, n, 1, k, d_x, n, f, d_mean, d_axes, stream));
+  double* gram = (double*)malloc(sizeof(double) * (size_t)(n * n));
+  double* scat = (double*)malloc(sizeof(double) * (size_t)(f * f));
+  double* axes = (double*)malloc(sizeof(double) * (size_t)(k * f));
+  HIP_OK(hipMemcpyAsync(gram, d_gram, sizeof(double) * (size_t)(n * n), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(scat, d_scat, sizeof(double) * (size_t)(f * f), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(axes, d_axes, sizeof(double) * (size_t)(k * f), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  double worst = 0.0, top = 0.0;                               /* the same sums in long double on the host */
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < n; ++j) {
+      long double acc = 0.0L;
+      for (int64_t c = 0; c < f; ++c) acc += ((long double)x[i * f + c] - mean[c]) * ((long double)x[j * f + c] - mean[c]);
+      double e = fabs(gram[i * n + j] - (double)acc);
+      if (e > worst) worst = e;
+      if (fabs((double)acc) > top) top = fabs((double)acc);
+    }
+  for (int64_t i = 0; i < f; ++i)
+    for (int64_t j = 0; j < f; ++j) {
+      long double acc = 0.0L;
+      for (int64_t c = 0; c < n; ++c) acc += ((long double)x[c * f + i] - mean[i]) * ((long double)x[c * f + j] - mean[j]);
+      double e = fabs(scat[i * f + j] - (double)acc);
+      if (e > worst) worst = e;
+    }
+  for (int64_t i = 0; i < k; ++i)
+    for (int64_t j = 0; j < f; ++j) {
+      long double acc = 0.0L;
+      for (int64_t c = 0; c < n; ++c) acc += (long double)vec[c * n + i] * ((long double)x[c * f + j] - mean[j]);
+      double e = fabs(axes[i * f + j] - (double)acc);
+      if (e > worst) worst = e;
+    }
+  int ok = worst <= 1e-12 * top;
+  char detail[200];
+  snprintf(detail, sizeof detail, "%lld x %lld, k=%lld: Gram, scatter, U^T Xc vs long double: max |err| %.2e (largest entry %.2e)",
+           (long long)n, (long long)f, (long long)k, worst, top);
+  report(name, ok, detail);
+  hipFree(d_x); hipFree(d_mean); hipFree(d_vec); hipFree(d_gram); hipFree(d_scat); hipFree(d_axes);
+  free(x); free(mean); free(vec); free(gram); free(scat); free(axes);
+}
+
 static void case_errors(hipStream_t stream) {
   float* d = (float*)dev_alloc(sizeof(float) * 64 * 8);
   int64_t* di = (int64_t*)dev_alloc(sizeof(int64_t) * 64);
@@ -473,6 +529,7 @@ int main(void) {
   case_topk(stream, 3, 12, 64, 20, 0, 0, "topk k > ndb padding");
   case_vit(stream, 0, "vit 3 blocks D=384 mlp");
   case_vit(stream, 1, "vit 3 blocks D=384 swiglu");
+  case_pca(stream, 70, 131, 9, "pca fit products 70 x 131 (float64 matrix cores)");
   case_errors(stream);
 
   HIP_OK(hipStreamDestroy(stream));

@@ -123,3 +123,44 @@ def test_pca_u_based_sign_rule_and_rank_deficient_axes():
     assert bool(torch.isfinite(z).all()) and bool(torch.isfinite(full.components_).all())
     assert float(z[:, -1].abs().max()) == 0.0 and float(full.components_[-1].abs().max()) == 0.0
     assert float((z[:, :39].var(dim=0, unbiased=True) - 1.0).abs().max()) < 1e-2      # whitened: unit variance
+
+
+@pytest.mark.parametrize("n,f", [(70, 130), (130, 70), (64, 64), (1, 5), (257, 1031), (260, 1032), (1032, 132)])
+def test_pca_f64_products_vs_float64(n, f):
+    """csrc/pca_f64.hip (the float64 matrix-core products of the fit) against the same products in torch float64 of the
+    same centred data: Gram, scatter (both mirrored from the upper tiles) and the back-projection, ragged shapes."""
+    from anyloc_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + f)
+    x = (torch.randn(n, f, generator=g) * 3 + 40.0).to(DEV)            # a large common offset: centring must be in float64
+    mean = x.mean(dim=0, dtype=torch.float64)
+    xw = x.double() - mean
+    for side, want in ((0, xw @ xw.t()), (1, xw.t() @ xw)):
+        got = ops.pca_gram_f64(x, mean, side)
+        assert got.dtype == torch.float64 and got.shape == want.shape
+        assert torch.equal(got, got.t())                                  # mirrored, not recomputed
+        assert float((got - want).abs().max()) <= 1e-13 * float(want.abs().max()) * max(n, f) ** 0.5
+    k = min(n, 7)
+    vec = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))[0].to(DEV)
+    got = ops.pca_axes_f64(vec, k, x, mean)
+    want = vec[:, :k].t() @ xw
+    assert got.shape == (k, f) and float((got - want).abs().max()) <= 1e-13 * float(want.abs().max() + 1) * n ** 0.5
+    # eigenvectors are read where they lie: a view of the first k columns, and column-major storage (what eigh returns)
+    assert torch.equal(ops.pca_axes_f64(vec[:, :k], k, x, mean), got)
+    assert torch.equal(ops.pca_axes_f64(vec.t().contiguous().t(), k, x, mean), got)
+    with pytest.raises(ValueError):
+        ops.pca_gram_f64(x, mean[:-1], 0) if f > 1 else ops.pca_axes_f64(vec[:-1], k, x, mean)
+
+
+def test_pca_fit_makes_no_float64_copy_of_the_data():
+    """The precise fit reads the fp32 descriptors where they lie: no float64 copy (2 x the data, what the torch.matmul
+    route needed) and no centred fp32 copy (1 x), at a shape where the symmetric matrix is small."""
+    from anyloc_amd import pca
+    n, f = 1024, 49152
+    x = decaying(n, f, seed=5, rank=64).to(DEV)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    pca.PCA(16).fit(x)
+    torch.cuda.synchronize()
+    extra = torch.cuda.max_memory_allocated() - base
+    assert extra < 0.5 * x.numel() * 4, (extra, x.numel() * 4)
