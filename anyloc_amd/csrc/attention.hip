@@ -463,18 +463,22 @@ __device__ __forceinline__ float ah_pow2_recip(float inv) { return __uint_as_flo
 
 constexpr int AH_STAGE = 16384;       // K hi | K lo | V hi | V lo, 4 KiB each
 
-// QG = 32-query groups per wave (1 or 2), NW = waves per workgroup; a workgroup always covers QG * NW = 4 consecutive
-// groups (128 queries) of one (image, head).  QG = 2: a wave's K / V fragments serve 64 queries, i.e. half the LDS reads,
-// DMA issues and barriers per unit of work, at 2 waves per SIMD.
-template <int QG, int NW>
+// QG = 32-query groups per wave (1 or 2), NW = waves per workgroup, KS = key splits: the waves of a workgroup are NW / KS
+// query waves x KS key waves; a workgroup covers QG * NW / KS consecutive 32-query groups of one (image, head).
+// QG = 2: a wave's K / V fragments serve 64 queries, i.e. half the LDS reads, DMA issues and barriers per unit of work.
+// KS = 2 (few images per call): every step stages KS consecutive key tiles, key wave kw takes tile KS * step + kw, and the
+// key waves' partial (O, m, l) meet in LDS at the end in split order -- twice the workgroups and half the serial chain of
+// key tiles per wave: one ViT-g image is 24 heads x 5 workgroups x 17 tiles with KS = 1, 24 x 9 x 9 with KS = 2.
+template <int QG, int NW, int KS = 1>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned char* __restrict__ planes,
                                                                   const float* __restrict__ inv, int T, int heads, int64_t G,
                                                                   unsigned char* __restrict__ out2, float* __restrict__ out_inv,
                                                                   int64_t R, int QB) {
-  static_assert(QG * NW == 4 && (QG == 1 || QG == 2), "a workgroup covers four 32-query groups");
+  static_assert((QG == 1 || QG == 2) && (KS == 1 || KS == 2) && NW % KS == 0 && 16 * KS % NW == 0, "unsupported shape");
   constexpr int NT = 64 * NW;
-  constexpr int PIECES = 16 / NW;       // 1-KiB DMA pieces per wave and key tile
-  extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];   // 2 stages + 16 bytes for the block reduction
+  constexpr int QW = NW / KS;           // query waves
+  constexpr int PIECES = 16 * KS / NW;  // 1-KiB DMA pieces per wave and step
+  extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];   // 2 x KS stages + 16 bytes for the block reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware: the QB workgroups of one (image, head) -- which stream the same K / V tiles, 271 KB at T = 530 -- get
   // consecutive ids on ONE XCD, so the tiles come from HBM / the fabric into that XCD's L2 once instead of once per XCD
@@ -484,7 +488,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   const int64_t r0 = b * T, r1 = r0 + T;
   const int64_t g_first = r0 >> 5, g_last = (r1 - 1) >> 5;
   const int ng = (int)(g_last - g_first + 1);
-  const int64_t gq0 = g_first + qb * 4 + wave * QG;
+  const int qw = wave % QW, kw = wave / QW;
+  const int64_t gq0 = g_first + (qb * QW + qw) * QG;
   const bool wave_active = gq0 <= g_last;
   const int ql = lane & 31, h2 = lane >> 5;
   const int64_t tile_bytes = 8192;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
     fm = fmaxf(fm, inv[((int64_t)2 * heads + hh) * G + g_first + gg]);
   }
   fm = wave_max(fm);
-  float* red = reinterpret_cast<float*>(ah_smem + 2 * AH_STAGE);
+  float* red = reinterpret_cast<float*>(ah_smem + 2 * KS * AH_STAGE);
   if (lane == 0) red[wave] = fm;
   __syncthreads();
   fm = red[0];
@@ -525,15 +530,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
       const_cast<unsigned char*>(planes + part_bytes), 0, (int)part_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(planes + 2 * part_bytes), 0, (int)part_bytes, 0x00020000);
-  auto issue = [&](int t, int stage) {
-    const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
+  auto issue = [&](int step, int stage) {                 // the KS key tiles of a step, 16 pieces each
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const int piece = i * NW + wave;                     // 0..7: K planes, 8..15: V planes
-      unsigned char* st = ah_smem + stage * AH_STAGE + piece * 1024;
-      const unsigned voff = (unsigned)((piece & 7) * 1024 + lane * 16);
-      if (i * NW < 8) dma16_to_lds(k_rsrc, st, voff, soff);
-      else dma16_to_lds(v_rsrc, st, voff, soff);
+      const int sub = (i * NW) / 16;                       // which tile of the step (compile-time: wave < NW <= 16)
+      const int piece = (i * NW) % 16 + wave;              // 0..7: K planes, 8..15: V planes
+      const int t = step * KS + sub;
+      if (t < ng) {                                        // wave-uniform
+        const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
+        unsigned char* st = ah_smem + (stage * KS + sub) * AH_STAGE + piece * 1024;
+        const unsigned voff = (unsigned)((piece & 7) * 1024 + lane * 16);
+        if ((i * NW) % 16 < 8) dma16_to_lds(k_rsrc, st, voff, soff);
+        else dma16_to_lds(v_rsrc, st, voff, soff);
+      }
     }
   };
 
@@ -562,16 +571,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   // as the ds_read's immediate offset -- the tile body is instantiated per stage so that the stage is a compile-time constant
   unsigned k_lane[4], v_lane[2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) k_lane[s] = (unsigned)(ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
+  for (int s = 0; s < 4; ++s) k_lane[s] = (unsigned)(kw * AH_STAGE + ql * 128 + (((2 * s + h2) ^ ((ql >> 1) & 7)) << 4));
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) v_lane[s2] = (unsigned)(ql * 64 + (((h2 * 2 + s2) ^ ((ql >> 2) & 3)) << 4));
+  for (int s2 = 0; s2 < 2; ++s2) v_lane[s2] = (unsigned)(kw * AH_STAGE + ql * 64 + (((h2 * 2 + s2) ^ ((ql >> 2) & 3)) << 4));
 
-  auto tile = [&](const int t, auto stagec) {
+  const int nsteps = (ng + KS - 1) / KS;
+  bool first = true;                    // this wave has not processed a tile yet
+  auto tile = [&](const int step, auto stagec) {
     constexpr int stage = decltype(stagec)::value;
-    if (t + 1 < ng) issue(t + 1, stage ^ 1);
-    if (wave_active) {
+    if (step + 1 < nsteps) issue(step + 1, stage ^ 1);
+    const int t = step * KS + kw;
+    if (wave_active && t < ng) {
       const int64_t gk = g_first + t;
-      const unsigned char* Ks = ah_smem + stage * AH_STAGE;
+      const unsigned char* Ks = ah_smem + stage * KS * AH_STAGE;
       const unsigned char* Vs = Ks + 8192;
       float fk, fv;
       if (ng <= 64) {                   // wave-uniform lane index: v_readlane, no memory access in the loop
@@ -612,8 +624,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
         }
       const bool edge = gk == g_first || gk == g_last;      // wave-uniform: only the image's first / last key group
       // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
-      const float vratio = t == 0 ? 1.0f : fv_run * ah_pow2_recip(fv);
+      const float vratio = first ? 1.0f : fv_run * ah_pow2_recip(fv);
       fv_run = fv;
+      first = false;
 #pragma unroll
       for (int qg = 0; qg < QG; ++qg) {
         // scores in the exp2 domain: t = S_true * log2(e) = sacc * c, c = fq * fk * log2(e) / 8 > 0 -- the maximum is
@@ -672,9 +685,48 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
     }
     __syncthreads();                    // everyone is done with this stage; the next tile's DMA has landed
   };
-  for (int t = 0; t < ng; t += 2) {
-    tile(t, std::integral_constant<int, 0>{});
-    if (t + 1 < ng) tile(t + 1, std::integral_constant<int, 1>{});
+  for (int s = 0; s < nsteps; s += 2) {
+    tile(s, std::integral_constant<int, 0>{});
+    if (s + 1 < nsteps) tile(s + 1, std::integral_constant<int, 1>{});
+  }
+
+  if constexpr (KS > 1) {
+    // the key waves' partial sums meet in LDS (the stages are free after the loop's last barrier), in units that do not
+    // depend on a wave's own tiles: O * fv_run (a power of two), m and l as they are; key wave 0 adds them in split order
+    float* mb = reinterpret_cast<float*>(ah_smem);          // [(KS - 1) * QW * QG][34][64] floats: 17 KiB at KS = 2, QW = 2
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[qg][0][r] *= fv_run; oacc[qg][1][r] *= fv_run; }
+    fv_run = 1.0f;
+    if (kw > 0) {
+#pragma unroll
+      for (int qg = 0; qg < QG; ++qg) {
+        float* dst = mb + (((kw - 1) * QW + qw) * QG + qg) * 34 * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dst[r * 64] = oacc[qg][0][r]; dst[(16 + r) * 64] = oacc[qg][1][r]; }
+        dst[32 * 64] = m_run[qg];
+        dst[33 * 64] = l_run[qg];
+      }
+    }
+    __syncthreads();
+    if (kw > 0) return;
+#pragma unroll
+    for (int k = 1; k < KS; ++k)
+#pragma unroll
+      for (int qg = 0; qg < QG; ++qg) {
+        const float* src = mb + (((k - 1) * QW + qw) * QG + qg) * 34 * 64 + lane;
+        const float m_o = src[32 * 64], l_o = src[33 * 64];
+        const float m_new = fmaxf(m_run[qg], m_o);            // key wave 0 always owns tile 0: m_run is finite
+        const float a0 = __builtin_amdgcn_exp2f(m_run[qg] - m_new), a1 = __builtin_amdgcn_exp2f(m_o - m_new);   // exp2(-inf) = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          oacc[qg][0][r] = oacc[qg][0][r] * a0 + src[r * 64] * a1;
+          oacc[qg][1][r] = oacc[qg][1][r] * a0 + src[(16 + r) * 64] * a1;
+        }
+        l_run[qg] = l_run[qg] * a0 + l_o * a1;
+        m_run[qg] = m_new;
+      }
   }
 
   // oacc[db][r] = O[q][db*32 + (r&3) + 8*(r>>2) + 4*h2] * l_run / fv_run (in P * 2^14 units, which cancel against l_run)
@@ -770,11 +822,27 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   ProfScope prof("attention", stream, flops, 8.0 * batch * T * D * 2);
   const int qgroups = (T + 31) / 32 + 1;                    // an image intersects at most this many 32-row groups
   const size_t lds = 2 * AH_STAGE + 64;
-  // four waves of 32 queries per workgroup.  Measured and removed: two waves of 64 queries (12.7 vs 13.7 ms per step at
-  // B=61), a software-pipelined loop with a 3-stage ring (15.0 ms), and (round 3) all K fragments of a tile read first with
+  // four waves of 32 queries per workgroup.  Measured: two waves of 64 queries (13.9 against 13.1 ms per step at B = 61,
+  // 34 against 25 us per launch at B = 1: kept as option attn_h3_qg = 2, profiles/r05_attention_qg2.log); measured and
+  // removed: a software-pipelined loop with a 3-stage ring (15.0 ms), and (round 3) all K fragments of a tile read first with
   // the twelve score MFMAs issued back to back (13.2 vs 13.2 ms) and the V fragments read per 32-column half (126 instead of
   // 152 VGPRs: four waves per SIMD; 13.4 vs 13.5 ms): neither the dependent-chain gaps nor the occupancy is what holds this
   // kernel at 40 % matrix-core utilisation -- DESIGN.md 4.2b
+  // few images per call: two query waves x two key waves per workgroup (KS = 2) -- twice the workgroups, half the serial
+  // chain of key tiles per wave -- as long as all of them are resident at once (two per CU: 64 KiB of LDS each);
+  // option attn_h3_ks: 0 = this rule, 1 / 2 force.  One ViT-g image (322 x 322): 27.7 -> 20.8 us per launch, two images 31.8 -> 26.3;
+  // three and more (648+ workgroups) lose 3 - 12 us, as does the same split with 64-query waves (profiles/r05_attention_ks.log)
+  const int QB2 = (qgroups + 1) / 2;
+  const int64_t ks_opt = option(OPT_ATTN_H3_KS);
+  if (ks_opt == 2 || (ks_opt == 0 && (int64_t)QB2 * heads * batch <= 512)) {
+    const dim3 grid2((unsigned)((int64_t)QB2 * heads * batch));
+    const size_t lds2 = 4 * AH_STAGE + 64;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<1, 4, 2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    ANYLOC_CHECK_ARG(attr == hipSuccess, "attention_h3: cannot reserve %zu bytes of LDS", lds2);
+    hipLaunchKernelGGL((attention_h3_kernel<1, 4, 2>), grid2, dim3(256), lds2, stream, planes, inv, T, heads, G, out2, out_inv, R, QB2);
+    return launch_status("attention_h3_kernel<1,4,2>");
+  }
   const int QB = (qgroups + 3) / 4;                         // workgroups (of four 32-query groups) per image and head
   ANYLOC_CHECK_ARG((int64_t)QB * heads * batch < (1ll << 31), "attention_h3: grid too large");
   const dim3 grid((unsigned)((int64_t)QB * heads * batch));

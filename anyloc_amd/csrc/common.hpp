@@ -93,6 +93,7 @@ enum Option {
   OPT_TOPK_FEWQ_QDMA,    // few-query scores on fp16 planes: 1 = queries pre-split once, DMA'd into LDS per slab; 0 = split per slab
   OPT_H3S_W12_TALL,      // small-M plan of the w12 / fc1 GEMM of one image: 1 = 192 x 128 tiles (one workgroup per CU), 0 = 128 x 128
   OPT_ATTN_H3_QG,        // attention_h3: 32-query groups per wave, 1 (four waves of 32 queries, default) or 2 (two waves of 64: A/B)
+  OPT_ATTN_H3_KS,        // attention_h3: key splits across the waves of a workgroup, 0 = by grid size (2 when all workgroups are resident), 1, 2
   OPT_COUNT
 };
 int64_t option(Option o);

@@ -66,6 +66,8 @@ const char* anyloc_last_error(void);
  *   attn_cfg (0) attn_x6 (-1)         anyloc_attention: kernel variant; split-bf16 products (1 always, 0 never, -1 caller)
  *   attn_h3_qg (1)                    attention of the two-term fp16 forward: 1 = four waves of 32 queries per workgroup, 2 = two waves of
  *                                     64 queries (A/B: measured slower, profiles/r05_attention_qg2.log)
+ *   attn_h3_ks (0)                    the same kernel's key splits: 2 = two query waves x two key waves per workgroup (half the serial
+ *                                     chain of key tiles; partial sums meet in LDS), 1 = none, 0 = 2 when all workgroups are resident
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
  *   kmeans_max_chunks (0 = two per CU)

@@ -91,14 +91,15 @@ def test_attention(dev, B, T, heads, kernel, monkeypatch):
     assert _rel(out, ref) < 5e-6
 
 
-@pytest.mark.parametrize("qg", [1, 2])
-@pytest.mark.parametrize("B,T,heads", [(2, 257, 6), (1, 530, 24), (3, 33, 2), (1, 128, 1), (2, 1370, 2), (5, 530, 4)])
-def test_attention_h3(dev, B, T, heads, qg):
+@pytest.mark.parametrize("qg,ks", [(1, 1), (2, 1), (1, 2)], ids=["4x32q", "2x64q", "2x32q-x-2keys"])
+@pytest.mark.parametrize("B,T,heads", [(2, 257, 6), (1, 530, 24), (3, 33, 2), (1, 128, 1), (2, 1370, 2), (5, 530, 4), (1, 20, 3)])
+def test_attention_h3(dev, B, T, heads, qg, ks):
     """The attention kernel of the two-term fp16 forward (anyloc_attention_h3: per-(head, 32-row group) scaled fp16
     tiles, three matrix-core products per contraction, output written as the h2 image of the projection GEMM)
     against float64.  Tokens of very different magnitude share 32-row groups and images share groups (T % 32 != 0)."""
     from anyloc_amd import ops
     ops.set_option("attn_h3_qg", qg)                      # 2 = the two-waves-of-64-queries workgroup shape (A/B variant)
+    ops.set_option("attn_h3_ks", ks)                      # 2 = two query waves x two key waves (the shape of few-image calls)
     D = heads * 64
     g = torch.Generator().manual_seed(B * T + heads)
     qkv = torch.randn(B, T, 3 * D, generator=g) * 1.5

@@ -63,14 +63,16 @@ def _spiky_qkv(B, T, heads, seed):
 LONG_T = [(1, 1531, 24), (3, 1531, 2), (2, 2395, 3), (1, 5330, 2), (3, 5330, 1), (2, 2047, 2), (2, 2049, 1)]
 
 
+@pytest.mark.parametrize("ks", [1, 2], ids=["keys-unsplit", "keys-split-2"])
 @pytest.mark.parametrize("B,T,heads", LONG_T)
-def test_attention_h3_long_sequences(B, T, heads):
+def test_attention_h3_long_sequences(B, T, heads, ks):
     """``anyloc_attention_h3`` (the default forward's attention) at the script / VPAir / demo-cap lengths and on both
     sides of the 64-key-group boundary (T = 2047: image 0 lies on 64 global 32-row groups -- scales in a lane register --
     and image 1, starting inside group 63, on 65 -- scales from memory -- in ONE launch; 2049: always 65), images sharing
     32-row groups (T % 32 != 0), against float64."""
     from anyloc_amd import _lib, ops
     _lib.load()
+    ops.set_option("attn_h3_ks", ks)                      # both workgroup shapes (the library picks by grid size)
     D = heads * 64
     qkv = _spiky_qkv(B, T, heads, B * T + heads)
     img, inv = ops.attention_h3(qkv.to(DEV), heads)
