@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   const int64_t r0 = b * T, r1 = r0 + T;
   const int64_t g_first = r0 >> 5, g_last = (r1 - 1) >> 5;
   const int ng = (int)(g_last - g_first + 1);
-  const int qw = wave % QW, kw = wave / QW;
+  const int qw = KS == 1 ? wave : wave % QW, kw = KS == 1 ? 0 : wave / QW;   // (KS = 1 compiles to the unsplit kernel)
   const int64_t gq0 = g_first + (qb * QW + qw) * QG;
   const bool wave_active = gq0 <= g_last;
   const int ql = lane & 31, h2 = lane >> 5;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
       const int sub = (i * NW) / 16;                       // which tile of the step (compile-time: wave < NW <= 16)
       const int piece = (i * NW) % 16 + wave;              // 0..7: K planes, 8..15: V planes
       const int t = step * KS + sub;
-      if (t < ng) {                                        // wave-uniform
+      if (KS == 1 || t < ng) {                             // wave-uniform (KS = 1: the caller only asks for tiles that exist)
         const unsigned soff = (unsigned)((((int64_t)h) * G + g_first + t) * tile_bytes);
         unsigned char* st = ah_smem + (stage * KS + sub) * AH_STAGE + piece * 1024;
         const unsigned voff = (unsigned)((piece & 7) * 1024 + lane * 16);
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
     constexpr int stage = decltype(stagec)::value;
     if (step + 1 < nsteps) issue(step + 1, stage ^ 1);
     const int t = step * KS + kw;
-    if (wave_active && t < ng) {
+    if (wave_active && (KS == 1 || t < ng)) {
       const int64_t gk = g_first + t;
       const unsigned char* Ks = ah_smem + stage * KS * AH_STAGE;
       const unsigned char* Vs = Ks + 8192;
@@ -624,9 +624,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
         }
       const bool edge = gk == g_first || gk == g_last;      // wave-uniform: only the image's first / last key group
       // O is kept in units of the current V tile's scale: moving to a tile with another scale is a power-of-two factor
-      const float vratio = first ? 1.0f : fv_run * ah_pow2_recip(fv);
+      const float vratio = (KS == 1 ? t == 0 : first) ? 1.0f : fv_run * ah_pow2_recip(fv);
       fv_run = fv;
-      first = false;
+      if (KS > 1) first = false;
 #pragma unroll
       for (int qg = 0; qg < QG; ++qg) {
         // scores in the exp2 domain: t = S_true * log2(e) = sacc * c, c = fq * fk * log2(e) / 8 > 0 -- the maximum is
