@@ -494,20 +494,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   const int ql = lane & 31, h2 = lane >> 5;
   const int64_t tile_bytes = 8192;
 
-  // ---- scale of this image's output rows: the largest V-tile scale over all heads and key groups ----
-  float fm = 0.f;
-  for (int i = tid; i < heads * ng; i += NT) {
-    const int hh = i / ng, gg = i - hh * ng;
-    fm = fmaxf(fm, inv[((int64_t)2 * heads + hh) * G + g_first + gg]);
-  }
-  fm = wave_max(fm);
-  float* red = reinterpret_cast<float*>(ah_smem + 2 * KS * AH_STAGE);
-  if (lane == 0) red[wave] = fm;
-  __syncthreads();
-  fm = red[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) fm = fmaxf(fm, red[w]);
-
   // ---- Q fragments (B operand): lane (query ql, half h2), k-step s: d = 16 s + 8 h2 + j = chunk 2 s + h2 of row ql ----
   attn_u32x4 qf[QG][2][4];
   float fq[QG];
@@ -546,6 +532,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
     }
   };
 
+  issue(0, 0);                          // the first step's tiles: in flight under everything the prologue still loads
+
   // per-tile K / V scales: lane t keeps those of key tile t (ng <= 64 for T <= 1984; longer images fall back to loads)
   float fk_lane = 1.0f, fv_lane = 1.0f;
   if (lane < ng) {
@@ -564,8 +552,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const unsigned
   }
   float fv_run = 1.0f;
 
-  issue(0, 0);
-  __syncthreads();                      // drains the DMA counter (fence) and publishes stage 0
+  // ---- scale of this image's output rows: the largest V-tile scale over all heads and key groups (used by the epilogue) ----
+  // its loads travel with the first tile's DMA and the Q fragments; the block maximum is published by the same barrier as stage 0
+  float fm = 0.f;
+  for (int i = tid; i < heads * ng; i += NT) {
+    const int hh = i / ng, gg = i - hh * ng;
+    fm = fmaxf(fm, inv[((int64_t)2 * heads + hh) * G + g_first + gg]);
+  }
+  fm = wave_max(fm);
+  float* red = reinterpret_cast<float*>(ah_smem + 2 * KS * AH_STAGE);
+  if (lane == 0) red[wave] = fm;
+  __syncthreads();                      // drains the DMA counter (fence) and publishes stage 0 (and red[])
+  fm = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) fm = fmaxf(fm, red[w]);
 
   // fragment addresses: lane-dependent part once (the swizzled 16-byte slot of each k-step), the stage / plane / d-block part
   // as the ds_read's immediate offset -- the tile body is instantiated per stage so that the stage is a compile-time constant
