@@ -72,7 +72,7 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
                        ("exact 3-way bf16 split" if products == 6 else "row-scaled 2-term fp16 split") + ")")
                       if split else "fp32 MFMA peak"),
         "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "clock_note": ("profiles/r03_pmc_h3_sq_raw.md + r03_pmc_h3_write_raw.md (h3; re-measured in round 4: r04_pmc_sq.md) / "
+        "clock_note": ("profiles/r03_pmc_h3_sq_raw.md + r03_pmc_h3_write_raw.md (h3; re-measured in rounds 4 and 5: r04_pmc_sq.md, r05_pmc_summary.md) / "
                        "r01_pmc_x6.md (x6): under these GEMMs the chip runs at its power limit -- ~1.49 GHz under the profiler "
                        "with the matrix cores busy ~82 % of all SIMD cycles for the h3 w12 kernel (1.65 GHz / 83.6 % for x6); "
                        "`peak` is the nominal 2.4 GHz figure.  Calibration (profiles/r03_calib_h3_hipblaslt_warm.log): the same "
