@@ -218,7 +218,7 @@ class PowerSampler:
                 "sclk_mhz_avg": round(sum(ck) / len(ck), 0) if ck else None,
                 "sclk_mhz_max": round(max(ck), 0) if ck else None,
                 "sclk_note": "hwmon freq1_input; under rocm-smi this node reads the ~94 MHz sleep-state marker when the clock is "
-                             "firmware-managed -- the PMC passes (profiles/r04_pmc_summary.md) give the in-kernel clock"}
+                             "firmware-managed -- the PMC passes (profiles/r05_pmc_summary.md) give the in-kernel clock"}
 
 
 def pmc_traffic(kernel, gemm):
