@@ -14,4 +14,4 @@ cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $R; f=$(find gpurun_out/${T}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${T}_kernel_stats.csv && head -8 gpurun_out/${T}_kernel_stats.csv | cut -c1-200
 python tools/bench_brief.py gpurun_out/${T}_prof_bench.json profiled | head -1 | cut -c1-300
 rm -rf gpurun_out/${T}_prof
-bash tools/gpu_pmc_vit.sh
+[ -z "$NO_PMC" ] && bash tools/gpu_pmc_vit.sh
