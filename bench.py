@@ -735,12 +735,71 @@ def main():
                               v.get("ms_per_iteration") or v.get("kernel_ms"))
                           for k, v in st.items()}
     out["roofline"]["checks"] = summ
+    out["roofline"].update(flat_evidence(out))
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     if failed:
         print(f"PARITY VIOLATION: {failed}", file=sys.stderr, flush=True)
         sys.exit(3)
+
+
+def flat_evidence(out):
+    """SCALAR copies of the run's evidence for `roofline` (round 6): a parsed copy of the line that keeps only the scalar
+    members of the contract objects still carries the end-to-end fraction, the power record, the exact-fp32 mode, the parity
+    summary and one figure per stage.  Every key is a plain number / bool (None when the run skipped that part)."""
+    r = out["roofline"]
+    flat = {}
+
+    def put(key, v, nd=4):
+        if isinstance(v, bool) or v is None:
+            flat[key] = v
+        elif isinstance(v, (int, float)):
+            flat[key] = round(float(v), nd) if isinstance(v, float) else v
+    put("e2e_frac", (r.get("end_to_end") or {}).get("frac"))
+    pw = r.get("power") or {}
+    put("power_w", pw.get("avg_w"), 1)
+    put("power_cap_w", pw.get("cap_w"), 1)
+    put("sclk_mhz", pw.get("sclk_mhz_avg"), 0)
+    f32 = (out.get("modes") or {}).get("f32") or {}
+    put("f32_mode_images_per_s", f32.get("value"), 2)
+    put("f32_mode_frac", f32.get("frac"))
+    put("f32_mode_e2e_frac", f32.get("end_to_end_frac"))
+    x6 = (out.get("modes") or {}).get("x6") or {}
+    put("x6_mode_images_per_s", x6.get("value"), 2)
+    pr = out.get("parity") or {}
+    put("parity_ok", pr.get("ok"))
+    put("parity_images", pr.get("images"))
+    put("parity_token_max_abs_err", pr.get("token_max_abs_err"), 10)
+    put("parity_vlad_rel_err", pr.get("vlad_max_rel_err"), 10)
+    put("label_mismatches", pr.get("label_mismatches"))
+    put("topk_index_mismatches", pr.get("topk_index_mismatches"))
+    rc = out.get("retrieval_check") or {}
+    put("retrieval_ok", rc.get("ok"))
+    put("retrieval_queries", rc.get("queries"))
+    put("retrieval_index_mismatches", rc.get("index_mismatches"))
+    st = out.get("stages") or {}
+    put("b1_ms", (st.get("vitg_b1") or {}).get("ms_per_image"), 3)
+    put("b1_480x640_ms", (st.get("vitg_b1_480x640") or {}).get("ms_per_image"), 3)
+    put("script_path_images_per_s", (st.get("script_path_vitg") or {}).get("images_per_s"), 1)
+    legs = (st.get("script_path_vitg") or {}).get("legs_ms") or {}
+    put("script_generate_multi_ms", legs.get("generate_multi_total"), 2)
+    put("script_get_top_k_recall_ms", legs.get("get_top_k_recall_total"), 2)
+    put("vlad61_frac", (st.get("vlad_61img_pipeline_tokens") or {}).get("frac"))
+    put("vlad256_frac", (st.get("vlad_256img_pipeline_tokens") or {}).get("frac"))
+    put("kmeans_frac", (st.get("kmeans_5Mx1536") or {}).get("frac"))
+    put("config3_shard_frac", (st.get("config3_shard") or {}).get("frac"))
+    put("config3_shard_ms", (st.get("config3_shard") or {}).get("ms"), 2)
+    put("config3_whole_db_s", (st.get("config3_whole_db") or {}).get("seconds_per_retrieval"), 3)
+    put("vitl_518_images_per_s", (st.get("vitl_518_2taps") or {}).get("images_per_s"), 1)
+    put("config2_full_job_s", (st.get("config2_full_job") or {}).get("seconds"), 2)
+    bad = [k for k, v in st.items() if isinstance(v, dict) and v.get("oracle_ok") is False]
+    if st:
+        flat["stages_oracle_ok"] = not bad
+    km = r.get("kernels_ms_per_step") or {}
+    put("attention_ms_per_step", km.get("attention"), 3)
+    put("layernorm_ms_per_step", km.get("layernorm_h2"), 3)
+    return flat
 
 
 def retrieval_identity(results, db, gt_timed, tol=3e-6):
