@@ -81,6 +81,7 @@ SIGNATURES = {
     "anyloc_attention_h3": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vlad_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "anyloc_vlad_auto_parts": (C.c_int, [c_i64, c_i64, c_i64, c_i64]),
+    "anyloc_vlad_workspace_bytes_parts": (c_sz, [c_i64, c_i64, c_i64, c_i64, C.c_int32]),
     "anyloc_vlad_hard": (C.c_int, [c_f32p, c_i64p, c_i64, c_i64, c_i64, c_f32p, c_i64, C.c_uint,
                                    c_f32p, c_i64p, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vlad_soft": (C.c_int, [c_f32p, c_i64p, c_i64, c_i64, c_i64, c_f32p, c_i64, C.c_float,
@@ -102,7 +103,7 @@ SIGNATURES = {
     "anyloc_vit_destroy": (None, [C.c_void_p]),
     "anyloc_vit_attach_x3": (C.c_int, [C.c_void_p, C.POINTER(VitBlockX3)]),
     "anyloc_vit_attach_h2": (C.c_int, [C.c_void_p, C.POINTER(VitBlockH2)]),
-    "anyloc_vit_set_telemetry": (C.c_int, [C.c_void_p, c_f32p]),
+    "anyloc_vit_set_telemetry": (C.c_int, [C.c_void_p, c_f32p, C.c_int32]),
     "anyloc_vit_block_ffn_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "anyloc_vit_workspace_bytes": (c_sz, [C.c_void_p, c_i64, c_i64, c_i64]),
     "anyloc_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_i64, c_i64, c_i64, c_f32p, C.c_int32,
@@ -114,7 +115,7 @@ SIGNATURES = {
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),
 }
 
-ABI_VERSION = 7          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
+ABI_VERSION = 8          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
 
 _lib = None
 

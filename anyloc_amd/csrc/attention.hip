@@ -837,9 +837,8 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
   if (ks_opt == 2 || (ks_opt == 0 && (int64_t)QB2 * heads * batch <= 512)) {
     const dim3 grid2((unsigned)((int64_t)QB2 * heads * batch));
     const size_t lds2 = 4 * AH_STAGE + 64;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<1, 4, 2>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    ANYLOC_CHECK_ARG(attr == hipSuccess, "attention_h3: cannot reserve %zu bytes of LDS", lds2);
+    static DynLds dyn_lds_once;                          // (per device: a process may drive several GPUs)
+    ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(attention_h3_kernel<1, 4, 2>), (int)lds2));
     hipLaunchKernelGGL((attention_h3_kernel<1, 4, 2>), grid2, dim3(256), lds2, stream, planes, inv, T, heads, G, out2, out_inv, R, QB2);
     return launch_status("attention_h3_kernel<1,4,2>");
   }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -94,11 +95,28 @@ enum Option {
   OPT_H3S_W12_TALL,      // small-M plan of the w12 / fc1 GEMM of one image: 1 = 192 x 128 tiles (one workgroup per CU), 0 = 128 x 128
   OPT_ATTN_H3_QG,        // attention_h3: 32-query groups per wave, 1 (four waves of 32 queries, default) or 2 (two waves of 64: A/B)
   OPT_ATTN_H3_KS,        // attention_h3: key splits across the waves of a workgroup, 0 = by grid size (2 when all workgroups are resident), 1, 2
+  OPT_VLAD_GATHER_V,     // one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the hazard study (0 = shipped)
   OPT_COUNT
 };
 int64_t option(Option o);
 
 int launch_status(const char* what);
+
+// A kernel that needs more than the default 64 KiB of dynamic LDS must be told so with hipFuncSetAttribute -- a property of
+// the (kernel, DEVICE) pair: a process that drives several GPUs (device = "cuda:N", the sharded bench) has to set it on each.
+// One DynLds per launch site (a static local: one per kernel instantiation) remembers the devices already done as a bit set;
+// a failed call is reported and NOT remembered.
+struct DynLds { std::atomic<unsigned long long> seen{0}; };
+inline int ensure_dyn_lds(DynLds& st, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "hipGetDevice");
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (dev < 64 && (st.seen.load(std::memory_order_relaxed) & bit)) return ANYLOC_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (dev < 64) st.seen.fetch_or(bit, std::memory_order_relaxed);
+  return ANYLOC_OK;
+}
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -241,6 +259,7 @@ struct H3Problem {
   unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
   // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])
   unsigned char* C2; int64_t RC; const float* c_inv;
+  unsigned* c_max;                          // optional [RC]: atomicMax of the bits of the largest scaled magnitude per row (FFN-bound telemetry)
   const char* tag;
 };
 
@@ -272,8 +291,10 @@ int attention_h3(const unsigned char* planes, const float* inv, int64_t batch, i
 // test / fallback producer of the same tiles from an fp32 [rows, 3D] buffer
 int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsigned char* planes, float* inv,
                         hipStream_t stream);
-// telemetry: *out = max(*out, max over rows < M of 2^15 / (largest |hi-plane value| of the row)) for an h2 image of R rows
-int h2_row_looseness(const void* h2, int64_t M, int64_t R, int64_t K, float* out, hipStream_t stream);
+// FFN-bound telemetry: rowmax [nblocks][M] = bits of the largest scaled magnitude every row of a block's fc2 operand image holds
+// (atomicMax by the fc1 / w12 epilogue, zero = block not run fused) -> out[l * groups + g] = max over the rows of group g
+// (rows_per_group consecutive rows: an image, or all M) of 2^15 / rowmax; 0 for a block that left no maxima
+int ffn_looseness(const unsigned* rowmax, int nblocks, int64_t M, int64_t rows_per_group, float* out, hipStream_t stream);
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
 // small-M plans (gemm_h3s.hip): GEMMs of fewer than ~2 workgroups of 128 x 256 per CU -- one or a few images per call
 enum { H3_KIND_OTHER = 0, H3_KIND_QKV = 1, H3_KIND_PROJ = 2, H3_KIND_FC1 = 3, H3_KIND_FC2 = 4 };

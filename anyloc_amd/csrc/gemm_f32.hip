@@ -358,12 +358,8 @@ int launch_cfg(const GemmProblem& p, hipStream_t stream) {
   const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
   const size_t lds = (size_t)2 * (BM + BN) * ((ABL & 64) ? BK : BK + 4) * sizeof(float);
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, BK, OCC, EPI, ROWSQ, KFULL, ABL>;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(kern), (int)((int)lds)));
   const double ks = p.ksplit > 1 ? p.ksplit : 1;
   const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K * ks;
   const double bytes = 4.0 * (((double)p.M * p.K + (double)p.N * p.K) * ks + (double)p.M * p.N * ks);

@@ -385,40 +385,46 @@ __global__ __launch_bounds__(64) void layernorm_h2_direct_kernel(const float* __
   }
 }
 
-// FFN-bound telemetry (anyloc_vit_set_telemetry): largest scaled magnitude of every row of an h2 image (the leading plane
-// carries it) -> looseness of the bound the row was quantised against, 2^15 / max; the launch's maximum lands in *out.
-// One thread per row, k-blocks walked in order: adjacent rows are adjacent 32-byte pieces, so a wave reads 2-KiB runs.
-__global__ __launch_bounds__(256) void h2_row_looseness_kernel(const unsigned char* __restrict__ img, int64_t M, int64_t R, int K16,
-                                                               float* __restrict__ out) {
-  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  float amax = 0.f;
-  if (row < M) {
-    const unsigned char* p = img + row * 32;
-    for (int kb = 0; kb < K16; ++kb) {
-      const hu32x4 a = *reinterpret_cast<const hu32x4*>(p + (int64_t)kb * 2 * R * 32);
-      const hu32x4 b = *reinterpret_cast<const hu32x4*>(p + (int64_t)kb * 2 * R * 32 + 16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f16x2 x = __builtin_bit_cast(f16x2, a[j]), y = __builtin_bit_cast(f16x2, b[j]);
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf((float)x[0]), fabsf((float)x[1])), fmaxf(fabsf((float)y[0]), fabsf((float)y[1]))));
-      }
-    }
+// FFN-bound telemetry (anyloc_vit_set_telemetry).  The fc1 / w12 epilogue leaves, per block and token row, the largest scaled
+// magnitude the row holds in the fc2 operand image (atomicMax of the bit patterns, gemm_h3_kernel.hpp); a bound that is 2^L
+// above the row's real maximum shows as 2^(15 - L).  One workgroup per (block, row group): out = max over the group's rows of
+// 2^15 / max (a row that left nothing nonzero lies more than 2^39 below its bound, or is exactly zero -- a token row of an
+// FFN activation is never that: reported as 2^40); a block none of whose rows left a maximum did not run fused: 0.
+__global__ __launch_bounds__(256) void ffn_looseness_kernel(const unsigned* __restrict__ rowmax, int64_t M, int64_t rpg, int groups,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ unsigned any[4];
+  const int l = blockIdx.x / groups, g = blockIdx.x % groups;
+  const unsigned* rm = rowmax + (int64_t)l * M;
+  const int64_t r0 = (int64_t)g * rpg, r1 = min(M, r0 + rpg);
+  float loose = 0.f;
+  unsigned seen = 0u;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+    const unsigned b = rm[r];
+    seen |= b;
+    loose = fmaxf(loose, b ? 32768.0f / __uint_as_float(b) : 1.099511627776e12f);
   }
-  // a row whose leading plane is all zero lies more than 2^39 below its bound (or is exactly zero: then nothing was lost,
-  // but a token row of an FFN activation is never that) -- report it as 2^40
-  float loose = row < M ? (amax > 0.f ? 32768.0f / amax : 1.099511627776e12f) : 0.f;
   loose = wave_max(loose);
-  if ((threadIdx.x & 63) == 0 && loose > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(loose));   // positive floats order as their bits
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) seen |= (unsigned)__shfl_xor((int)seen, o, 64);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = loose;
+    any[threadIdx.x >> 6] = seen;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    out[blockIdx.x] = (any[0] | any[1] | any[2] | any[3]) ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : 0.0f;
 }
 
 }  // namespace
 
-int h2_row_looseness(const void* h2, int64_t M, int64_t R, int64_t K, float* out, hipStream_t stream) {
-  ANYLOC_CHECK_ARG(h2 && out && M > 0 && R >= M && K > 0 && K % 16 == 0, "h2_row_looseness: bad arguments");
-  ProfScope prof("ffn_telemetry", stream, 0.0, 2.0 * M * K);
-  hipLaunchKernelGGL(h2_row_looseness_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<const unsigned char*>(h2), M, R, (int)(K / 16), out);
-  return launch_status("h2_row_looseness_kernel");
+int ffn_looseness(const unsigned* rowmax, int nblocks, int64_t M, int64_t rows_per_group, float* out, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(rowmax && out && nblocks > 0 && M > 0 && rows_per_group > 0, "ffn_looseness: bad arguments");
+  const int groups = (int)((M + rows_per_group - 1) / rows_per_group);
+  ProfScope prof("ffn_telemetry", stream, 0.0, 4.0 * nblocks * M);
+  hipLaunchKernelGGL(ffn_looseness_kernel, dim3((unsigned)(nblocks * groups)), dim3(256), 0, stream, rowmax, M, rows_per_group,
+                     groups, out);
+  return launch_status("ffn_looseness_kernel");
 }
 
 size_t h2_bytes(int64_t rows, int64_t K) { return (size_t)((K + 15) / 16) * 2 * (size_t)rows * 32; }
@@ -533,12 +539,8 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
   do {                                                                                                                \
     using Cfg = H3Cfg<MI, NI, WM, WN, ST, KB>;                                                                        \
     const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);         \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI, KB>), \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));                          \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
+    static DynLds dyn_lds_once; \
+    ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI, KB>), (int)(Cfg::LDS)));                                                                                                                 \
     hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, OCC, EPI, KB>), dim3((unsigned)(tiles_m * tiles_n)),        \
                        dim3(64 * WM * WN), Cfg::LDS, stream, p, tiles_m, tiles_n);                                    \
   } while (0)

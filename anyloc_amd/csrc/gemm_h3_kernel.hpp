@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
       const float ai = rok ? p.a_inv[row] : 0.0f;
       float cs = 1.0f;
       if constexpr (EPI == EPI_SWIGLU_T_H2) cs = rok ? h2_scale_of_inv(p.c_inv[row]) : 0.0f;
+      float cmx = 0.0f;                                  // largest scaled magnitude of this lane's part of the row (telemetry)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int64_t wr = wr0 + ni * 32 + 4 * hl;
@@ -292,6 +293,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
             unsigned qh[4], ql[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) h2_pack2(o[2 * j] * cs, o[2 * j + 1] * cs, qh[j], ql[j]);
+            if (p.c_max) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) cmx = fmaxf(cmx, fabsf(o[j] * cs));
+            }
             hu32x4 ph, plo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ph[j] = qh[j]; plo[j] = ql[j]; }
@@ -303,6 +308,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
             *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
             *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
           }
+        }
+      }
+      if constexpr (EPI == EPI_SWIGLU_T_H2) {
+        // FFN-bound telemetry: c_max[row] = largest |value * 2^e_bound| the row holds in the fc2 operand image (positive floats
+        // order as their bit patterns); one atomic per (row, wave) -- the two halves of a row meet by one lane exchange
+        if (p.c_max) {
+          cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+          if (rok && hl == 0) atomicMax(p.c_max + row, __float_as_uint(cmx));
         }
       }
     }
@@ -514,10 +527,20 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
           hu32x4 ph, plo;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ph[j] = qh[j]; plo[j] = ql[j]; }
-          if (row < p.M && kcol < (SW ? p.N / 2 : p.N)) {
+          const bool live = row < p.M && kcol < (SW ? p.N / 2 : p.N);
+          if (live) {
             unsigned char* o = p.C2 + (((kcol >> 4) * 2) * p.RC + row) * 32 + ((((kcol >> 3) & 1) ^ (int)((row >> 3) & 1)) << 4);
             *reinterpret_cast<hu32x4*>(o) = ph;
             *reinterpret_cast<hu32x4*>(o + p.RC * 32) = plo;
+          }
+          if (p.c_max) {
+            // FFN-bound telemetry (see the transposed SwiGLU epilogue): the LPR lanes of a row meet by xor exchanges
+            static_assert((LPR & (LPR - 1)) == 0, "lanes per row: a power of two");
+            float cmx = live ? fmaxf(fmaxf(fmaxf(fabsf(t0[0]), fabsf(t0[1])), fmaxf(fabsf(t0[2]), fabsf(t0[3]))),
+                                     fmaxf(fmaxf(fabsf(t1[0]), fabsf(t1[1])), fmaxf(fabsf(t1[2]), fabsf(t1[3])))) : 0.0f;
+#pragma unroll
+            for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o2, 64));
+            if (row < p.M && lane % LPR == 0) atomicMax(p.c_max + row, __float_as_uint(cmx));
           }
         }
       }

@@ -166,12 +166,8 @@ template <int WM, int WN, int MB, int NB, int OCC, int EPI>
 int launch_h3m(const H3Problem& p, hipStream_t stream) {
   using Cfg = HmCfg<WM, WN, MB, NB>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3m_kernel<WM, WN, MB, NB, OCC, EPI>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_h3m_kernel<WM, WN, MB, NB, OCC, EPI>), (int)(Cfg::LDS)));
   hipLaunchKernelGGL((gemm_h3m_kernel<WM, WN, MB, NB, OCC, EPI>), dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * Cfg::NW), Cfg::LDS,
                      stream, p, tiles_m, tiles_n);
   return launch_status("gemm_h3m_kernel");

@@ -31,12 +31,8 @@ template <int EPI, int MI, int NI, int WM, int WN, int KB, int ST = 3>
 int launch_small(const H3Problem& p, hipStream_t stream) {
   using Cfg = H3Cfg<MI, NI, WM, WN, ST, KB>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr_set = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>), (int)(Cfg::LDS)));
   hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>), dim3((unsigned)(tiles_m * tiles_n * std::max(1, p.ksplit))),
                      dim3(64 * WM * WN), Cfg::LDS, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_h3_kernel (small-M plan)");

@@ -215,12 +215,8 @@ template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int SCHE
 int launch_x6(const X6Problem& p, hipStream_t stream) {
   using Cfg = X6Cfg<MI, NI, WM, WN, STAGES>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED, OUT3>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr_set = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED, OUT3>), (int)(Cfg::LDS)));
   hipLaunchKernelGGL((gemm_x6_kernel<MI, NI, WM, WN, STAGES, OCC, EPI, SCHED, OUT3>), dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WM * WN),
                      Cfg::LDS, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_x6_kernel");

@@ -227,9 +227,8 @@ int launch_f64(const F64Operand& A, const F64Operand& B, int64_t M, int64_t N, i
   const int64_t Tm = (M + TM - 1) / TM, Tn = (N + TM - 1) / TM;
   const dim3 grid((unsigned)(symmetric ? ((Tm + 1) / 2) * (Tm + 1) : Tm * Tn));
   constexpr size_t lds = sizeof(double) * 4 * TK * LDT;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<VA, VB>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  ANYLOC_CHECK_ARG(attr == hipSuccess, "%s: cannot reserve %zu bytes of LDS", what, lds);
+  static DynLds dyn_lds_once;                            // (per device; a failure is reported, not remembered)
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(gemm_f64_kernel<VA, VB>), (int)lds));
   ProfScope prof(what, stream, 2.0 * (double)M * (double)N * (double)K * (symmetric ? 0.5 : 1.0), 0.0);
   hipLaunchKernelGGL((gemm_f64_kernel<VA, VB>), grid, dim3(NT), lds, stream, A, B, M, N, K, symmetric ? 1 : 0, C);
   return launch_status("gemm_f64_kernel");

@@ -359,12 +359,8 @@ int scores_fewq_h3(const float* db, int64_t ldd, int64_t rows, const float* quer
   // qimg != nullptr: the queries' pre-split planes (fewq_query_image) go to LDS by DMA; nullptr: split by the staging lanes
 #define ANYLOC_FEWQ_H3(QD)                                                                                                       \
   do {                                                                                                                           \
-    static bool attr = false;                                                                                                    \
-    if (!attr) {                                                                                                                 \
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_h3_kernel<QD>),                                   \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SH_STAGE));                                 \
-      attr = true;                                                                                                               \
-    }                                                                                                                            \
+    static DynLds dyn_lds_once; \
+    ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(scores_fewq_h3_kernel<QD>), (int)(2 * SH_STAGE)));                                                                                                                            \
     hipLaunchKernelGGL(scores_fewq_h3_kernel<QD>, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SH_STAGE, stream, db,  \
                        ldd, rows, queries, ldq, (int)nq, qinv, kslice, qimg, part, rsq_part);                                    \
   } while (0)

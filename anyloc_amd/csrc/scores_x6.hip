@@ -234,12 +234,8 @@ template <int BK>
 int launch_fewq(const float* db, int64_t ldd, int64_t rows, const float* queries, int64_t ldq, int64_t nq, int64_t kslice, int ksplit,
                 float* part, float* rsq_part, hipStream_t stream) {
   const int64_t tiles = (rows + SX_BM - 1) / SX_BM;
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SxCfg<BK>::STAGE));
-    attr = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(scores_fewq_x6_kernel<BK>), (int)(2 * SxCfg<BK>::STAGE)));
   hipLaunchKernelGGL((scores_fewq_x6_kernel<BK>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 2 * SxCfg<BK>::STAGE, stream, db,
                      ldd, rows, queries, ldq, (int)nq, kslice, part, rsq_part);
   return launch_status("scores_fewq_x6_kernel");

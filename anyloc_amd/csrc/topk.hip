@@ -350,12 +350,8 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
                 "merge keys hold the column in 15 bits and the slot in 16");
   const size_t k2 = (size_t)((k + 1) & ~1ll);
   const size_t lds = 16 * (k2 + CAP) + 12 * k2 + 16;      // 37 KiB at k = 20: four blocks per CU
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (KMAX + CAP) + 12 * KMAX + 16));
-    attr = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(topk_merge_kernel), (int)(16 * (KMAX + CAP) + 12 * KMAX + 16)));
   if (metric == 1) {
     hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)nq), dim3(256), 0, stream, queries, dim, w.qn);
     ANYLOC_TRY(launch_status("rownorm_sq_kernel(q)"));

@@ -32,7 +32,8 @@ struct anyloc_vit {
   std::vector<anyloc_vit_block_x3> x3;      // optional: three-plane bf16 images of the four weight matrices
   std::vector<anyloc_vit_block_h2> h2;      // optional: two-plane fp16 images + row scales of the same matrices
   std::vector<char> ffn_exact;              // per block: 1 = quantise the FFN activation against the exact row maximum
-  float* ffn_looseness = nullptr;           // telemetry target (device [depth]) or null
+  float* ffn_looseness = nullptr;           // telemetry target (device [depth] or [depth][batch]) or null
+  int telemetry_per_image = 0;              // 1: one figure per (block, image) instead of one per block
   unsigned char* patch_w2 = nullptr;        // fp16 mode: two-plane image + row scales of patch_w, built (and owned) by
   float* patch_inv = nullptr;               // anyloc_vit_attach_h2
   void drop_patch_image() {
@@ -54,6 +55,8 @@ struct VitWs {
   float* qinv;              // fp16 mode, fused attention: 2^-e per (part, head, 32-row group) tile of q | k | v (in qkv)
   float* sk_part;           // fp16 mode, small-M plans: partial accumulators of a split-K launch (gemm_h3s.hip)
   unsigned* sk_tickets;     //                           arrival counters per tile, zero between launches
+  unsigned* hmax;           // fp16 mode, FFN-bound telemetry: [depth][M] largest scaled magnitude per row (bits), RIGHT BEHIND the
+                            // tickets so that one memset clears both
   size_t bytes;
 };
 
@@ -75,6 +78,7 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   w.qinv = a.take<float>(qkv_inv_count(M, c.heads));
   w.sk_part = a.take<float>(H3_SPLIT_PART_BYTES / sizeof(float));
   w.sk_tickets = a.take<unsigned>(H3_SPLIT_TICKETS);
+  w.hmax = a.take<unsigned>((size_t)c.depth * M);
   w.bytes = a.off;
   return w;
 }
@@ -125,12 +129,12 @@ int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const v
               int64_t w_row0, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
               const char* tag, hipStream_t stream, unsigned char* c2 = nullptr, const float* c_inv = nullptr,
               unsigned char* qkv_planes = nullptr, float* qkv_inv = nullptr, int heads = 0, const VitWs* ws = nullptr,
-              int kind = H3_KIND_OTHER) {
+              int kind = H3_KIND_OTHER, unsigned* c_max = nullptr) {
   if (A) ANYLOC_TRY(split_h2(A, K, M, K, a2, ainv, stream));
   H3Problem g{};
   if (ws) { g.sk_part = ws->sk_part; g.sk_tickets = ws->sk_tickets; }
   g.kind = kind;
-  g.C2 = c2; g.RC = M; g.c_inv = c_inv;
+  g.C2 = c2; g.RC = M; g.c_inv = c_inv; g.c_max = c_max;
   g.qkv_planes = qkv_planes; g.qkv_inv = qkv_inv; g.heads = heads; g.groups = (M + 31) / 32;
   g.A2 = a2; g.RA = M; g.a_inv = ainv;
   g.W2 = static_cast<const unsigned char*>(w2) + w_row0 * 32; g.RW = w_rows; g.w_inv = winv + w_row0;
@@ -296,9 +300,10 @@ int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks) {
   return ANYLOC_OK;
 }
 
-int anyloc_vit_set_telemetry(anyloc_vit_t* h, float* ffn_looseness) {
+int anyloc_vit_set_telemetry(anyloc_vit_t* h, float* ffn_looseness, int32_t per_image) {
   ANYLOC_CHECK_ARG(h, "vit_set_telemetry: null handle");
   h->ffn_looseness = ffn_looseness;
+  h->telemetry_per_image = per_image ? 1 : 0;
   return ANYLOC_OK;
 }
 
@@ -347,7 +352,13 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   const int64_t ldo = (int64_t)n_taps * D;
   const int norm_taps = (flags & ANYLOC_VIT_NORM_TAPS) ? 1 : 0;
   const int last_layer = tap_layers[n_taps - 1];
-  if (h3m) ANYLOC_HIP(hipMemsetAsync(w.sk_tickets, 0, H3_SPLIT_TICKETS * sizeof(unsigned), stream));   // split-K arrival counters
+  // split-K arrival counters; with telemetry on also the rows' maxima of every block that will run (adjacent: one memset)
+  const bool telem = h3m && h->ffn_looseness != nullptr;
+  if (h3m)
+    ANYLOC_HIP(hipMemsetAsync(w.sk_tickets, 0,
+                              telem ? (size_t)(reinterpret_cast<char*>(w.hmax + (size_t)(last_layer + 1) * M) - reinterpret_cast<char*>(w.sk_tickets))
+                                    : H3_SPLIT_TICKETS * sizeof(unsigned),
+                              stream));
   // does any tap need the block OUTPUT of the last executed layer?
   bool last_needs_full = false;
   for (int t = 0; t < n_taps; ++t)
@@ -460,13 +471,13 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       // the hidden activation is quantised in the epilogue against the row bound LayerNorm 2 left in w.hinv
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, nullptr, Hh, M, Hh,
-                             EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1));
+                             EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1,
+                             telem ? w.hmax + (size_t)l * M : nullptr));
       else
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0,
                              h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, nullptr, Hh, M, 2 * Hh,
                              h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
-                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1));
-      if (h->ffn_looseness) ANYLOC_TRY(h2_row_looseness(w.h3, M, M, Hh, h->ffn_looseness + l, stream));
+                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1, telem ? w.hmax + (size_t)l * M : nullptr));
       ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
     } else if (h3m) {
@@ -503,6 +514,8 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   }
   if (flags & ANYLOC_VIT_NORM_CONCAT)
     ANYLOC_TRY(l2norm_rows(out, ldo, out, ldo, batch * rows_per_img, ldo, 1e-12f, stream));
+  // FFN-bound telemetry: one figure per executed block (and image) from the row maxima the fc1 / w12 epilogues left
+  if (telem) ANYLOC_TRY(ffn_looseness(w.hmax, last_layer + 1, M, h->telemetry_per_image ? T : M, h->ffn_looseness, stream));
   return ANYLOC_OK;
 }
 

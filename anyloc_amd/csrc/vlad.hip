@@ -453,6 +453,16 @@ size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img, int64_t 
   return carve(nullptr, 0, total_tokens, D, K, n_img, parts).bytes + 256;
 }
 
+// the same for a call that passes ANYLOC_VLAD_PARTS(parts): sized for the larger of the library's count and the caller's
+size_t anyloc_vlad_workspace_bytes_parts(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K, int32_t parts) {
+  int p = 1;
+  if (fused_supported(D, K) && n_img > 0) {
+    p = fused_parts(n_img, total_tokens);
+    if (parts > p) p = parts > 64 ? 64 : parts;
+  }
+  return carve(nullptr, 0, total_tokens, D, K, n_img, p).bytes + 256;
+}
+
 int anyloc_vlad_auto_parts(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K) {
   return (fused_supported(D, K) && n_img > 0 && !two_pass_forced()) ? fused_parts(n_img, total_tokens) : 1;
 }
@@ -523,12 +533,8 @@ int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
   {
     const int sl = K > 128 ? SL / 2 : SL;           // K up to 256: half-width column slices keep K * sl floats in LDS
     const size_t lds = (size_t)K * sl * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 256 * SL * (int)sizeof(float) / 2));
-      attr = true;
-    }
+    static DynLds dyn_lds_once;
+    ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(accumulate_kernel<false>), (int)(256 * SL * (int)sizeof(float) / 2)));
     const double bytes = 4.0 * ((double)total_tokens * D + 2.0 * (double)n_img * K * D);
     ProfScope prof("vlad_accumulate", stream, 2.0 * total_tokens * D, bytes);
     // grid.y is limited to 65535: loop over image groups
@@ -576,12 +582,8 @@ int anyloc_vlad_soft(const float* tokens, const int64_t* offsets, int64_t n_img,
   }
   {
     const size_t lds = (size_t)K * SLS * (sizeof(double) + sizeof(float));
-    static bool attr = false;
-    if (!attr) {
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(soft_accumulate_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * SLS * 12));
-      attr = true;
-    }
+    static DynLds dyn_lds_once;
+    ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(soft_accumulate_kernel), (int)(64 * SLS * 12)));
     ProfScope prof("vlad_soft_accumulate", stream, 2.0 * total_tokens * D * K * K, 4.0 * total_tokens * D);
     for (int64_t i0 = 0; i0 < n_img; i0 += 65535) {
       const int64_t cnt = std::min<int64_t>(65535, n_img - i0);
@@ -765,12 +767,8 @@ int anyloc_kmeans_step(const float* x, int64_t n, int64_t D, const float* center
   {
     const int sl = K > 128 ? SL / 2 : SL;
     const size_t lds = (size_t)K * sl * sizeof(float) + (size_t)K * sizeof(unsigned);
-    static bool attr = false;
-    if (!attr) {
-      ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 129 * 1024));
-      attr = true;
-    }
+    static DynLds dyn_lds_once;
+    ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(accumulate_kernel<true>), (int)(129 * 1024)));
     ProfScope prof("kmeans_accumulate", stream, 1.0 * n * D, 4.0 * ((double)n * D + (double)chunks * K * D));
     hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((D + sl - 1) / sl), (unsigned)chunks), dim3(sl), lds,
                        stream, x, (const int64_t*)nullptr, rows, n, (int)D, (int)K, w.lab32, (const float*)nullptr,

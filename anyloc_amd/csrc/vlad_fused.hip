@@ -446,7 +446,11 @@ __device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-template <int NV, int SW, bool KMEANS>
+// GV (hazard study, round 6; option vlad_gather_v, D = 1536 VLAD mode only): 0 = the shipped gather arithmetic (mul, sub, select);
+// 1 = the round-5 form that was NOT reproducible run to run (one fma + select); 2 / 3 / 4 = 1 with `s_nop 3` behind
+// s_set_gpr_idx_on / in front of s_set_gpr_idx_off / behind it; 5 = all three; 7 = 1 with the compiler's own lowering of the
+// dynamic subscript; 8 = 1 with LLVM's usage pattern in our asm (indexed v_mov out, plain adds, indexed v_mov back)
+template <int NV, int SW, bool KMEANS, int GV = 0>
 __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   constexpr int D = NV * 128;
   constexpr int LD = D + 4;
@@ -821,6 +825,28 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
         } else if constexpr (CW == 2) {
           asm volatile("s_set_gpr_idx_on %4, 0x9\n\tv_add_f32 v192, v192, %2\n\tv_add_f32 v224, v224, %3\n\ts_set_gpr_idx_off"
                        : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
+        } else if constexpr (CW == 3 && GV == 7) {
+          static_for<CW>([&](auto j) { acc[j][(int)k] += v[j]; });
+        } else if constexpr (CW == 3 && GV == 8) {
+          float t0, t1, t2;
+          asm volatile("s_set_gpr_idx_on %6, 0x1\n\tv_mov_b32 %0, v160\n\tv_mov_b32 %1, v192\n\tv_mov_b32 %2, v224\n\ts_set_gpr_idx_off"
+                       : "=&v"(t0), "=&v"(t1), "=&v"(t2)
+                       : "{v[160:191]}"(acc[0]), "{v[192:223]}"(acc[1]), "{v[224:255]}"(acc[2]), "s"(k));
+          t0 += v[0]; t1 += v[1]; t2 += v[2];
+          asm volatile("s_set_gpr_idx_on %6, 0x8\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
+                       : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                       : "v"(t0), "v"(t1), "v"(t2), "s"(k));
+        } else if constexpr (CW == 3 && GV >= 2 && GV <= 5) {
+#define ANYLOC_GV_ASM(PRE, MID, POST)                                                                                  \
+  asm volatile("s_set_gpr_idx_on %6, 0x9\n\t" PRE "v_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"             \
+               "v_add_f32 v224, v224, %5\n\t" MID "s_set_gpr_idx_off" POST                                             \
+               : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])                              \
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k))
+          if constexpr (GV == 2) ANYLOC_GV_ASM("s_nop 3\n\t", "", "");
+          else if constexpr (GV == 3) ANYLOC_GV_ASM("", "s_nop 3\n\t", "");
+          else if constexpr (GV == 4) ANYLOC_GV_ASM("", "", "\n\ts_nop 3");
+          else ANYLOC_GV_ASM("s_nop 3\n\t", "s_nop 3\n\t", "\n\ts_nop 3");
+#undef ANYLOC_GV_ASM
         } else if constexpr (CW == 3) {
           asm volatile("s_set_gpr_idx_on %6, 0x9\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
                        "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
@@ -906,7 +932,8 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
               const int k = kk[2 * p2 + e];
 #pragma unroll
               for (int j = 0; j < CW; ++j) {
-                const float r = v[buf][e][j] * nq[buf][e] - c[2 * p2 + e][j];
+                const float r = GV == 0 ? v[buf][e][j] * nq[buf][e] - c[2 * p2 + e][j]
+                                        : __builtin_fmaf(v[buf][e][j], nq[buf][e], -c[2 * p2 + e][j]);
                 v[buf][e][j] = k < 0 ? 0.0f : r;
               }
               add_token(k < 0 ? 0 : k, v[buf][e]);
@@ -1057,16 +1084,25 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
 
 #undef x_rsrc
 
-template <int NV, int SW, bool KMEANS>
+template <int NV, int SW, bool KMEANS, int GV = 0>
 int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
   constexpr int D = NV * 128;
   const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + TT + SW * 32 + 4 + TT * 32);
-  auto kern = fused3_kernel<NV, SW, KMEANS>;
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
+  if constexpr (NV == 12 && SW == 8 && !KMEANS && GV == 0) {
+    switch ((int)option(OPT_VLAD_GATHER_V)) {                 // hazard study (tools/stress_vlad.py): see fused3_kernel
+      case 1: return launch_fused3<NV, SW, KMEANS, 1>(a, units, stream);
+      case 2: return launch_fused3<NV, SW, KMEANS, 2>(a, units, stream);
+      case 3: return launch_fused3<NV, SW, KMEANS, 3>(a, units, stream);
+      case 4: return launch_fused3<NV, SW, KMEANS, 4>(a, units, stream);
+      case 5: return launch_fused3<NV, SW, KMEANS, 5>(a, units, stream);
+      case 7: return launch_fused3<NV, SW, KMEANS, 7>(a, units, stream);
+      case 8: return launch_fused3<NV, SW, KMEANS, 8>(a, units, stream);
+      default: break;
+    }
   }
+  auto kern = fused3_kernel<NV, SW, KMEANS, GV>;
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(kern), (int)((int)lds)));
   ProfScope prof(KMEANS ? "kmeans_fused" : "vlad_fused", stream, 2.0 * a.total * D * 32,
                  4.0 * ((double)a.total * D + 2.0 * (double)units * a.K * D));
   unsigned grid = (unsigned)units;
@@ -1085,12 +1121,8 @@ int launch_fused(const FusedArgs& a, int64_t units, hipStream_t stream) {
   constexpr int SW = 8;
   const size_t lds = sizeof(float) * (TT * (D + 4) + SW * TT * 32 + SW * TT + TT + TT + 32);
   auto kern = vlad_fused_kernel<NV, KMEANS>;
-  static bool attr = false;
-  if (!attr) {
-    ANYLOC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    attr = true;
-  }
+  static DynLds dyn_lds_once;
+  ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(kern), (int)((int)lds)));
   const double bytes = 4.0 * ((double)a.total * D + 2.0 * (double)units * a.K * D);
   ProfScope prof(KMEANS ? "kmeans_fused" : "vlad_fused", stream, 2.0 * a.total * D * 32, bytes);
   unsigned grid = (unsigned)units;

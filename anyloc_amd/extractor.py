@@ -22,11 +22,13 @@ from . import _lib, ops, weights
 from .synth import ARCH, PATCH, POS_GRID
 
 DEFAULT_GEMM = "h3"      # block-GEMM arithmetic when neither the constructor nor ANYLOC_GEMM says otherwise
-# FFN-bound telemetry of the h3 forward (include/anyloc_hip.h, anyloc_vit_set_telemetry): the first forward of a model and
-# every FFN_CHECK_EVERY-th after it also measure how far the Cauchy-Schwarz bound of each block's hidden activation lies
-# above the rows' real maxima; a block beyond FFN_LOOSENESS_MAX is switched to the exact row-maximum quantiser (and the
-# forward that found it is repeated).  Within 2^16 of the bound every element keeps its 22 bits; 2^14 leaves a margin of 4.
-FFN_CHECK_EVERY = 64
+# FFN-bound telemetry of the h3 forward (include/anyloc_hip.h, anyloc_vit_set_telemetry): EVERY call measures, per executed
+# block and IMAGE, how far the Cauchy-Schwarz bound of the block's hidden activation lies above the rows' real maxima (the
+# fc1 / w12 epilogue leaves the maxima, one small launch reduces them; the host reads [depth, batch] floats per call).  An
+# image with a block beyond FFN_LOOSENESS_MAX is run again with exactly ITS loose blocks on the exact row-maximum quantiser,
+# and nothing outlives the call: the bits of an image depend on that image alone -- not on its batch mates, not on earlier
+# calls (round 5 sampled call 0 and every 64th, and a tripped block stayed switched for the handle's life).  Within 2^18 of
+# the bound every element keeps its 22 bits relative to the row maximum; 2^14 leaves a margin of 4.
 FFN_LOOSENESS_MAX = 2.0 ** 14
 _DINO_V2_MODELS = ("dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14", "dinov2_vitg14")
 _DINO_FACETS = ("query", "key", "value", "token")
@@ -180,12 +182,13 @@ class HipDinoV2:
             _lib.check(lib.anyloc_vit_attach_h2(self._handle, h2), "anyloc_vit_attach_h2")
         # the plane image of one activation operand must stay inside 2 GiB of buffer addressing
         self.max_rows = (2 ** 31 - 1) // (6 * max(dim, hidden)) - 512
-        # FFN-bound telemetry (h3 mode): per-block looseness of the last checked forward, blocks switched to the exact quantiser
-        self.ffn_check_every = FFN_CHECK_EVERY
+        # FFN-bound telemetry (h3 mode): per-block looseness of the last call (max over its images), the blocks that ran on
+        # the exact quantiser for some image of the last call, and how many images were run again over the handle's life
+        self.ffn_check = True             # False: no telemetry, no host sync (capture / timing probes; the bound is then unchecked)
         self.ffn_looseness = None
         self.ffn_exact_blocks = set()
-        self._forwards = 0
-        self._telemetry = torch.zeros(depth, dtype=torch.float32, device=device) if self.gemm == "h3" else None
+        self.ffn_reruns = 0
+        self._telemetry = None            # device [depth, batch] of the largest batch seen (h3 mode)
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -211,7 +214,6 @@ class HipDinoV2:
             raise RuntimeError(f"{self.name}: the model forward needs all {self.full_depth} blocks and the final "
                                f"norm.weight / norm.bias (loaded: {self.depth} blocks)")
         with _on_device(self.device):          # every launch of the call on the model's device, whatever the current one is
-            self._begin_call()
             tok = self._forward_taps(img, [(self.depth - 1, "token")], True, False, False)
             res = ops.layernorm(tok[:, 0].contiguous(), self._final_norm[0], self._final_norm[1], 1e-6)
         return res if img.is_cuda else ops.to_home(res, img.device)
@@ -228,19 +230,7 @@ class HipDinoV2:
         CURRENT HIP device and stream, so the call runs with this model's device current (a caller that built the
         extractor with device="cuda:N" need not have called torch.cuda.set_device(N))."""
         with _on_device(self.device):
-            self._begin_call()
             return self._forward_taps(img, taps, use_cls, norm_taps, norm_concat)
-
-    def _begin_call(self):
-        """FFN-bound telemetry schedule, per CALL of the public surface (a batch split into chunks is one call: all its
-        chunks are checked or none).  The check is SAMPLED -- call 0 of a model and every ``ffn_check_every``-th after it --
-        because reading the looseness back is one host sync; a block that trips it stays on the exact quantiser for the rest
-        of the handle's life, so the bits of an image may depend on whether an earlier image tripped a block (both
-        quantisers meet the oracle bar; ``ffn_check_every = 1`` checks every call, ``0`` none).  Synthetic ViT-S / L / g
-        weights measure 2^7 - 2^9 against the 2^14 limit."""
-        self._check_call = (self._telemetry is not None and self.ffn_check_every > 0
-                            and self._forwards % self.ffn_check_every == 0)
-        self._forwards += 1
 
     def _forward_taps(self, img, taps, use_cls, norm_taps, norm_concat):
         if img.ndim != 4 or img.shape[1] != 3:
@@ -280,28 +270,51 @@ class HipDinoV2:
         flags = (ops.VIT_USE_CLS if use_cls else 0) | (ops.VIT_NORM_TAPS if norm_taps else 0) | \
             (ops.VIT_NORM_CONCAT if norm_concat else 0) | (ops.VIT_SPLIT_BF16 if self.gemm == "x6" else 0) | \
             (ops.VIT_SPLIT_FP16 if self.gemm == "h3" else 0)
-        def forward():
-            _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(img), B, H, W, _lib.ptr(self.pos_table(H, W)),
-                                              n_taps, layers, facets, flags, _lib.ptr(out), _lib.ptr(ws),
+        def forward(x, y):
+            _lib.check(lib.anyloc_vit_forward(self._handle, _lib.ptr(x), x.shape[0], H, W, _lib.ptr(self.pos_table(H, W)),
+                                              n_taps, layers, facets, flags, _lib.ptr(y), _lib.ptr(ws),
                                               ws.numel(), _lib.stream_ptr()), "anyloc_vit_forward")
-        if not getattr(self, "_check_call", False):
-            forward()
+        if self.gemm != "h3" or not self.ffn_check:
+            forward(img, out)
             return out
-        # a checked forward: measure the looseness of every executed block's FFN bound; blocks beyond the limit move to the
-        # exact row-maximum quantiser and the forward is repeated with them (one host sync per checked forward)
-        self._telemetry.zero_()
-        _lib.check(lib.anyloc_vit_set_telemetry(self._handle, _lib.ptr(self._telemetry)), "anyloc_vit_set_telemetry")
+        # the call with the FFN-bound telemetry on: one figure per (executed block, image)
+        if self._telemetry is None or self._telemetry.numel() < self.depth * B:
+            self._telemetry = torch.empty(self.depth * B, dtype=torch.float32, device=self.device)
+        _lib.check(lib.anyloc_vit_set_telemetry(self._handle, _lib.ptr(self._telemetry), 1), "anyloc_vit_set_telemetry")
         try:
-            forward()
+            forward(img, out)
+            n_blocks = taps[-1][0] + 1
+            loose = self._telemetry[:n_blocks * B].cpu().reshape(n_blocks, B)          # (the call's one host sync)
+            self.ffn_looseness = loose.max(dim=1).values.numpy().copy()
+            self.ffn_exact_blocks = set()
+            bad = (loose > FFN_LOOSENESS_MAX)
+            if bool(bad.any()):
+                # images grouped by the set of blocks THEY trip: for each such set the call runs again with exactly those
+                # blocks exact -- the WHOLE batch, same row count and batch positions, because the kernels' summation orders
+                # depend on both (small-M plans, the global 32-row key groups of attention) -- and only the group's images
+                # take their rows from it.  So an image's bits depend on the image, its position and the call's shape, never
+                # on what its batch mates contain; the switches are cleared before the call returns.
+                groups = {}
+                for b in range(B):
+                    key = tuple(int(l) for l in torch.nonzero(bad[:, b]).flatten())
+                    if key:
+                        groups.setdefault(key, []).append(b)
+                _lib.check(lib.anyloc_vit_set_telemetry(self._handle, None, 0), "anyloc_vit_set_telemetry")
+                res = torch.empty_like(out)
+                for key, members in groups.items():
+                    try:
+                        for l in key:
+                            _lib.check(lib.anyloc_vit_block_ffn_exact(self._handle, l, 1), "anyloc_vit_block_ffn_exact")
+                        forward(img, res)
+                    finally:
+                        for l in key:
+                            _lib.check(lib.anyloc_vit_block_ffn_exact(self._handle, l, 0), "anyloc_vit_block_ffn_exact")
+                    idx = torch.tensor(members, device=self.device)
+                    out.index_copy_(0, idx, res.index_select(0, idx))
+                    self.ffn_exact_blocks.update(key)
+                    self.ffn_reruns += len(members)
         finally:
-            _lib.check(lib.anyloc_vit_set_telemetry(self._handle, None), "anyloc_vit_set_telemetry")
-        self.ffn_looseness = self._telemetry.cpu().numpy().copy()
-        tripped = [i for i, v in enumerate(self.ffn_looseness) if v > FFN_LOOSENESS_MAX and i not in self.ffn_exact_blocks]
-        if tripped:
-            for i in tripped:
-                _lib.check(lib.anyloc_vit_block_ffn_exact(self._handle, i, 1), "anyloc_vit_block_ffn_exact")
-            self.ffn_exact_blocks.update(tripped)
-            forward()
+            _lib.check(lib.anyloc_vit_set_telemetry(self._handle, None, 0), "anyloc_vit_set_telemetry")
         return out
 
 

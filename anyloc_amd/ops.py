@@ -233,9 +233,13 @@ def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_te
     lib = _lib.load()
     if dist_mode not in ("cosine", "euclidean"):
         raise NotImplementedError(f"dist_mode {dist_mode!r}")
+    parts = int(parts)
+    if not 0 <= parts <= 64:
+        raise ValueError(f"vlad: parts {parts} outside 0..64 (0 = the library's choice)")
     flags = (VLAD_NORM_DESCS if norm_descs else 0) | (VLAD_INTRA_NORM if intra_norm else 0) | \
-        (VLAD_EUCLIDEAN if dist_mode == "euclidean" else 0) | ((int(parts) & 0x7f) << 8)
-    ws_bytes = lib.anyloc_vlad_workspace_bytes(total, n_img, D, K)
+        (VLAD_EUCLIDEAN if dist_mode == "euclidean" else 0) | (parts << 8)
+    # (sized for the larger of the library's workgroups-per-image count and the caller's)
+    ws_bytes = lib.anyloc_vlad_workspace_bytes_parts(total, n_img, D, K, parts)
     ws = _lib.workspace(ws_bytes, device, "vlad")
     if mode == "hard":
         _lib.check(lib.anyloc_vlad_hard(_lib.ptr(packed), _lib.ptr(offsets), n_img, total, D,

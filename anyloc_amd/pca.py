@@ -132,11 +132,29 @@ class PCA:
             piv = axes.abs().argmax(dim=1)
             sign = torch.sign(axes[torch.arange(k, device=device), piv])
         else:
-            if xc is None:                                                 # Xc V = X V - mean V: the mean as a bias row
-                u = _gemm(X, axes.contiguous(), -(axes.double() * mean64).sum(dim=1).to(torch.float32))
+            cols = torch.arange(k, device=device)
+            if xc is None and n <= f:
+                # Gram side: U is in hand -- the eigenvectors the axes were back-projected from (axes = U^T Xc / s and the
+                # normalisation scale rows by positive numbers, so U's largest entry carries the sign sklearn looks at)
+                uk = vec[:, :k]
+                sign = torch.sign(uk[uk.abs().argmax(dim=0), cols]).to(torch.float32)
+            elif xc is None:
+                # scatter side: U diag(s) = Xc V, formed from row blocks CENTRED FIRST (round 5 took X V + (-mean V) as a bias:
+                # with |mean v_k| far above the column's largest |u| entry the fp32 cancellation could pick the wrong pivot)
+                best = torch.zeros(k, device=device)
+                sign = torch.ones(k, device=device)
+                at = axes.contiguous()
+                rows_b = max(1, (64 << 20) // (4 * f))
+                for r0 in range(0, n, rows_b):
+                    ub = _gemm((X[r0:r0 + rows_b] - self.mean_).contiguous(), at)
+                    pb = ub.abs().argmax(dim=0)
+                    vb = ub[pb, cols]
+                    take = vb.abs() > best
+                    best = torch.where(take, vb.abs(), best)
+                    sign = torch.where(take, torch.sign(vb), sign)
             else:
                 u = _gemm(xc, axes.contiguous())                           # [n, k] = U diag(s): same signs as U
-            sign = torch.sign(u[u.abs().argmax(dim=0), torch.arange(k, device=device)])
+                sign = torch.sign(u[u.abs().argmax(dim=0), cols])
         sign = torch.where(sign == 0, torch.ones_like(sign), sign)
         self.components_ = (axes * sign[:, None]).contiguous()
         self._dead = dead

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 7
+#define ANYLOC_ABI_VERSION 8
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -70,6 +70,8 @@ const char* anyloc_last_error(void);
  *                                     chain of key tiles; partial sums meet in LDS), 1 = none, 0 = 2 when all workgroups are resident
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
+ *   vlad_gather_v (0)                 one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the round-6
+ *                                     hazard study (tools/stress_vlad.py); 0 = the shipped arithmetic
  *   kmeans_max_chunks (0 = two per CU)
  *   h3_mfma16 (-1)                    plain-store two-term fp16 GEMMs of >= 256 tiles of 256 x 256 on the 16 x 16 x 32 MFMA kernel
  *                                     (csrc/gemm_h3m.hip): -1 when the contraction is >= 4096 long (retrieval panels), 0 never, 1 always
@@ -249,6 +251,9 @@ int anyloc_attention_h3(const float* qkv, void* out_img, float* out_inv, int64_t
 size_t anyloc_vlad_workspace_bytes(int64_t total_tokens, int64_t n_img,
                                    int64_t D, int64_t K);
 int anyloc_vlad_auto_parts(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K);   /* the library's choice (1 where the one-pass kernel does not apply) */
+/* ABI 8: the workspace of a call that passes ANYLOC_VLAD_PARTS(parts) -- sized for the larger of the library's own count and
+ * the caller's (anyloc_vlad_workspace_bytes alone covers a caller's count only while it does not exceed the library's). */
+size_t anyloc_vlad_workspace_bytes_parts(int64_t total_tokens, int64_t n_img, int64_t D, int64_t K, int32_t parts);
 int anyloc_vlad_hard(const float* tokens, const int64_t* offsets, int64_t n_img,
                      int64_t total_tokens, int64_t D, const float* centers,
                      int64_t K, unsigned flags, float* out, int64_t* labels,
@@ -410,14 +415,19 @@ typedef struct anyloc_vit_block_h2 {
 } anyloc_vit_block_h2;
 int anyloc_vit_attach_h2(anyloc_vit_t* h, const anyloc_vit_block_h2* blocks /*host array [depth]*/);
 
-/* FFN-bound telemetry of the two-term fp16 forward (ABI 5).  The fused fc1 epilogue quantises the hidden activation
- * against an UPPER BOUND of its row (fc1_bound above); a bound that is more than ~2^16 above the row's real maximum costs
- * low bits.  With a device array ffn_looseness [depth] (zeroed by the caller) set here, every later forward also measures,
- * per executed block, max over token rows of 2^15 / (largest scaled magnitude the row actually holds in the fc2 operand
- * image) -- i.e. how loose the bound was -- with one extra read of that image per block.  NULL switches it off (default).
+/* FFN-bound telemetry of the two-term fp16 forward (ABI 5; per image and without an extra pass over the image since ABI 8).
+ * The fused fc1 epilogue quantises the hidden activation against an UPPER BOUND of its row (fc1_bound above); a bound more
+ * than ~2^18 above the row's real maximum would cost low bits.  With a device array set here, every later forward also
+ * reports, per executed block, max over token rows of 2^15 / (largest scaled magnitude the row actually holds in the fc2
+ * operand image) -- how loose the bound was: the epilogue leaves the rows' maxima by atomicMax (no extra read of the image),
+ * one small launch at the end of the forward reduces them.  per_image = 0: ffn_looseness[depth], one figure per block over
+ * all rows of the call; per_image = 1: ffn_looseness[depth][batch] (row-major, the call's batch), one figure per block and
+ * image, so that a caller can decide per IMAGE -- independent of what else is in the batch and of earlier calls.  A block that
+ * did not run fused (exact mode, not executed) reports 0.  NULL switches it off (default).
  * anyloc_vit_block_ffn_exact(h, layer, 1) makes that block write its activation as fp32 and quantise it against the exact
- * row maximum instead (the data flow of fc1_bound = 0); the Python host flips it for blocks whose looseness exceeds 2^14. */
-int anyloc_vit_set_telemetry(anyloc_vit_t* h, float* ffn_looseness /*device [depth] or NULL*/);
+ * row maximum instead (the data flow of fc1_bound = 0).  The Python host checks EVERY call: images with a block above 2^14
+ * are run again with exactly their own loose blocks switched, and the switches are cleared after the call. */
+int anyloc_vit_set_telemetry(anyloc_vit_t* h, float* ffn_looseness /*device [depth] / [depth][batch] or NULL*/, int32_t per_image);
 int anyloc_vit_block_ffn_exact(anyloc_vit_t* h, int32_t layer, int32_t exact);
 #define ANYLOC_VIT_SPLIT_FP16 16u    /* block GEMMs as three fp16 products, fp32-level accuracy */
 

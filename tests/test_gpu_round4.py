@@ -294,7 +294,7 @@ def test_patch_embedding_on_the_fp16_gemm_agrees_with_the_fp32_gemm(name, batch,
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 7, device=DEV, depth=1))
     try:
         ext = utilities.DinoV2ExtractFeatures(name, 0, "token", device=DEV)
-        ext.dino_model.ffn_check_every = 0
+        ext.dino_model.ffn_check = False
         g = torch.Generator().manual_seed(5)
         for img in (torch.randn(batch, 3, *hw, generator=g), torch.rand(batch, 3, *hw, generator=g) * 255.0):
             img = img.to(DEV)

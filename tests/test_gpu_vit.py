@@ -187,7 +187,7 @@ def test_small_m_plans_agree_with_the_plain_kernels(batch):
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device=DEV, depth=3))
     try:
         ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
-        ext.dino_model.ffn_check_every = 0
+        ext.dino_model.ffn_check = False
         img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(10 + batch)).to(DEV)
         with ops.options(h3s_enable=0):
             want = ext(img).clone()
@@ -221,7 +221,7 @@ def test_split_k_hand_off_under_load():
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 4, device=DEV, depth=3))
     try:
         ext = utilities.DinoV2ExtractFeatures(name, 2, "value", device=DEV)
-        ext.dino_model.ffn_check_every = 0
+        ext.dino_model.ffn_check = False
         for batch in (1, 2):
             img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(70 + batch)).to(DEV)
             with ops.options(h3s_cfg=0, h3s_kb=1, h3s_ksplit=1, h3s_stages=3):
@@ -266,13 +266,70 @@ def test_ffn_bound_telemetry_switches_a_loose_block_to_the_exact_quantiser():
         assert m.ffn_looseness is not None and m.ffn_looseness[2] > ex.FFN_LOOSENESS_MAX, m.ffn_looseness
         assert m.ffn_exact_blocks == {2}, (m.ffn_exact_blocks, m.ffn_looseness)
         assert all(0 < m.ffn_looseness[i] <= ex.FFN_LOOSENESS_MAX for i in (0, 1, 3)), m.ffn_looseness
+        assert m.ffn_reruns == 3                                  # every image of the call trips block 2 and was run again
         full = dinov2_ref.DinoVisionTransformer(name)
         full.blocks = full.blocks[:4]
         full.load_state_dict(sd, strict=True)
         ref = dinov2_ref.extract_facet(full.eval(), img, 3, "token")
         assert float((got - ref).abs().max()) <= 2e-5
-        # the switch is sticky and later forwards need no repeat
+        # nothing is sticky (round 6): the next call decides again from its own data and gives the same bits
         again = ext(img.to(DEV)).cpu()
         assert torch.equal(again, got)
+        assert m.ffn_reruns == 6 and m.ffn_exact_blocks == {2}
+    finally:
+        weights.unregister_state_dict(name)
+
+
+def test_ffn_bound_decision_is_per_image_and_leaves_no_state(monkeypatch):
+    """Round 6: the decision between the bound quantiser and the exact one is taken per CALL and per IMAGE from the
+    looseness the forward itself measured (one figure per block and image).  With the threshold moved between the images'
+    own figures, some images of a batch trip a block and others do not: every image's tokens are bit for bit what the image
+    gives at the same position of a call whose other images are clean -- whatever its batch mates contain -- and the same
+    before and after a tripping image went through the handle."""
+    import utilities
+    from anyloc_amd import extractor as ex
+    from oracle import dinov2_ref
+    name = "dinov2_vits14"
+    sd = synth.synthetic_state_dict(name, 9, device="cpu", depth=4)
+    weights.register_state_dict(name, {k: v.to(DEV) for k, v in sd.items()})
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 3, "token", device=DEV)
+        m = ext.dino_model
+        g = torch.Generator().manual_seed(21)
+        imgs = torch.cat([torch.randn(3, 3, 224, 224, generator=g), 0.05 * torch.randn(3, 3, 224, 224, generator=g)]).to(DEV)
+        # per-image figures of block 1 at the stock threshold (nothing trips on ordinary weights)
+        ext(imgs)
+        assert m.ffn_reruns == 0 and m.ffn_exact_blocks == set()
+        per_img = m._telemetry[:4 * 6].cpu().reshape(4, 6)
+        assert float(per_img.min()) > 1.0 and float(per_img.max()) <= ex.FFN_LOOSENESS_MAX
+        order = torch.argsort(per_img[1])
+        thr = float(0.5 * (per_img[1][order[2]] + per_img[1][order[3]]))          # three images below, three above (block 1)
+        if not per_img[1][order[2]] < thr < per_img[1][order[3]]:
+            pytest.skip("the images' looseness figures coincide: no threshold separates them")
+        monkeypatch.setattr(ex, "FFN_LOOSENESS_MAX", thr)
+        trips = [bool((m_l > thr).any()) for m_l in per_img.t()]
+        assert any(trips) and not all(trips), trips
+        clean = trips.index(False)
+        # what image i gives at batch position i of a six-image call whose other images are all the clean one (the kernels'
+        # summation orders depend on the call's row count and on the position, so both are kept)
+        def filler_with(i):
+            b = imgs[clean:clean + 1].repeat(6, 1, 1, 1)
+            b[i] = imgs[i]
+            return b
+        want = [ext(filler_with(i))[i].clone() for i in range(6)]
+        runs0 = m.ffn_reruns
+        batch = ext(imgs)
+        assert m.ffn_reruns - runs0 == sum(trips) and m.ffn_exact_blocks, (m.ffn_reruns, runs0, trips)
+        for i in range(6):
+            assert torch.equal(batch[i], want[i]), (i, trips)
+        # a clean call after a tripping one through the same handle: the same bits as before it, and nothing stays switched
+        again = ext(filler_with(clean))
+        assert torch.equal(again[clean], want[clean]) and m.ffn_exact_blocks == set()
+        # both quantisers meet the oracle bar
+        full = dinov2_ref.DinoVisionTransformer(name)
+        full.blocks = full.blocks[:4]
+        full.load_state_dict(sd, strict=True)
+        ref = dinov2_ref.extract_facet(full.eval(), imgs.cpu(), 3, "token")
+        assert float((batch.cpu() - ref).abs().max()) <= 2e-5
     finally:
         weights.unregister_state_dict(name)

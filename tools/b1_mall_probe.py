@@ -19,7 +19,7 @@ img = torch.randn(1, 3, 322, 322, device=dev)
 for depth in (2, 32):
     weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device=dev, depth=depth))
     ext = utilities.DinoV2ExtractFeatures(name, depth - 1, "token", device=dev)
-    ext.dino_model.ffn_check_every = 0
+    ext.dino_model.ffn_check = False
     for _ in range(5):
         ext(img)
     torch.cuda.synchronize()

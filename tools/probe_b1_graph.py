@@ -17,7 +17,7 @@ import utilities  # noqa: E402
 name = "dinov2_vitg14"
 weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device="cuda", depth=40))
 ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device="cuda")
-ext.dino_model.ffn_check_every = 0                     # (the sampled telemetry read-back is a host sync: not capturable)
+ext.dino_model.ffn_check = False                     # (the sampled telemetry read-back is a host sync: not capturable)
 for hw in ((322, 322), (476, 630)):
     img = torch.randn(1, 3, *hw, device="cuda")
     for _ in range(5):

@@ -18,7 +18,7 @@ dev = "cuda"
 name = "dinov2_vitg14"
 weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device=dev, depth=32))
 ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device=dev)
-ext.dino_model.ffn_check_every = 0
+ext.dino_model.ffn_check = False
 TAGS = {"qkv": "vit_qkv_gemm", "proj": "vit_proj_gemm", "w12": "vit_w12_gemm", "fc2": "vit_fc2_gemm"}
 _, qu, _ = synth.synthetic_places(8, 8, 322, 322, seed=42, device=dev)
 img = qu[3:4]

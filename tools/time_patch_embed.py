@@ -18,7 +18,7 @@ dev = "cuda"
 name = "dinov2_vitg14"
 weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device=dev, depth=32))
 ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device=dev)
-ext.dino_model.ffn_check_every = 0
+ext.dino_model.ffn_check = False
 for batch, n in ((1, 60), (61, 8)):
     img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(1)).to(dev)
     toks = {}

@@ -16,7 +16,7 @@ dev = "cuda"
 name = "dinov2_vitg14"
 weights.register_state_dict(name, synth.synthetic_state_dict(name, 0, device=dev, depth=32))
 ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device=dev)
-ext.dino_model.ffn_check_every = 0
+ext.dino_model.ffn_check = False
 streams = [torch.cuda.Stream() for _ in range(4)]
 
 
