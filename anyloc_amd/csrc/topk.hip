@@ -287,10 +287,35 @@ struct TopkWs {
   int64_t panel, q_chunk;
   size_t bytes;
 };
-TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim) {
+// A prepared database (anyloc_topk_index_build: faiss' index.add): per panel of index_panel(dim) rows the two-plane fp16 image
+// the score GEMM reads, then the rows' 2^-e and their raw sums of squares.  Layout inside the caller's buffer:
+//   [n_panels][align256(h2_bytes(panel, dim))] images (a shorter last panel: an image of its own row count at its slot)
+//   [ndb] float 2^-e      [ndb] float sum of squares
+int64_t index_panel(int64_t dim) { return std::min(H3_PANEL, h3_rows_limit(dim)); }
+bool index_supported(int64_t ndb, int64_t dim) { return ndb > 0 && dim % 16 == 0 && dim >= 16 && h3_rows_limit(dim) >= 256; }
+struct IndexView {
+  unsigned char* img;
+  float *dinv, *dss;
+  int64_t panel;
+  size_t slot, bytes;
+};
+IndexView index_view(void* p, int64_t ndb, int64_t dim) {
+  IndexView v;
+  v.panel = index_panel(dim);
+  const int64_t np = (ndb + v.panel - 1) / v.panel;
+  v.slot = align_up(h2_bytes(v.panel, dim), 256);
+  unsigned char* b = static_cast<unsigned char*>(p);
+  v.img = b;
+  v.dinv = reinterpret_cast<float*>(b + (size_t)np * v.slot);
+  v.dss = v.dinv + align_up((size_t)ndb, 64);
+  v.bytes = (size_t)np * v.slot + 2 * align_up((size_t)ndb, 64) * sizeof(float);
+  return v;
+}
+
+TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim, bool indexed = false) {
   Arena a(ws, cap);
   TopkWs w;
-  const bool h3 = h3_scores(nq, ndb, dim);
+  const bool h3 = indexed || h3_scores(nq, ndb, dim);
   w.panel = h3 ? std::min(H3_PANEL, h3_rows_limit(dim)) : PANEL;
   w.q_chunk = h3 ? std::min<int64_t>(nq, h3_rows_limit(dim)) : nq;
   const int64_t panel = std::min<int64_t>(w.panel, std::max<int64_t>(ndb, 1));
@@ -298,14 +323,14 @@ TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim) {
   const int64_t n_qchunks = h3 ? (nq + w.q_chunk - 1) / w.q_chunk : 0;
   // (few-query fp16 path: the queries' pre-split planes, 10 KiB per 32-k slab)
   w.qimg = a.take<unsigned char>(h3 ? (size_t)n_qchunks * h2_bytes(w.q_chunk, dim) : few_queries(nq, dim) ? fewq_query_image_bytes(dim) : 1);
-  w.dimg = a.take<unsigned char>(h3 ? h2_bytes(panel, dim) : 1);
+  w.dimg = a.take<unsigned char>(h3 && !indexed ? h2_bytes(panel, dim) : 1);
   w.qinv = a.take<float>(h3 ? nq : 64);                  // (few-query fp16 path: the <= 64 queries' row scales)
-  w.dinv = a.take<float>(h3 ? panel : 1);
+  w.dinv = a.take<float>(h3 && !indexed ? panel : 1);
   w.qn = a.take<float>(std::max<int64_t>(nq, 1));
   w.dn = a.take<float>(std::max<int64_t>(ndb, 1));
   w.dss = a.take<float>(std::max<int64_t>(ndb, 1));
   w.dnorm = a.take<float>(std::max<int64_t>(ndb, 1));
-  const bool few = few_queries(nq, dim);
+  const bool few = !indexed && few_queries(nq, dim);
   w.part = a.take<float>(few ? (size_t)SPLITK_MAX * panel * 64 : 1);
   w.rsq_part = a.take<float>(few ? (size_t)SPLITK_MAX * panel : 1);
   w.bytes = a.off;
@@ -324,23 +349,28 @@ size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t
   return carve(nullptr, 0, nq, ndb, dim).bytes + 256;
 }
 
-int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, int64_t dim, int64_t k, int metric,
-                unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
-                void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+}  // extern "C"
+
+// the search; `index` != nullptr: the database side comes from a prepared index (db may be null), every query count runs
+// on the fp16 score panels
+static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t ndb, int64_t dim, int64_t k, int metric,
+                     unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
+                     const void* index, hipStream_t stream) {
   ANYLOC_CHECK_ARG(nq >= 0 && ndb >= 0, "topk: negative size");
   if (nq == 0 || k == 0) return ANYLOC_OK;
   ANYLOC_CHECK_ARG(queries && dist && idx, "topk: null pointer");
-  ANYLOC_CHECK_ARG(db || ndb == 0, "topk: null database");
+  ANYLOC_CHECK_ARG(db || ndb == 0 || index, "topk: null database");
+  const bool indexed = index != nullptr;
+  const IndexView iv = indexed ? index_view(const_cast<void*>(index), ndb, dim) : IndexView{};
   ANYLOC_CHECK_ARG(k >= 1 && k <= KMAX, "topk: k=%lld outside [1,%d]", (long long)k, KMAX);
   ANYLOC_CHECK_ARG(metric == 0 || metric == 1, "topk: metric %d", metric);
   ANYLOC_CHECK_ARG(dim >= 4 && dim % 4 == 0, "topk: dim %lld must be a positive multiple of 4", (long long)dim);
   ANYLOC_CHECK_ARG(nq < (1ll << 31), "topk: too many queries");
   ANYLOC_CHECK_ARG((flags & ~ANYLOC_TOPK_NORMALIZE_DB) == 0, "topk: unknown flags %u", flags);
-  TopkWs w = carve(workspace, workspace_bytes, nq, ndb, dim);
+  TopkWs w = carve(workspace, workspace_bytes, nq, ndb, dim, indexed);
   const bool norm_db = (flags & ANYLOC_TOPK_NORMALIZE_DB) != 0;
-  const bool few = few_queries(nq, dim);
-  const bool h3 = h3_scores(nq, ndb, dim);
+  const bool few = !indexed && few_queries(nq, dim);
+  const bool h3 = indexed || h3_scores(nq, ndb, dim);
   const int64_t PANEL_ROWS = w.panel;
   if (!workspace || w.bytes > workspace_bytes) {
     set_error("topk: workspace %zu < %zu", workspace_bytes, w.bytes);
@@ -386,12 +416,24 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
     const int64_t pc = std::min<int64_t>(PANEL_ROWS, ndb - c0);
     GemmProblem g{};
     g.tag = "topk_scores_gemm";
+    const float* dn_panel = w.dn + c0;                       // the merge kernel's squared-norm term of the panel's rows (L2)
     if (h3) {
-      // the panel's operand image + its rows' sums of squares (raw: the L2 term; or, normalising, the F.normalize divisor)
+      // the panel's operand image + its rows' sums of squares (raw: the L2 term; or, normalising, the F.normalize divisor):
+      // quantised here, or -- prepared index -- read where anyloc_topk_index_build left them
       const bool want_ss = metric == 1 || norm_db;
-      ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, want_ss ? (norm_db ? w.dss : w.dn) + c0 : nullptr, stream));
+      const unsigned char* dimg = w.dimg;
+      const float* dinv = w.dinv;
+      const float* dss = w.dss + c0;
+      if (indexed) {
+        dimg = iv.img + (size_t)(c0 / iv.panel) * iv.slot;
+        dinv = iv.dinv + c0;
+        dss = iv.dss + c0;
+        if (metric == 1 && !norm_db) dn_panel = dss;
+      } else {
+        ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, want_ss ? (norm_db ? w.dss : w.dn) + c0 : nullptr, stream));
+      }
       if (norm_db) {
-        hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, w.dss + c0, pc, w.dnorm + c0,
+        hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, dss, pc, w.dnorm + c0,
                            w.dn + c0);
         ANYLOC_TRY(launch_status("dbnorm_kernel"));
       }
@@ -405,7 +447,7 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
         for (int64_t kb0 = 0; kb0 < K16; kb0 += KC16) {
           H3Problem h{};
           h.A2 = w.qimg + c * h2_bytes(w.q_chunk, dim) + kb0 * (2 * qc * 32); h.RA = qc; h.a_inv = w.qinv + q0;
-          h.W2 = w.dimg + kb0 * (2 * pc * 32); h.RW = pc; h.w_inv = w.dinv;
+          h.W2 = dimg + kb0 * (2 * pc * 32); h.RW = pc; h.w_inv = dinv;
           h.C = w.scores + q0 * pc; h.ldc = pc;
           h.M = qc; h.N = pc; h.K16 = (int)std::min<int64_t>(KC16, K16 - kb0);
           h.accumulate = kb0 > 0;
@@ -454,7 +496,7 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
     {
       ProfScope prof("topk_merge", stream, 0.0, 4.0 * nq * pc);
       hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.scores, pc, pc,
-                         index_base + c0, (int)k, metric, w.qn, w.dn + c0, norm_db ? w.dnorm + c0 : (const float*)nullptr, dist,
+                         index_base + c0, (int)k, metric, w.qn, dn_panel, norm_db ? w.dnorm + c0 : (const float*)nullptr, dist,
                          idx_ll, first);
       ANYLOC_TRY(launch_status("topk_merge_kernel"));
     }
@@ -464,6 +506,51 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
   hipLaunchKernelGGL(topk_finish_kernel, dim3((unsigned)((nq * k + 255) / 256)), dim3(256), 0, stream, dist, idx_ll,
                      nq * k, metric);
   return launch_status("topk_finish_kernel");
+}
+
+extern "C" {
+
+int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, int64_t dim, int64_t k, int metric,
+                unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
+                void* stream) {
+  return topk_impl(queries, nq, db, ndb, dim, k, metric, flags, index_base, dist, idx, workspace, workspace_bytes, nullptr,
+                   static_cast<hipStream_t>(stream));
+}
+
+size_t anyloc_topk_index_bytes(int64_t ndb, int64_t dim) {
+  return index_supported(ndb, dim) ? index_view(nullptr, ndb, dim).bytes + 256 : 0;
+}
+
+int anyloc_topk_index_build(const float* db, int64_t ndb, int64_t dim, void* index, size_t index_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ANYLOC_CHECK_ARG(db && index && ndb > 0, "topk_index_build: null pointer / empty database");
+  if (!index_supported(ndb, dim)) {
+    set_error("topk_index_build: dim %lld is not served by the fp16 score panels", (long long)dim);
+    return ANYLOC_ERR_UNSUPPORTED;
+  }
+  const IndexView iv = index_view(index, ndb, dim);
+  if (iv.bytes > index_bytes) {
+    set_error("topk_index_build: index buffer %zu < %zu", index_bytes, iv.bytes);
+    return ANYLOC_ERR_WORKSPACE;
+  }
+  for (int64_t c0 = 0; c0 < ndb; c0 += iv.panel) {
+    const int64_t pc = std::min<int64_t>(iv.panel, ndb - c0);
+    ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, iv.img + (size_t)(c0 / iv.panel) * iv.slot, iv.dinv + c0, iv.dss + c0, stream));
+  }
+  return ANYLOC_OK;
+}
+
+size_t anyloc_topk_index_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k) {
+  (void)k;
+  return index_supported(ndb, dim) ? carve(nullptr, 0, nq, ndb, dim, true).bytes + 256 : 0;
+}
+
+int anyloc_topk_search_index(const float* queries, int64_t nq, const void* index, int64_t ndb, int64_t dim, int64_t k, int metric,
+                             unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  ANYLOC_CHECK_ARG(index && index_supported(ndb, dim), "topk_search_index: no index / shape not served by the fp16 score panels");
+  return topk_impl(queries, nq, nullptr, ndb, dim, k, metric, flags, index_base, dist, idx, workspace, workspace_bytes, index,
+                   static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

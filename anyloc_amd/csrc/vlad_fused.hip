@@ -449,7 +449,8 @@ __device__ __forceinline__ void f3_store_cols(__amdgpu_buffer_rsrc_t rsrc, unsig
 // GV (hazard study, round 6; option vlad_gather_v, D = 1536 VLAD mode only): 0 = the shipped gather arithmetic (mul, sub, select);
 // 1 = the round-5 form that was NOT reproducible run to run (one fma + select); 2 / 3 / 4 = 1 with `s_nop 3` behind
 // s_set_gpr_idx_on / in front of s_set_gpr_idx_off / behind it; 5 = all three; 7 = 1 with the compiler's own lowering of the
-// dynamic subscript; 8 = 1 with LLVM's usage pattern in our asm (indexed v_mov out, plain adds, indexed v_mov back)
+// dynamic subscript; 8 = 1 with LLVM's usage pattern in our asm (indexed v_mov out, plain adds, indexed v_mov back); 9 = 1 with the
+// accumulator read through src1 (mode 0xA); 10 / 11 = 2 with `s_nop 0` / `s_nop 1` (how many wait states the switch needs)
 template <int NV, int SW, bool KMEANS, int GV = 0>
 __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   constexpr int D = NV * 128;
@@ -602,16 +603,16 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   // (register-indexed access to the accumulators of a RUNTIME cluster id, wave-uniform in an SGPR: the epilogue and the fold)
   auto acc_get = [&](int k, float (&v)[CW]) {
     if constexpr (CW == 1) {
-      asm volatile("s_set_gpr_idx_on %1, 0x1\n\tv_mov_b32 %0, v224\n\ts_set_gpr_idx_off" : "=&v"(v[0]) : "s"(k), "{v[224:255]}"(acc[0]));
+      asm volatile("s_set_gpr_idx_on %1, 0x1\n\ts_nop 3\n\tv_mov_b32 %0, v224\n\ts_set_gpr_idx_off" : "=&v"(v[0]) : "s"(k), "{v[224:255]}"(acc[0]));
     } else if constexpr (CW == 2) {
-      asm volatile("s_set_gpr_idx_on %2, 0x1\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v224\n\ts_set_gpr_idx_off"
+      asm volatile("s_set_gpr_idx_on %2, 0x1\n\ts_nop 3\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v224\n\ts_set_gpr_idx_off"
                    : "=&v"(v[0]), "=&v"(v[1]) : "s"(k), "{v[192:223]}"(acc[0]), "{v[224:255]}"(acc[1]));
     } else if constexpr (CW == 3) {
-      asm volatile("s_set_gpr_idx_on %3, 0x1\n\tv_mov_b32 %0, v160\n\tv_mov_b32 %1, v192\n\tv_mov_b32 %2, v224\n\ts_set_gpr_idx_off"
+      asm volatile("s_set_gpr_idx_on %3, 0x1\n\ts_nop 3\n\tv_mov_b32 %0, v160\n\tv_mov_b32 %1, v192\n\tv_mov_b32 %2, v224\n\ts_set_gpr_idx_off"
                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
                    : "s"(k), "{v[160:191]}"(acc[0]), "{v[192:223]}"(acc[1]), "{v[224:255]}"(acc[2]));
     } else if constexpr (CW == 4) {
-      asm volatile("s_set_gpr_idx_on %4, 0x1\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v160\n\tv_mov_b32 %2, v192\n\tv_mov_b32 %3, v224\n\t"
+      asm volatile("s_set_gpr_idx_on %4, 0x1\n\ts_nop 3\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v160\n\tv_mov_b32 %2, v192\n\tv_mov_b32 %3, v224\n\t"
                    "s_set_gpr_idx_off"
                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                    : "s"(k), "{v[128:159]}"(acc[0]), "{v[160:191]}"(acc[1]), "{v[192:223]}"(acc[2]), "{v[224:255]}"(acc[3]));
@@ -621,16 +622,16 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
   };
   auto acc_set = [&](int k, const float (&v)[CW]) {
     if constexpr (CW == 1) {
-      asm volatile("s_set_gpr_idx_on %2, 0x8\n\tv_mov_b32 v224, %1\n\ts_set_gpr_idx_off" : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
+      asm volatile("s_set_gpr_idx_on %2, 0x8\n\ts_nop 3\n\tv_mov_b32 v224, %1\n\ts_set_gpr_idx_off" : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
     } else if constexpr (CW == 2) {
-      asm volatile("s_set_gpr_idx_on %4, 0x8\n\tv_mov_b32 v192, %2\n\tv_mov_b32 v224, %3\n\ts_set_gpr_idx_off"
+      asm volatile("s_set_gpr_idx_on %4, 0x8\n\ts_nop 3\n\tv_mov_b32 v192, %2\n\tv_mov_b32 v224, %3\n\ts_set_gpr_idx_off"
                    : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
     } else if constexpr (CW == 3) {
-      asm volatile("s_set_gpr_idx_on %6, 0x8\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
+      asm volatile("s_set_gpr_idx_on %6, 0x8\n\ts_nop 3\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
                    : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
                    : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
     } else if constexpr (CW == 4) {
-      asm volatile("s_set_gpr_idx_on %8, 0x8\n\tv_mov_b32 v128, %4\n\tv_mov_b32 v160, %5\n\tv_mov_b32 v192, %6\n\tv_mov_b32 v224, %7\n\t"
+      asm volatile("s_set_gpr_idx_on %8, 0x8\n\ts_nop 3\n\tv_mov_b32 v128, %4\n\tv_mov_b32 v160, %5\n\tv_mov_b32 v192, %6\n\tv_mov_b32 v224, %7\n\t"
                    "s_set_gpr_idx_off"
                    : "+{v[128:159]}"(acc[0]), "+{v[160:191]}"(acc[1]), "+{v[192:223]}"(acc[2]), "+{v[224:255]}"(acc[3])
                    : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k));
@@ -820,10 +821,10 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
       auto add_token = [&](int k, const float* v) {
         if (k < 0) return;
         if constexpr (CW == 1) {
-          asm volatile("s_set_gpr_idx_on %2, 0x9\n\tv_add_f32 v224, v224, %1\n\ts_set_gpr_idx_off"
+          asm volatile("s_set_gpr_idx_on %2, 0x9\n\ts_nop 3\n\tv_add_f32 v224, v224, %1\n\ts_set_gpr_idx_off"
                        : "+{v[224:255]}"(acc[0]) : "v"(v[0]), "s"(k));
         } else if constexpr (CW == 2) {
-          asm volatile("s_set_gpr_idx_on %4, 0x9\n\tv_add_f32 v192, v192, %2\n\tv_add_f32 v224, v224, %3\n\ts_set_gpr_idx_off"
+          asm volatile("s_set_gpr_idx_on %4, 0x9\n\ts_nop 3\n\tv_add_f32 v192, v192, %2\n\tv_add_f32 v224, v224, %3\n\ts_set_gpr_idx_off"
                        : "+{v[192:223]}"(acc[0]), "+{v[224:255]}"(acc[1]) : "v"(v[0]), "v"(v[1]), "s"(k));
         } else if constexpr (CW == 3 && GV == 7) {
           static_for<CW>([&](auto j) { acc[j][(int)k] += v[j]; });
@@ -836,7 +837,13 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
           asm volatile("s_set_gpr_idx_on %6, 0x8\n\tv_mov_b32 v160, %3\n\tv_mov_b32 v192, %4\n\tv_mov_b32 v224, %5\n\ts_set_gpr_idx_off"
                        : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
                        : "v"(t0), "v"(t1), "v"(t2), "s"(k));
-        } else if constexpr (CW == 3 && GV >= 2 && GV <= 5) {
+        } else if constexpr (CW == 3 && GV == 9) {
+          // the accumulator read through src1 (mode 0xA = SRC1_REL | DST_REL) instead of src0
+          asm volatile("s_set_gpr_idx_on %6, 0xa\n\tv_add_f32 v160, %3, v160\n\tv_add_f32 v192, %4, v192\n\t"
+                       "v_add_f32 v224, %5, v224\n\ts_set_gpr_idx_off"
+                       : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
+        } else if constexpr (CW == 3 && ((GV >= 2 && GV <= 5) || GV == 10 || GV == 11)) {
 #define ANYLOC_GV_ASM(PRE, MID, POST)                                                                                  \
   asm volatile("s_set_gpr_idx_on %6, 0x9\n\t" PRE "v_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"             \
                "v_add_f32 v224, v224, %5\n\t" MID "s_set_gpr_idx_off" POST                                             \
@@ -845,15 +852,23 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
           if constexpr (GV == 2) ANYLOC_GV_ASM("s_nop 3\n\t", "", "");
           else if constexpr (GV == 3) ANYLOC_GV_ASM("", "s_nop 3\n\t", "");
           else if constexpr (GV == 4) ANYLOC_GV_ASM("", "", "\n\ts_nop 3");
+          else if constexpr (GV == 10) ANYLOC_GV_ASM("s_nop 0\n\t", "", "");
+          else if constexpr (GV == 11) ANYLOC_GV_ASM("s_nop 1\n\t", "", "");
           else ANYLOC_GV_ASM("s_nop 3\n\t", "s_nop 3\n\t", "\n\ts_nop 3");
 #undef ANYLOC_GV_ASM
-        } else if constexpr (CW == 3) {
+        } else if constexpr (CW == 3 && GV == 1) {
+          // (hazard study: NO wait state behind the mode switch -- with the one-fma residual this is the irreproducible form)
           asm volatile("s_set_gpr_idx_on %6, 0x9\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
                        "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
                        : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
                        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
+        } else if constexpr (CW == 3) {
+          asm volatile("s_set_gpr_idx_on %6, 0x9\n\ts_nop 3\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
+                       "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
+                       : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(k));
         } else if constexpr (CW == 4) {
-          asm volatile("s_set_gpr_idx_on %8, 0x9\n\tv_add_f32 v128, v128, %4\n\tv_add_f32 v160, v160, %5\n\t"
+          asm volatile("s_set_gpr_idx_on %8, 0x9\n\ts_nop 3\n\tv_add_f32 v128, v128, %4\n\tv_add_f32 v160, v160, %5\n\t"
                        "v_add_f32 v192, v192, %6\n\tv_add_f32 v224, v224, %7\n\ts_set_gpr_idx_off"
                        : "+{v[128:159]}"(acc[0]), "+{v[160:191]}"(acc[1]), "+{v[192:223]}"(acc[2]), "+{v[224:255]}"(acc[3])
                        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k));
@@ -923,12 +938,15 @@ __global__ __launch_bounds__(64 * SW) void fused3_kernel(FusedArgs a) {
             if (p2 + 1 < TG / 2) read_pair(buf ^ 1, p2 + 1);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              // A row past the unit (label -1) adds an exact zero to cluster 0 -- a select, not a branch: with the branch form
-              // (add_token skipped under `k < 0`) and with a fused multiply-add here, the launch was NOT reproducible run to
-              // run on 300+ images (rates 1e-3 ... 1e-1 of the images; tools/stress_vlad.py, profiles/r05_vlad_stress_bisect.log;
-              // bisected over library builds, cause not found in the ISA: waits and registers are right).  This form and k-means
-              // mode's are reproducible over 40 000 image-runs; tests/test_gpu_vlad_topk.py::test_vlad_reproducible_under_load
-              // keeps watching.
+              // A row past the unit (label -1) adds an exact zero to cluster 0 -- a select, not a branch.  Round 5 found two
+              // forms of this gather (a fused multiply-add here; the branch form of add_token) NOT reproducible run to run, and
+              // shipped whichever arithmetic passed the stress.  Round 6 found the mechanism (DESIGN.md 4.3,
+              // profiles/r06_vlad_gather_hazard.log, tools/micro/gpr_idx_hazard.hip): in GPR-index mode the first indexed VALU
+              // behind s_set_gpr_idx_on can execute before the mode switch has taken effect unless wait states separate them --
+              // `s_nop 3` behind the switch makes the fma form bitwise reproducible too, idle issue slots IN FRONT of the switch
+              // make every image wrong.  Every s_set_gpr_idx_on of this file is followed by `s_nop 3` now; the arithmetic stays
+              // mul, sub, select (the bits of rounds 3-5).  tests/test_gpu_vlad_topk.py::test_vlad_reproducible_under_load and
+              // tests/test_gpu_round6.py::test_gather_hazard_variants_of_the_one_pass_vlad_kernel keep watching.
               const int k = kk[2 * p2 + e];
 #pragma unroll
               for (int j = 0; j < CW; ++j) {
@@ -1097,6 +1115,9 @@ int launch_fused3(const FusedArgs& a, int64_t units, hipStream_t stream) {
       case 5: return launch_fused3<NV, SW, KMEANS, 5>(a, units, stream);
       case 7: return launch_fused3<NV, SW, KMEANS, 7>(a, units, stream);
       case 8: return launch_fused3<NV, SW, KMEANS, 8>(a, units, stream);
+      case 9: return launch_fused3<NV, SW, KMEANS, 9>(a, units, stream);
+      case 10: return launch_fused3<NV, SW, KMEANS, 10>(a, units, stream);
+      case 11: return launch_fused3<NV, SW, KMEANS, 11>(a, units, stream);
       default: break;
     }
   }

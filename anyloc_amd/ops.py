@@ -431,6 +431,44 @@ def topk(queries, db, k, metric="ip", index_base=0, normalize_db=False):
     return dist, idx
 
 
+def topk_index_bytes(ndb, dim):
+    """Bytes of the prepared database side of ``topk`` (0: shape not served by the fp16 score panels)."""
+    return int(_lib.load().anyloc_topk_index_bytes(int(ndb), int(dim)))
+
+
+def topk_index_build(db):
+    """faiss' ``index.add(db)``: the database rows as the two-plane fp16 operand images of the score GEMM + row scales + sums
+    of squares, built once (anyloc_topk_index_build) -> uint8 device tensor for ``topk_indexed``.  dim % 16 == 0."""
+    _need_cuda(db)
+    db = _f32c(db)
+    ndb, dim = db.shape
+    nbytes = topk_index_bytes(ndb, dim)
+    if nbytes == 0:
+        raise ValueError(f"topk_index_build: a [{ndb}, {dim}] database is not served by the fp16 score panels (dim % 16)")
+    index = torch.empty(nbytes, dtype=torch.uint8, device=db.device)
+    _lib.check(_lib.load().anyloc_topk_index_build(_lib.ptr(db), ndb, dim, _lib.ptr(index), index.numel(), _lib.stream_ptr()),
+               "anyloc_topk_index_build")
+    return index
+
+
+def topk_indexed(queries, index, ndb, k, metric="ip", index_base=0, normalize_db=False):
+    """``topk`` against a database prepared by ``topk_index_build`` (same results; the fp32 rows are not read)."""
+    _need_cuda(queries, index)
+    queries = _f32c(queries)
+    if not 1 <= int(k) <= 1024:
+        raise ValueError(f"k={k} outside [1, 1024] (candidate lists are merged in LDS)")
+    nq, dim = queries.shape
+    dist = torch.empty(nq, k, dtype=torch.float32, device=queries.device)
+    idx = torch.empty(nq, k, dtype=torch.int64, device=queries.device)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.anyloc_topk_index_workspace_bytes(nq, ndb, dim, k), queries.device, "topk")
+    _lib.check(lib.anyloc_topk_search_index(_lib.ptr(queries), nq, _lib.ptr(index), int(ndb), dim, k,
+                                            0 if metric == "ip" else 1, TOPK_NORMALIZE_DB if normalize_db else 0, index_base,
+                                            _lib.ptr(dist), _lib.ptr(idx), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+               "anyloc_topk_search_index")
+    return dist, idx
+
+
 # ---- tuning options (anyloc_set_option; names in include/anyloc_hip.h) ----------------
 def set_option(name, value):
     _lib.check(_lib.load().anyloc_set_option(name.encode(), int(value)), f"anyloc_set_option({name})")

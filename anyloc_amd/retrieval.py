@@ -30,8 +30,63 @@ def recalls_from_indices(top_k, indices, gt_pos, use_percentage=True, sub_sample
     return recalls
 
 
+FEW_QUERIES = 64          # at most this many queries stream the fp32 database once (anyloc_topk's few-query path)
+
+
+class FlatIndex:
+    """The flat index of ``get_top_k_recall`` kept between searches -- faiss' ``index.add(db)`` (reference
+    ``utilities.py:441-442, :446-447``) apart from ``index.search(qu, k)`` (``:450``).  ``get_top_k_recall`` builds and
+    drops its index per call, as the reference does; a caller that searches ONE database several times (a resident shard
+    of the sharded search, the own-queries / other-ranks'-queries halves of an overlapped step) builds a ``FlatIndex``
+    once: the rows as the two-plane fp16 operand images of the score GEMM + their scales and sums of squares
+    (``anyloc_topk_index_build``; 4 bytes per element, the size of the fp32 rows), which every later search of more than
+    ``FEW_QUERIES`` queries reads instead of re-quantising the database panel by panel (14 ms of a 320 ms retrieval on a
+    125 000 x 49 152 shard).  Results are those of ``search`` bit for bit (same kernels, same operands).
+
+    ``planes``: "auto" builds the images when the shape is served (dim % 16 == 0) and the device has the memory to spare,
+    True insists, False never (every search quantises on the fly, as ``search``).  ``keep_fp32=False`` drops the reference
+    to the fp32 rows once the images exist (searches of <= FEW_QUERIES queries then also run on the panels)."""
+
+    def __init__(self, db, method="cosine", norm_descs=True, planes="auto", keep_fp32=True):
+        if method not in ("cosine", "l2"):
+            raise NotImplementedError(f"Method: {method}")
+        dev = _lib.require_gpu()
+        self.method, self.norm_descs = method, bool(norm_descs)
+        self.db = ops._f32c(torch.as_tensor(db), dev)
+        self.ntotal, self.dim = int(self.db.shape[0]), int(self.db.shape[1])
+        self.planes = None
+        nbytes = ops.topk_index_bytes(self.ntotal, self.dim) if self.ntotal else 0
+        if planes == "auto":
+            planes = nbytes > 0 and torch.cuda.mem_get_info(dev)[0] > nbytes + (8 << 30)
+        if planes:
+            self.planes = ops.topk_index_build(self.db)
+            if not keep_fp32:
+                self.db = None
+
+    @property
+    def has_planes(self):
+        return self.planes is not None
+
+    def search(self, qu, k):
+        """(dist, idx) device tensors of the top ``k`` rows for every query (``index.search``)."""
+        dev = _lib.require_gpu()
+        qu_d = ops._f32c(torch.as_tensor(qu), dev)
+        if qu_d.dim() == 1:
+            qu_d = qu_d.unsqueeze(0)
+        if self.norm_descs:
+            qu_d = ops.l2norm_rows(qu_d)
+        metric = "ip" if self.method == "cosine" else "l2"
+        if self.planes is not None and (qu_d.shape[0] > FEW_QUERIES or self.db is None):
+            return ops.topk_indexed(qu_d, self.planes, self.ntotal, int(k), metric, normalize_db=self.norm_descs)
+        return ops.topk(qu_d, self.db, int(k), metric, normalize_db=self.norm_descs)
+
+
 def search(db, qu, k, method="cosine", norm_descs=True):
-    """Normalise (optionally) and search: returns device tensors (dist, idx)."""
+    """Normalise (optionally) and search: returns device tensors (dist, idx).  ``db``: the rows, or a ``FlatIndex``."""
+    if isinstance(db, FlatIndex):
+        if (db.method, db.norm_descs) != (method, bool(norm_descs)):
+            raise ValueError(f"FlatIndex built for ({db.method}, norm_descs={db.norm_descs}), searched with ({method}, {norm_descs})")
+        return db.search(qu, k)
     dev = _lib.require_gpu()
     db_d, qu_d = ops._f32c(db, dev), ops._f32c(qu, dev)
     if method == "cosine":
@@ -121,7 +176,7 @@ def gather_rows(local, counts, rank, group, comm):
 
 
 def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_descs=True,
-                   group=None, search_fn=None, counts=None, timings=None):
+                   group=None, search_fn=None, counts=None, timings=None, overlap="auto"):
     """Database-sharded retrieval, one process per GPU.
 
     Every rank owns ``db_shard`` (rows ``shard_base ...`` of the global database)
@@ -134,7 +189,13 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
     shares, as in bench.py) -- saves the per-call all-gather of the counts and its host sync.  ``timings`` (optional dict):
     an INSTRUMENTED call -- the device is drained after every leg and the legs' wall times land in it as
     ``all_gather_ms`` / ``search_ms`` / ``gather_ms`` / ``merge_ms`` (bench.py reports them from an untimed step; the
-    timed steps run without the drains)."""
+    timed steps run without the drains).
+
+    ``db_shard`` may be a ``FlatIndex`` (the resident shard prepared once).  ``overlap`` (round 6): the rank's OWN queries
+    are searched while the all-gather of the others' is in flight (``async_op``: RCCL runs it on its own stream over xGMI)
+    and the rest afterwards -- two searches over the shard instead of one, so it pays only where a second pass costs no
+    second quantisation of the database: "auto" = when ``db_shard`` is a ``FlatIndex`` with prepared planes, the shares
+    are equal (one ``all_gather_into_tensor``) and the call is not an instrumented one.  Same lists either way."""
     import time
 
     import torch.distributed as dist
@@ -162,15 +223,36 @@ def sharded_search(db_shard, shard_base, qu_local, k, method="cosine", norm_desc
             raise ValueError(f"counts must list every rank's query rows: got {counts} for world size {world}, "
                              f"rank {rank} holds {qu_local.shape[0]} rows")
     t0 = lap("setup_ms", time.perf_counter()) if timings is not None else 0.0
-    qu_all = gather_rows(qu_local, counts, rank, group, comm)
-    if qu_all.device != qu_local.device:
-        qu_all = qu_all.to(qu_local.device)
-    t0 = lap("all_gather_ms", t0)
-    if search_fn is None:
-        d, i = search(db_shard, qu_all, k, method, norm_descs)
-        i = torch.where(i >= 0, i + shard_base, i)
+
+    def run_search(q):
+        if search_fn is None:
+            dd, ii = search(db_shard, q, k, method, norm_descs)
+            return dd, torch.where(ii >= 0, ii + shard_base, ii)
+        return search_fn(db_shard, q, k, method, norm_descs, shard_base)
+    equal = len(set(counts)) == 1 and counts[0] > 0
+    if overlap == "auto":
+        overlap = isinstance(db_shard, FlatIndex) and db_shard.has_planes and timings is None
+    if overlap and equal and world > 1:
+        # own queries against the shard while the others' rows travel; then the rest, in rank order around the own block
+        own = counts[rank]
+        qu_all = torch.empty(sum(counts), qu_local.shape[1], dtype=torch.float32, device=comm)
+        src = qu_local.to(comm, torch.float32).contiguous()
+        work = dist.all_gather_into_tensor(qu_all, src, group=group, async_op=True)
+        d_own, i_own = run_search(qu_local)
+        work.wait()
+        if qu_all.device != qu_local.device:
+            qu_all = qu_all.to(qu_local.device)
+        lo, hi = rank * own, (rank + 1) * own
+        rest = torch.cat([qu_all[:lo], qu_all[hi:]])
+        d_r, i_r = run_search(rest)
+        d = torch.cat([d_r[:lo], d_own.to(d_r.dtype), d_r[lo:]])
+        i = torch.cat([i_r[:lo], i_own.to(i_r.dtype), i_r[lo:]])
     else:
-        d, i = search_fn(db_shard, qu_all, k, method, norm_descs, shard_base)
+        qu_all = gather_rows(qu_local, counts, rank, group, comm)
+        if qu_all.device != qu_local.device:
+            qu_all = qu_all.to(qu_local.device)
+        t0 = lap("all_gather_ms", t0)
+        d, i = run_search(qu_all)
     t0 = lap("search_ms", t0)
     # ONE gather for both lists: the fp32 distances ride as their bit patterns next to the int64 indices
     packed = torch.cat([d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64), i.to(torch.int64)], dim=1).to(comm)

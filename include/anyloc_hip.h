@@ -331,6 +331,21 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb,
                 float* dist, int64_t* idx, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ABI 8: the database side prepared ONCE -- faiss' `index.add(db)` (utilities.py:441-442 / :446-447) apart from
+ * `index.search(qu, k)` (:450).  anyloc_topk quantises every 8192-row database panel into the two-plane fp16 operand image of
+ * its score GEMM on EVERY call (two reads + one write of the database: 14 ms of a 320 ms retrieval on a 125 000 x 49 152
+ * shard); a caller that searches one database several times builds those images, the rows' power-of-two scales and their
+ * sums of squares once into its own buffer (anyloc_topk_index_bytes: 4 bytes per element -- the size of the fp32 rows, which
+ * the search no longer touches) and passes it to anyloc_topk_search_index: same arguments and results as anyloc_topk (the
+ * same score kernels on the same operands: bit-identical lists), every query count on the fp16 panels.  dim % 16 == 0;
+ * anyloc_topk_index_bytes returns 0 for a shape the panels do not serve (use anyloc_topk). */
+size_t anyloc_topk_index_bytes(int64_t ndb, int64_t dim);
+int anyloc_topk_index_build(const float* db, int64_t ndb, int64_t dim, void* index, size_t index_bytes, void* stream);
+size_t anyloc_topk_index_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k);
+int anyloc_topk_search_index(const float* queries, int64_t nq, const void* index, int64_t ndb, int64_t dim, int64_t k,
+                             int metric, unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- ViT ----
  * DINOv2 ViT forward with early exit at the last tapped layer.
  * replaces: DinoV2ExtractFeatures.__call__, utilities.py:263-285 (the hub

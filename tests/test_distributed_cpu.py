@@ -64,6 +64,29 @@ def _search_job(rank, world, out_dir):
     assert {"all_gather_ms", "search_ms", "gather_ms"} <= set(legs) and all(v >= 0 for v in legs.values())
     if rank == 0:
         assert np.array_equal(i2, faiss_flat.flat_search(qu, db, 10, "ip")[1].numpy()) and "merge_ms" in legs
+    # the overlapped step (round 6): equal shares, the rank's own queries searched while the others' rows are in flight, the
+    # rest afterwards -- the lists of the plain step, in the global query order
+    qu2 = torch.nn.functional.normalize(torch.randn(12, 24, generator=g))
+    calls = []
+
+    def counting_search(db_s, q_all, k, method, norm, base):
+        calls.append(int(q_all.shape[0]))
+        return search_fn(db_s, q_all, k, method, norm, base)
+    for method in ("cosine", "l2"):
+        del calls[:]
+        d3, i3 = retrieval.sharded_search(shard, bounds[rank], qu2[6 * rank:6 * rank + 6], 10, method=method,
+                                          search_fn=counting_search, counts=[6, 6], overlap=True)
+        assert calls == [6, 6], calls                  # own block first, then the other rank's
+        if rank == 0:
+            d_ref, i_ref = faiss_flat.flat_search(qu2, db, 10, "ip" if method == "cosine" else "l2")
+            assert np.array_equal(i3, i_ref.numpy()), method
+            np.testing.assert_allclose(d3, d_ref.numpy(), atol=1e-5)
+    # (uneven shares fall back to the plain step whatever `overlap` says)
+    del calls[:]
+    d4, i4 = retrieval.sharded_search(shard, bounds[rank], q_loc, 10, search_fn=counting_search, counts=[4, 7], overlap=True)
+    assert calls == [11], calls
+    if rank == 0:
+        assert np.array_equal(i4, faiss_flat.flat_search(qu, db, 10, "ip")[1].numpy())
     # shares that do not describe this rank's rows are refused BEFORE any collective (no assert: survives python -O)
     with pytest.raises(ValueError):
         retrieval.sharded_search(shard, bounds[rank], q_loc, 10, search_fn=search_fn, counts=[5, 6])

@@ -1,0 +1,162 @@
+"""Round 6 (``pytest -m gpu``): the prepared flat index (faiss' ``index.add`` apart from ``index.search``: ABI 8,
+``anyloc_topk_index_build`` / ``anyloc_topk_search_index``), the overlapped sharded step on it, the workspace of a caller's
+workgroups-per-image count, and the gather hazard of the one-pass VLAD kernel."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rows(n, dim, seed, spread=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, dim, generator=g)
+    if spread:
+        x = x * (0.25 + 4.0 * torch.rand(n, 1, generator=g))          # row norms over more than a decade
+    return x
+
+
+@pytest.mark.parametrize("ndb,dim,nq,k", [(9001, 1024, 70, 20), (8192, 512, 300, 5), (20000, 256, 129, 33), (300, 2048, 65, 400)])
+def test_prepared_index_gives_the_lists_of_the_one_shot_search(ndb, dim, nq, k):
+    """``anyloc_topk_search_index`` reads the panels ``anyloc_topk_index_build`` left instead of quantising the database per
+    call: the same score kernels on the same operand images, so distances and indices are those of ``anyloc_topk`` on its fp16
+    panels BIT FOR BIT -- both metrics, normalising or not, a ragged last panel, k beyond the database (-1 padding), an index
+    base -- and identical to a float64 flat search."""
+    from anyloc_amd import ops
+    db, qu = _rows(ndb, dim, 1).to(DEV), _rows(nq, dim, 2).to(DEV)
+    db[7] = db[ndb - 3]                                                # a tie across panels: lower index first
+    index = ops.topk_index_build(db)
+    assert index.numel() == ops.topk_index_bytes(ndb, dim) > 0
+    for metric in ("ip", "l2"):
+        for norm in (False, True):
+            q = ops.l2norm_rows(qu) if norm else qu
+            with ops.options(topk_h3=1):                               # the one-shot search on the same (fp16 panel) path
+                d0, i0 = ops.topk(q, db, k, metric, index_base=11, normalize_db=norm)
+            d1, i1 = ops.topk_indexed(q, index, ndb, k, metric, index_base=11, normalize_db=norm)
+            assert torch.equal(i0, i1), (metric, norm)
+            assert torch.equal(d0, d1), (metric, norm)
+            # against float64
+            dbn = torch.nn.functional.normalize(db.double(), dim=1) if norm else db.double()
+            s = q.double() @ dbn.t()
+            if metric == "l2":
+                s = -((q.double() ** 2).sum(1, keepdim=True) + (dbn ** 2).sum(1)[None] - 2 * s)
+            kk = min(k, ndb)
+            ref = torch.sort(s, dim=1, descending=True, stable=True)
+            got_i = (i1[:, :kk] - 11)
+            same = got_i == ref.indices[:, :kk]
+            # a differing index is a near-tie of the float64 scores
+            alt = torch.gather(s, 1, got_i.clamp_min(0))
+            assert bool((same | ((alt - ref.values[:, :kk]).abs() <= 3e-6 * ref.values[:, :kk].abs().clamp_min(1.0))).all()), (metric, norm)
+            if k > ndb:
+                assert bool((i1[:, ndb:] == -1).all())
+
+
+def test_flat_index_object_serves_few_and_many_queries_and_drops_the_rows():
+    """``retrieval.FlatIndex``: built once, searched several times -- few queries stream the fp32 rows (anyloc_topk's few-query
+    path), many read the prepared planes; ``keep_fp32=False`` serves both from the planes.  All agree with ``retrieval.search``."""
+    from anyloc_amd import retrieval
+    dim = 4096
+    db, qu = _rows(3000, dim, 3).to(DEV), _rows(200, dim, 4).to(DEV)
+    for method in ("cosine", "l2"):
+        ix = retrieval.FlatIndex(db, method, planes=True)
+        assert ix.has_planes and ix.ntotal == 3000
+        for n in (9, 200):
+            d0, i0 = retrieval.search(db, qu[:n], 10, method)
+            d1, i1 = ix.search(qu[:n], 10)
+            assert torch.equal(i0, i1) and float((d0 - d1).abs().max()) <= 2e-6, (method, n)
+            d2, i2 = retrieval.search(ix, qu[:n], 10, method)
+            assert torch.equal(i1, i2) and torch.equal(d1, d2)
+        lean = retrieval.FlatIndex(db, method, planes=True, keep_fp32=False)
+        assert lean.db is None
+        d3, i3 = lean.search(qu[:9], 10)
+        assert torch.equal(i3, retrieval.search(db, qu[:9], 10, method)[1])
+    with pytest.raises(ValueError):
+        retrieval.search(retrieval.FlatIndex(db, "cosine", planes=False), qu, 5, "l2")
+    plain = retrieval.FlatIndex(db, "cosine", planes=False)
+    assert not plain.has_planes and torch.equal(plain.search(qu, 5)[1], retrieval.search(db, qu, 5)[1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from anyloc_amd import retrieval
+        dev = torch.device("cuda", 0)
+        dim = 1024
+        db, qu = _rows(5001, dim, 5), _rows(256, dim, 6)
+        bounds = [0, 2100, 5001]
+        shard = retrieval.FlatIndex(db[bounds[rank]:bounds[rank + 1]].to(dev), "cosine", planes=True)
+        q_loc = qu[128 * rank:128 * (rank + 1)].to(dev)
+        d_ref, i_ref = retrieval.search(db.to(dev), qu.to(dev), 10)
+        for overlap in (True, False, "auto"):
+            d, i = retrieval.sharded_search(shard, bounds[rank], q_loc, 10, counts=[128, 128], overlap=overlap)
+            if rank == 0:
+                assert np.array_equal(i, i_ref.cpu().numpy()), overlap
+                np.testing.assert_allclose(d, d_ref.cpu().numpy(), atol=2e-6)
+        if rank == 0:
+            open(os.path.join(out_dir, "ok"), "w").write("1")
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_sharded_step_on_a_prepared_shard_two_ranks_one_gpu(tmp_path):
+    """The overlapped sharded step (own queries searched while the others' travel, the rest afterwards) on prepared shards with
+    the real kernels: two ranks share cuda:0 over gloo; the merged lists are those of one flat search, with and without overlap."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_vlad_workspace_covers_a_callers_parts_count():
+    """``ops.vlad(parts=p)`` with p above the library's own count for the batch (round 5's advisor finding: the workspace was
+    sized for the library's count): sized by ``anyloc_vlad_workspace_bytes_parts`` now; out-of-range counts are refused in Python."""
+    from anyloc_amd import ops, synth
+    toks = synth.clustered_tokens(300, 529, 1536, n_modes=32, seed=5, noise=0.6, device=DEV)
+    c = 0.8 * synth.clustered_tokens(1, 32, 1536, n_modes=32, seed=3, device=DEV)[0]
+    assert ops.vlad_auto_parts(300, 300 * 529, 1536, 32) == 1
+    with ops.options(vlad_two_pass=1):
+        ref = ops.vlad(toks, c)
+    for p in (8, 3, 64):
+        got = ops.vlad(toks, c, parts=p)
+        assert float(((got - ref).norm(dim=1) / ref.norm(dim=1)).max()) <= 1e-5, p
+    for bad in (-1, 65, 128):
+        with pytest.raises(ValueError):
+            ops.vlad(toks, c, parts=bad)
+
+
+def test_gather_hazard_variants_of_the_one_pass_vlad_kernel():
+    """in GPR-index mode the first indexed VALU behind ``s_set_gpr_idx_on`` needs wait states.  The shipped
+    gather (``s_nop`` behind every mode switch) is bitwise reproducible under load in BOTH residual arithmetics; the variant
+    kept for the record (one fma, no wait state: option vlad_gather_v = 1) is the form round 5 found irreproducible -- it is
+    only reported here, not asserted (a hazard is not obliged to fire)."""
+    from anyloc_amd import ops, synth
+    c = 0.8 * synth.clustered_tokens(1, 32, 1536, n_modes=32, seed=3, device=DEV)[0]
+    toks = synth.clustered_tokens(400, 529, 1536, n_modes=32, seed=11, noise=0.6, device=DEV)
+    with ops.options(vlad_two_pass=1):
+        ref = ops.vlad(toks, c)
+    report = {}
+    for gv in (0, 2, 1):
+        with ops.options(vlad_gather_v=gv):
+            first = ops.vlad(toks, c).clone()
+            differ = sum(int((ops.vlad(toks, c) != first).any(dim=1).sum()) for _ in range(10))
+            wrong = int((((first - ref).norm(dim=1) / ref.norm(dim=1)) > 1e-5).sum())
+        report[gv] = (wrong, differ)
+        if gv != 1:
+            assert (wrong, differ) == (0, 0), report
+    print("gather variants (wrong vs two-pass, differing over 10 repeats):", report)
