@@ -98,6 +98,7 @@ SIGNATURES = {
     "anyloc_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "anyloc_topk": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i64, C.c_int, C.c_uint, c_i64, c_f32p,
                               c_i64p, C.c_void_p, c_sz, C.c_void_p]),
+    "anyloc_topk_path": (C.c_int, [c_i64, c_i64, c_i64]),
     "anyloc_topk_index_bytes": (c_sz, [c_i64, c_i64]),
     "anyloc_topk_index_build": (C.c_int, [c_f32p, c_i64, c_i64, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_topk_index_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),

@@ -517,6 +517,11 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb, 
                    static_cast<hipStream_t>(stream));
 }
 
+int anyloc_topk_path(int64_t nq, int64_t ndb, int64_t dim) {
+  if (nq <= 0 || ndb < 0 || dim < 4 || dim % 4) return -1;
+  return h3_scores(nq, ndb, dim) ? 2 : few_queries(nq, dim) ? 1 : 0;
+}
+
 size_t anyloc_topk_index_bytes(int64_t ndb, int64_t dim) {
   return index_supported(ndb, dim) ? index_view(nullptr, ndb, dim).bytes + 256 : 0;
 }

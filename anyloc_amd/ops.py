@@ -213,14 +213,15 @@ def vlad_auto_parts(n_img, n_tok_total, D, K):
 
 
 def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_temp=1.0,
-         return_labels=False, dist_mode="cosine", parts=0):
+         return_labels=False, dist_mode="cosine", parts=0, out=None):
     """VLAD descriptors of a batch of images.
 
     tokens: device tensor [n_img, N, D] / [N, D], or a list of [N_i, D] tensors.
     centers: [K, D].  ``dist_mode``: the metric of the hard assignment (the VLAD object's ``dist_mode``; the soft
     weights are always cosine, as in the reference).  ``parts`` (hard mode): workgroups per image as the caller's choice
     (ANYLOC_VLAD_PARTS; 0 = the library's) -- a batch handed over in pieces keeps the bits of the one-call result when every
-    piece passes the whole batch's count.  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
+    piece passes the whole batch's count.  ``out``: an [n_img, K*D] fp32 device tensor to fill (a caller that streams a
+    batch in pieces hands over slices of ONE result tensor).  Returns [n_img, K*D] (and int64 labels [total] for hard mode)."""
     device = _lib.require_gpu()
     centers = _f32c(centers, device)
     K, D = centers.shape
@@ -228,7 +229,10 @@ def vlad(tokens, centers, mode="hard", norm_descs=True, intra_norm=True, soft_te
     if n_img and packed.numel() and Dt != D:
         raise ValueError(f"descriptor dim {Dt} != cluster centre dim {D}")
     total = packed.shape[0]
-    out = torch.empty(n_img, K * D, dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty(n_img, K * D, dtype=torch.float32, device=device)
+    elif tuple(out.shape) != (n_img, K * D) or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError(f"vlad: out must be a contiguous fp32 device tensor [{n_img}, {K * D}]")
     labels = torch.empty(total, dtype=torch.int64, device=device) if (return_labels and mode == "hard") else None
     lib = _lib.load()
     if dist_mode not in ("cosine", "euclidean"):

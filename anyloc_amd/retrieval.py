@@ -30,22 +30,21 @@ def recalls_from_indices(top_k, indices, gt_pos, use_percentage=True, sub_sample
     return recalls
 
 
-FEW_QUERIES = 64          # at most this many queries stream the fp32 database once (anyloc_topk's few-query path)
-
-
 class FlatIndex:
     """The flat index of ``get_top_k_recall`` kept between searches -- faiss' ``index.add(db)`` (reference
     ``utilities.py:441-442, :446-447``) apart from ``index.search(qu, k)`` (``:450``).  ``get_top_k_recall`` builds and
     drops its index per call, as the reference does; a caller that searches ONE database several times (a resident shard
     of the sharded search, the own-queries / other-ranks'-queries halves of an overlapped step) builds a ``FlatIndex``
     once: the rows as the two-plane fp16 operand images of the score GEMM + their scales and sums of squares
-    (``anyloc_topk_index_build``; 4 bytes per element, the size of the fp32 rows), which every later search of more than
-    ``FEW_QUERIES`` queries reads instead of re-quantising the database panel by panel (14 ms of a 320 ms retrieval on a
-    125 000 x 49 152 shard).  Results are those of ``search`` bit for bit (same kernels, same operands).
+    (``anyloc_topk_index_build``; 4 bytes per element, the size of the fp32 rows), which every later search that
+    ``anyloc_topk`` would score on its fp16 panels (``anyloc_topk_path``: many queries) reads instead of re-quantising the
+    database panel by panel (14 ms of a 320 ms retrieval on a 125 000 x 49 152 shard); the other shapes (few queries
+    streaming the rows once, small problems on the fp32-MFMA panels) keep their path.  Results are therefore those of
+    ``search`` bit for bit (same kernels, same operands).
 
     ``planes``: "auto" builds the images when the shape is served (dim % 16 == 0) and the device has the memory to spare,
     True insists, False never (every search quantises on the fly, as ``search``).  ``keep_fp32=False`` drops the reference
-    to the fp32 rows once the images exist (searches of <= FEW_QUERIES queries then also run on the panels)."""
+    to the fp32 rows once the images exist (every search then runs on the panels)."""
 
     def __init__(self, db, method="cosine", norm_descs=True, planes="auto", keep_fp32=True):
         if method not in ("cosine", "l2"):
@@ -76,7 +75,8 @@ class FlatIndex:
         if self.norm_descs:
             qu_d = ops.l2norm_rows(qu_d)
         metric = "ip" if self.method == "cosine" else "l2"
-        if self.planes is not None and (qu_d.shape[0] > FEW_QUERIES or self.db is None):
+        if self.planes is not None and (self.db is None or
+                                        _lib.load().anyloc_topk_path(int(qu_d.shape[0]), self.ntotal, self.dim) == 2):
             return ops.topk_indexed(qu_d, self.planes, self.ntotal, int(k), metric, normalize_db=self.norm_descs)
         return ops.topk(qu_d, self.db, int(k), metric, normalize_db=self.norm_descs)
 

@@ -271,7 +271,9 @@ class VLAD:
             # every piece with the workgroups-per-image count of the WHOLE batch: the bits of the one-call result
             if self.vlad_mode == "hard":
                 kw["parts"] = ops.vlad_auto_parts(n, n * multi_query.shape[1], multi_query.shape[2], c.shape[0])
-            out = torch.cat([ops.vlad(multi_query[s:s + step], c, **kw) for s in range(0, n, step)])
+            out = torch.empty(n, c.shape[0] * c.shape[1], dtype=torch.float32, device=c.device)     # ONE result tensor, filled by slices
+            for s in range(0, n, step):
+                ops.vlad(multi_query[s:s + step], c, out=out[s:s + step], **kw)
         else:
             out = ops.vlad(multi_query, c, **kw)
         return ops.to_home(out, home)

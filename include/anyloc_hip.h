@@ -339,6 +339,8 @@ int anyloc_topk(const float* queries, int64_t nq, const float* db, int64_t ndb,
  * the search no longer touches) and passes it to anyloc_topk_search_index: same arguments and results as anyloc_topk (the
  * same score kernels on the same operands: bit-identical lists), every query count on the fp16 panels.  dim % 16 == 0;
  * anyloc_topk_index_bytes returns 0 for a shape the panels do not serve (use anyloc_topk). */
+int anyloc_topk_path(int64_t nq, int64_t ndb, int64_t dim);   /* which scoring path anyloc_topk takes for this shape: 0 = fp32-MFMA
+                                                                  panels, 1 = few queries (database streamed once), 2 = fp16 panels */
 size_t anyloc_topk_index_bytes(int64_t ndb, int64_t dim);
 int anyloc_topk_index_build(const float* db, int64_t ndb, int64_t dim, void* index, size_t index_bytes, void* stream);
 size_t anyloc_topk_index_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k);

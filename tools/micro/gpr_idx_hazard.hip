@@ -5,6 +5,9 @@
 //   B  the same + `s_nop 3` between s_set_gpr_idx_on and the first indexed VALU
 //   C  residual as mul, sub (the shipped arithmetic), no wait state
 //   R  the compiler's own lowering of `acc[j][k] += r` (reference; fma residual)
+//   D  as A with `s_nop 7` IN FRONT of s_set_gpr_idx_on: the wave's issue slots are idle when the switch issues, the first
+//      indexed v_add follows it immediately (inside the library this made EVERY image wrong, profiles/r05_vlad_stress_bisect.log)
+//   E  as D + `s_nop 0` (one wait state) behind the switch
 // Every variant runs REPS times on the same inputs; reported: results that differ bitwise from the variant's first run, and
 // from the reference R (A, B, R compute the same arithmetic; C differs from R by the fma's single rounding only).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/gih tools/micro/gpr_idx_hazard.hip && /tmp/gih [workgroups] [reps]
@@ -65,6 +68,16 @@ __global__ __launch_bounds__(64 * SW) void gather(const float* __restrict__ x, c
                      "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
                      : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
                      : "v"(r[0]), "v"(r[1]), "v"(r[2]), "s"(ks));
+      } else if constexpr (VAR == 4) {
+        asm volatile("s_nop 7\n\ts_set_gpr_idx_on %6, 0x9\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
+                     "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
+                     : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "s"(ks));
+      } else if constexpr (VAR == 5) {
+        asm volatile("s_nop 7\n\ts_set_gpr_idx_on %6, 0x9\n\ts_nop 0\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
+                     "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
+                     : "+{v[160:191]}"(acc[0]), "+{v[192:223]}"(acc[1]), "+{v[224:255]}"(acc[2])
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "s"(ks));
       } else {
         asm volatile("s_set_gpr_idx_on %6, 0x9\n\tv_add_f32 v160, v160, %3\n\tv_add_f32 v192, v192, %4\n\t"
                      "v_add_f32 v224, v224, %5\n\ts_set_gpr_idx_off"
@@ -102,9 +115,10 @@ int main(int argc, char** argv) {
   std::vector<float> ref(nout), first(nout), cur(nout);
   hipLaunchKernelGGL(gather<3>, dim3(wgs), dim3(64 * SW), 0, 0, x, c, l, n, o);
   (void)hipMemcpy(ref.data(), o, nout * 4, hipMemcpyDeviceToHost);
-  const char* names[4] = {"A  fma, no wait state", "B  fma, s_nop 3 behind s_set_gpr_idx_on", "C  mul + sub, no wait state",
-                          "R  compiler lowering (reference)"};
-  for (int var = 0; var < 4; ++var) {
+  const char* names[6] = {"A  fma, no wait state", "B  fma, s_nop 3 behind s_set_gpr_idx_on", "C  mul + sub, no wait state",
+                          "R  compiler lowering (reference)", "D  s_nop 7 in front of the switch, none behind",
+                          "E  s_nop 7 in front, s_nop 0 behind"};
+  for (int var = 0; var < 6; ++var) {
     long differ_first = 0, differ_ref = 0;
     for (int r = 0; r <= reps; ++r) {
       (void)hipMemset(o, 0xff, nout * 4);
@@ -112,6 +126,8 @@ int main(int argc, char** argv) {
       if (var == 1) hipLaunchKernelGGL(gather<1>, dim3(wgs), dim3(64 * SW), 0, 0, x, c, l, n, o);
       if (var == 2) hipLaunchKernelGGL(gather<2>, dim3(wgs), dim3(64 * SW), 0, 0, x, c, l, n, o);
       if (var == 3) hipLaunchKernelGGL(gather<3>, dim3(wgs), dim3(64 * SW), 0, 0, x, c, l, n, o);
+      if (var == 4) hipLaunchKernelGGL(gather<4>, dim3(wgs), dim3(64 * SW), 0, 0, x, c, l, n, o);
+      if (var == 5) hipLaunchKernelGGL(gather<5>, dim3(wgs), dim3(64 * SW), 0, 0, x, c, l, n, o);
       (void)hipMemcpy(cur.data(), o, nout * 4, hipMemcpyDeviceToHost);
       if (r == 0) first = cur;
       for (int w = 0; w < wgs; ++w) {
