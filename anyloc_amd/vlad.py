@@ -247,10 +247,12 @@ class VLAD:
                        f"{self.cache_dir}/{cache_id}_t.pt")
 
     # Descriptors that arrive as ONE CPU tensor (scripts/dino_v2_vlad.py:236-260 hands over [n_img, 529, 1536]: 3.25 MB per image)
-    # go to the device in chunks of ~256 MB: the copy runs at the PCIe rate either way (56 GB/s), but the device buffer of a
-    # chunk is allocated once and reused by the next chunk, where ONE 832 MB buffer for 256 images cost the first call 33 ms
-    # of allocation on top of the 15 ms copy (bench stage script_path_vitg, `generate_multi_legs`)
-    HOST_CHUNK_BYTES = 256 << 20
+    # go to the device in pieces: the copy runs at the PCIe rate either way (56 GB/s), but the device buffer of a piece is
+    # allocated once and reused by the next piece, where ONE 832 MB buffer for 256 images cost the first call 33 ms of
+    # allocation on top of the 15 ms copy.  64 MB since round 6 (256 MB in round 5): the first call of a process 23 - 40 ms and
+    # every later one 22 ms on the probe's box, against 21 - 30 / 40 - 63 ms for 256 MB pieces and 35 - 53 / 33 for 16 MB
+    # (tools/probe_host_staging.py, profiles/r06_host_staging.log); the result rows land in ONE tensor, slice by slice
+    HOST_CHUNK_BYTES = 64 << 20
 
     def _generate_batch(self, multi_query):
         """[n_img,N,D] tensor or list of [N_i,D] -> [n_img, K*D] on the inputs' device."""

@@ -162,3 +162,31 @@ def test_gather_hazard_variants_of_the_one_pass_vlad_kernel():
         if gv != 1:
             assert (wrong, differ) == (0, 0), report
     print("gather variants (wrong vs two-pass, differing over 10 repeats):", report)
+
+
+def test_ffn_telemetry_layouts_agree_on_the_swiglu_epilogue():
+    """The rows' maxima of the fc2 operand image, left by the w12 epilogue as plain-store slots (few rows) or merged by atomicMax
+    (many rows), on the transposed SwiGLU epilogue of ViT-g (one image: the 192 x 128 small-M plan; three images: 64 x 128 tiles)
+    and on the row-major one (option h3_swiglu_t = 0): the same per-(block, image) figures and the same tokens either way."""
+    import utilities
+    from anyloc_amd import ops, synth, weights
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 3, device=DEV, depth=3))
+    try:
+        for swiglu_t in (1, 0):
+            with ops.options(h3_swiglu_t=swiglu_t):
+                ext = utilities.DinoV2ExtractFeatures(name, 2, "token", device=DEV)
+            m = ext.dino_model
+            for batch in (1, 3):
+                img = torch.randn(batch, 3, 322, 322, generator=torch.Generator().manual_seed(40 + batch)).to(DEV)
+                got = {}
+                for layout in (0, 1):
+                    with ops.options(ffn_telem_atomic=layout):
+                        tok = ext(img).clone()
+                        got[layout] = (tok, m._telemetry[:3 * batch].cpu().clone())
+                assert torch.equal(got[0][0], got[1][0]), (swiglu_t, batch)
+                assert torch.equal(got[0][1], got[1][1]), (swiglu_t, batch, got[0][1], got[1][1])
+                fig = got[0][1]
+                assert bool((fig > 1.0).all()) and bool((fig < 2.0 ** 14).all()), fig       # a bound is above the maximum, not wildly
+    finally:
+        weights.unregister_state_dict(name)

@@ -257,25 +257,35 @@ def test_ffn_bound_telemetry_switches_a_loose_block_to_the_exact_quantiser():
     sd["blocks.2.mlp.fc1.weight"] = f1.float()
     sd["blocks.2.mlp.fc1.bias"][7] = float(-c * (d * b).sum())
     weights.register_state_dict(name, {k: v.to(DEV) for k, v in sd.items()})
-    try:
+    from anyloc_amd import ops
+    full = dinov2_ref.DinoVisionTransformer(name)
+    full.blocks = full.blocks[:4]
+    full.load_state_dict(sd, strict=True)
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    ref = dinov2_ref.extract_facet(full.eval(), img, 3, "token")
+
+    def run():
         ext = utilities.DinoV2ExtractFeatures(name, 3, "token", device=DEV)
         assert ext.dino_model.gemm == "h3"
-        img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(2))
         got = ext(img.to(DEV)).cpu()
         m = ext.dino_model
         assert m.ffn_looseness is not None and m.ffn_looseness[2] > ex.FFN_LOOSENESS_MAX, m.ffn_looseness
         assert m.ffn_exact_blocks == {2}, (m.ffn_exact_blocks, m.ffn_looseness)
         assert all(0 < m.ffn_looseness[i] <= ex.FFN_LOOSENESS_MAX for i in (0, 1, 3)), m.ffn_looseness
         assert m.ffn_reruns == 3                                  # every image of the call trips block 2 and was run again
-        full = dinov2_ref.DinoVisionTransformer(name)
-        full.blocks = full.blocks[:4]
-        full.load_state_dict(sd, strict=True)
-        ref = dinov2_ref.extract_facet(full.eval(), img, 3, "token")
         assert float((got - ref).abs().max()) <= 2e-5
         # nothing is sticky (round 6): the next call decides again from its own data and gives the same bits
         again = ext(img.to(DEV)).cpu()
         assert torch.equal(again, got)
         assert m.ffn_reruns == 6 and m.ffn_exact_blocks == {2}
+        return got, m.ffn_looseness.copy()
+    try:
+        # the rows' maxima left as plain-store slots (few rows) / merged by atomicMax (many rows): the same figures and bits
+        with ops.options(ffn_telem_atomic=0):
+            a = run()
+        with ops.options(ffn_telem_atomic=1):
+            b = run()
+        assert torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     finally:
         weights.unregister_state_dict(name)
 
