@@ -96,7 +96,6 @@ enum Option {
   OPT_ATTN_H3_QG,        // attention_h3: 32-query groups per wave, 1 (four waves of 32 queries, default) or 2 (two waves of 64: A/B)
   OPT_ATTN_H3_KS,        // attention_h3: key splits across the waves of a workgroup, 0 = by grid size (2 when all workgroups are resident), 1, 2
   OPT_VLAD_GATHER_V,     // one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the hazard study (0 = shipped)
-  OPT_FFN_TELEM_ATOMIC,  // FFN-bound telemetry: -1 = plain-store slots while their array stays small (few rows), atomicMax beyond; 0 / 1 force
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -260,12 +259,9 @@ struct H3Problem {
   unsigned char* qkv_planes; float* qkv_inv; int heads; int64_t groups;
   // EPI_GELU_H2 / EPI_SWIGLU_H2: output image (RC rows) quantised with the given per-row 2^-e (c_inv[row])
   unsigned char* C2; int64_t RC; const float* c_inv;
-  // FFN-bound telemetry (optional): bits of the largest scaled magnitude per row of the output image.  c_max_slots = 0: ONE word
-  // per row, c_max[row], merged by atomicMax (many rows: the words spread over the memory channels); c_max_slots = N / 64: one
-  // word per (64-column slot of the GEMM's N, row), c_max[slot * RC + row], written by plain stores -- few rows (one image: 530
-  // words = one or two channels) would serialise every device-scope atomic of a launch behind each other (measured: +390 us
-  // per w12 launch at B = 1, profiles/r06_ffn_telemetry_atomics_b1.md)
-  unsigned* c_max; int c_max_slots;
+  // FFN-bound telemetry (optional): c_max[row] = bits of the largest scaled magnitude the row holds in the output image, merged by
+  // atomicMax (one per row and wave: +0.09 ms per one-image ViT-g forward, lost in the noise of a batched one)
+  unsigned* c_max;
   const char* tag;
 };
 
@@ -300,10 +296,7 @@ int qkv_planes_from_f32(const float* qkv, int64_t rows, int D, int heads, unsign
 // FFN-bound telemetry: rowmax [nblocks][M] = bits of the largest scaled magnitude every row of a block's fc2 operand image holds
 // (atomicMax by the fc1 / w12 epilogue, zero = block not run fused) -> out[l * groups + g] = max over the rows of group g
 // (rows_per_group consecutive rows: an image, or all M) of 2^15 / rowmax; 0 for a block that left no maxima
-// slots > 0: rowmax is [nblocks][slots][M] (plain-store mode of H3Problem::c_max); fused_mask: bit l set = block l ran fused (the
-// others report 0 without their words being read)
-int ffn_looseness(const unsigned* rowmax, int nblocks, int64_t M, int64_t rows_per_group, int slots, const uint64_t fused_mask[4],
-                  float* out, hipStream_t stream);
+int ffn_looseness(const unsigned* rowmax, int nblocks, int64_t M, int64_t rows_per_group, float* out, hipStream_t stream);
 int gemm_h3(const H3Problem& p, int epilogue, hipStream_t stream);
 // small-M plans (gemm_h3s.hip): GEMMs of fewer than ~2 workgroups of 128 x 256 per CU -- one or a few images per call
 enum { H3_KIND_OTHER = 0, H3_KIND_QKV = 1, H3_KIND_PROJ = 2, H3_KIND_FC1 = 3, H3_KIND_FC2 = 4 };

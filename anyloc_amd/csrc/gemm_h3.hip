@@ -389,27 +389,18 @@ __global__ __launch_bounds__(64) void layernorm_h2_direct_kernel(const float* __
 // magnitude the row holds in the fc2 operand image (atomicMax of the bit patterns, gemm_h3_kernel.hpp); a bound that is 2^L
 // above the row's real maximum shows as 2^(15 - L).  One workgroup per (block, row group): out = max over the group's rows of
 // 2^15 / max (a row that left nothing nonzero lies more than 2^39 below its bound, or is exactly zero -- a token row of an
-// FFN activation is never that: reported as 2^40).  Two layouts (H3Problem::c_max): one word per row merged by atomicMax, or
-// `slots` words per row written by plain stores (few rows).  A block whose bit is clear in the mask did not run fused: 0.
+// FFN activation is never that: reported as 2^40); a block none of whose rows left a maximum did not run fused: 0.
 __global__ __launch_bounds__(256) void ffn_looseness_kernel(const unsigned* __restrict__ rowmax, int64_t M, int64_t rpg, int groups,
-                                                            int slots, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3,
                                                             float* __restrict__ out) {
   __shared__ float red[4];
   __shared__ unsigned any[4];
   const int l = blockIdx.x / groups, g = blockIdx.x % groups;
-  const uint64_t mw = l < 64 ? m0 : l < 128 ? m1 : l < 192 ? m2 : m3;
-  if (!((mw >> (l & 63)) & 1ull)) {                        // the block did not run fused: nothing was left for it
-    if (threadIdx.x == 0) out[blockIdx.x] = 0.0f;
-    return;
-  }
-  const int ns = slots > 0 ? slots : 1;
-  const unsigned* rm = rowmax + (int64_t)l * ns * M;
+  const unsigned* rm = rowmax + (int64_t)l * M;
   const int64_t r0 = (int64_t)g * rpg, r1 = min(M, r0 + rpg);
   float loose = 0.f;
   unsigned seen = 0u;
   for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
-    unsigned b = rm[r];
-    for (int sl = 1; sl < ns; ++sl) b = max(b, rm[(int64_t)sl * M + r]);     // (positive floats order as their bit patterns)
+    const unsigned b = rm[r];                              // (positive floats order as their bit patterns)
     seen |= b;
     loose = fmaxf(loose, b ? 32768.0f / __uint_as_float(b) : 1.099511627776e12f);
   }
@@ -427,14 +418,12 @@ __global__ __launch_bounds__(256) void ffn_looseness_kernel(const unsigned* __re
 
 }  // namespace
 
-int ffn_looseness(const unsigned* rowmax, int nblocks, int64_t M, int64_t rows_per_group, int slots, const uint64_t fused_mask[4],
-                  float* out, hipStream_t stream) {
-  ANYLOC_CHECK_ARG(rowmax && out && nblocks > 0 && nblocks <= 256 && M > 0 && rows_per_group > 0 && slots >= 0,
-                   "ffn_looseness: bad arguments");
+int ffn_looseness(const unsigned* rowmax, int nblocks, int64_t M, int64_t rows_per_group, float* out, hipStream_t stream) {
+  ANYLOC_CHECK_ARG(rowmax && out && nblocks > 0 && M > 0 && rows_per_group > 0, "ffn_looseness: bad arguments");
   const int groups = (int)((M + rows_per_group - 1) / rows_per_group);
-  ProfScope prof("ffn_telemetry", stream, 0.0, 4.0 * nblocks * M * (slots > 0 ? slots : 1));
+  ProfScope prof("ffn_telemetry", stream, 0.0, 4.0 * nblocks * M);
   hipLaunchKernelGGL(ffn_looseness_kernel, dim3((unsigned)(nblocks * groups)), dim3(256), 0, stream, rowmax, M, rows_per_group,
-                     groups, slots, fused_mask[0], fused_mask[1], fused_mask[2], fused_mask[3], out);
+                     groups, out);
   return launch_status("ffn_looseness_kernel");
 }
 

@@ -315,14 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
         // order as their bit patterns); one atomic per (row, wave) -- the two halves of a row meet by one lane exchange
         if (p.c_max) {
           cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
-          if (rok && hl == 0) {
-            if (p.c_max_slots > 0) {                       // (a wave of 32 NI weight rows covers NI / 2 slots of 64)
-#pragma unroll
-              for (int sl = 0; sl < (NI + 1) / 2; ++sl) p.c_max[((wr0 >> 6) + sl) * p.RC + row] = __float_as_uint(cmx);
-            } else {
-              atomicMax(p.c_max + row, __float_as_uint(cmx));
-            }
-          }
+          if (rok && hl == 0) atomicMax(p.c_max + row, __float_as_uint(cmx));
         }
       }
     }
@@ -547,16 +540,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
                                      fmaxf(fmaxf(fabsf(t1[0]), fabsf(t1[1])), fmaxf(fabsf(t1[2]), fabsf(t1[3])))) : 0.0f;
 #pragma unroll
             for (int o2 = LPR / 2; o2 > 0; o2 >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o2, 64));
-            if (row < p.M && lane % LPR == 0) {
-              if (p.c_max_slots > 0) {
-                // GEMM columns of this sub-block: [gc0, gc0 + (SW ? 32 NI : 64)) -> its slots of 64
-                const int64_t gc0 = SW ? n0 + wn * 32 * NI : ocol0;
-#pragma unroll
-                for (int sl = 0; sl < (SW ? (NI + 1) / 2 : 1); ++sl) p.c_max[((gc0 >> 6) + sl) * p.RC + row] = __float_as_uint(cmx);
-              } else {
-                atomicMax(p.c_max + row, __float_as_uint(cmx));
-              }
-            }
+            if (row < p.M && lane % LPR == 0) atomicMax(p.c_max + row, __float_as_uint(cmx));
           }
         }
       }

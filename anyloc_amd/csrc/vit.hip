@@ -60,16 +60,6 @@ struct VitWs {
   size_t bytes;
 };
 
-// FFN-bound telemetry: 64-column slots of the fc1 / w12 GEMM's N per row (plain-store mode), or 0 = one word per row merged by
-// atomicMax.  Few rows -> slots (common.hpp, H3Problem::c_max); the array [depth][slots][M] must stay small.
-int telemetry_slots(const anyloc_vit_config& c, int64_t M) {
-  const int64_t n = (c.ffn_kind == 1 ? 2 : 1) * (int64_t)c.ffn_hidden, slots = n / 64;
-  const int64_t mode = option(OPT_FFN_TELEM_ATOMIC);
-  if (mode > 0 || slots < 1) return 0;
-  if (mode == 0) return (int)slots;
-  return (int64_t)c.depth * slots * M * 4 <= (32ll << 20) ? (int)slots : 0;
-}
-
 VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int64_t H, int64_t W) {
   Arena a(ws, cap);
   const int64_t np = (H / c.patch) * (W / c.patch), T = np + 1, M = batch * T;
@@ -88,12 +78,7 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   w.qinv = a.take<float>(qkv_inv_count(M, c.heads));
   w.sk_part = a.take<float>(H3_SPLIT_PART_BYTES / sizeof(float));
   w.sk_tickets = a.take<unsigned>(H3_SPLIT_TICKETS);
-  {
-    // (sized for either layout whatever the option says at carve time: the workspace query and the forward must agree)
-    const int64_t n64 = (c.ffn_kind == 1 ? 2 : 1) * (int64_t)c.ffn_hidden / 64;
-    const size_t slot_words = (int64_t)c.depth * n64 * M * 4 <= (32ll << 20) ? (size_t)c.depth * n64 * M : 0;
-    w.hmax = a.take<unsigned>(std::max((size_t)c.depth * M, option(OPT_FFN_TELEM_ATOMIC) == 0 ? (size_t)c.depth * n64 * M : slot_words));
-  }
+  w.hmax = a.take<unsigned>((size_t)c.depth * M);
   w.bytes = a.off;
   return w;
 }
@@ -144,12 +129,12 @@ int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const v
               int64_t w_row0, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
               const char* tag, hipStream_t stream, unsigned char* c2 = nullptr, const float* c_inv = nullptr,
               unsigned char* qkv_planes = nullptr, float* qkv_inv = nullptr, int heads = 0, const VitWs* ws = nullptr,
-              int kind = H3_KIND_OTHER, unsigned* c_max = nullptr, int c_max_slots = 0) {
+              int kind = H3_KIND_OTHER, unsigned* c_max = nullptr) {
   if (A) ANYLOC_TRY(split_h2(A, K, M, K, a2, ainv, stream));
   H3Problem g{};
   if (ws) { g.sk_part = ws->sk_part; g.sk_tickets = ws->sk_tickets; }
   g.kind = kind;
-  g.C2 = c2; g.RC = M; g.c_inv = c_inv; g.c_max = c_max; g.c_max_slots = c_max_slots;
+  g.C2 = c2; g.RC = M; g.c_inv = c_inv; g.c_max = c_max;
   g.qkv_planes = qkv_planes; g.qkv_inv = qkv_inv; g.heads = heads; g.groups = (M + 31) / 32;
   g.A2 = a2; g.RA = M; g.a_inv = ainv;
   g.W2 = static_cast<const unsigned char*>(w2) + w_row0 * 32; g.RW = w_rows; g.w_inv = winv + w_row0;
@@ -369,13 +354,10 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   const int last_layer = tap_layers[n_taps - 1];
   // split-K arrival counters; with telemetry on also the rows' maxima of every block that will run (adjacent: one memset)
   const bool telem = h3m && h->ffn_looseness != nullptr;
-  const int tslots = telem ? telemetry_slots(c, M) : 0;          // > 0: plain-store slots (fully written by every fused block: no memset)
-  const size_t tstride = (size_t)(tslots > 0 ? tslots : 1) * M;  // words per block
-  uint64_t fused_mask[4] = {0, 0, 0, 0};
   if (h3m)
     ANYLOC_HIP(hipMemsetAsync(w.sk_tickets, 0,
-                              telem && tslots == 0 ? (size_t)(reinterpret_cast<char*>(w.hmax + (size_t)(last_layer + 1) * M) - reinterpret_cast<char*>(w.sk_tickets))
-                                                   : H3_SPLIT_TICKETS * sizeof(unsigned),
+                              telem ? (size_t)(reinterpret_cast<char*>(w.hmax + (size_t)(last_layer + 1) * M) - reinterpret_cast<char*>(w.sk_tickets))
+                                    : H3_SPLIT_TICKETS * sizeof(unsigned),
                               stream));
   // does any tap need the block OUTPUT of the last executed layer?
   bool last_needs_full = false;
@@ -486,17 +468,16 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
     if (h3m && fuse_ffn) {
-      fused_mask[l >> 6] |= 1ull << (l & 63);
       // the hidden activation is quantised in the epilogue against the row bound LayerNorm 2 left in w.hinv
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, nullptr, Hh, M, Hh,
                              EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1,
-                             telem ? w.hmax + (size_t)l * tstride : nullptr, tslots));
+                             telem ? w.hmax + (size_t)l * M : nullptr));
       else
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0,
                              h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, nullptr, Hh, M, 2 * Hh,
                              h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
-                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1, telem ? w.hmax + (size_t)l * tstride : nullptr, tslots));
+                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1, telem ? w.hmax + (size_t)l * M : nullptr));
       ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
     } else if (h3m) {
@@ -534,8 +515,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   if (flags & ANYLOC_VIT_NORM_CONCAT)
     ANYLOC_TRY(l2norm_rows(out, ldo, out, ldo, batch * rows_per_img, ldo, 1e-12f, stream));
   // FFN-bound telemetry: one figure per executed block (and image) from the row maxima the fc1 / w12 epilogues left
-  if (telem)
-    ANYLOC_TRY(ffn_looseness(w.hmax, last_layer + 1, M, h->telemetry_per_image ? T : M, tslots, fused_mask, h->ffn_looseness, stream));
+  if (telem) ANYLOC_TRY(ffn_looseness(w.hmax, last_layer + 1, M, h->telemetry_per_image ? T : M, h->ffn_looseness, stream));
   return ANYLOC_OK;
 }
 

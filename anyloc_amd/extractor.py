@@ -15,6 +15,7 @@ import math
 
 import os
 
+import numpy as np
 import torch
 from torch.nn import functional as F
 
@@ -280,15 +281,21 @@ class HipDinoV2:
         # the call with the FFN-bound telemetry on: one figure per (executed block, image)
         if self._telemetry is None or self._telemetry.numel() < self.depth * B:
             self._telemetry = torch.empty(self.depth * B, dtype=torch.float32, device=self.device)
+            # the figures come back through PINNED memory and are read with NumPy: `.cpu()` + torch CPU reductions of these
+            # hundred bytes cost 15 + 9 ms per call on the 256-thread host (a one-image forward is 5.5 ms;
+            # profiles/r06_ffn_telemetry_b1.log), an asynchronous copy + a stream wait + a NumPy max cost ~0.03 ms
+            self._telemetry_host = torch.empty(self.depth * B, dtype=torch.float32, pin_memory=True)
         _lib.check(lib.anyloc_vit_set_telemetry(self._handle, _lib.ptr(self._telemetry), 1), "anyloc_vit_set_telemetry")
         try:
             forward(img, out)
             n_blocks = taps[-1][0] + 1
-            loose = self._telemetry[:n_blocks * B].cpu().reshape(n_blocks, B)          # (the call's one host sync)
-            self.ffn_looseness = loose.max(dim=1).values.numpy().copy()
+            self._telemetry_host[:n_blocks * B].copy_(self._telemetry[:n_blocks * B], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()                        # (the call's one host sync)
+            loose = self._telemetry_host.numpy()[:n_blocks * B].reshape(n_blocks, B)
+            self.ffn_looseness = loose.max(axis=1)
             self.ffn_exact_blocks = set()
-            bad = (loose > FFN_LOOSENESS_MAX)
-            if bool(bad.any()):
+            bad = loose > FFN_LOOSENESS_MAX
+            if bad.any():
                 # images grouped by the set of blocks THEY trip: for each such set the call runs again with exactly those
                 # blocks exact -- the WHOLE batch, same row count and batch positions, because the kernels' summation orders
                 # depend on both (small-M plans, the global 32-row key groups of attention) -- and only the group's images
@@ -296,7 +303,7 @@ class HipDinoV2:
                 # on what its batch mates contain; the switches are cleared before the call returns.
                 groups = {}
                 for b in range(B):
-                    key = tuple(int(l) for l in torch.nonzero(bad[:, b]).flatten())
+                    key = tuple(int(l) for l in np.nonzero(bad[:, b])[0])
                     if key:
                         groups.setdefault(key, []).append(b)
                 _lib.check(lib.anyloc_vit_set_telemetry(self._handle, None, 0), "anyloc_vit_set_telemetry")

@@ -70,10 +70,6 @@ const char* anyloc_last_error(void);
  *                                     chain of key tiles; partial sums meet in LDS), 1 = none, 0 = 2 when all workgroups are resident
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
- *   ffn_telem_atomic (-1)             FFN-bound telemetry of the two-term fp16 forward: how the fc1 / w12 epilogue leaves the rows' maxima --
- *                                     -1 = plain stores into one word per (64-column slot, row) while that array stays below 32 MiB (few
- *                                     rows: one image's 530 words sit in one or two memory channels and every atomic of a launch would
- *                                     queue there), atomicMax into one word per row beyond; 0 / 1 force the slots / the atomics (tests)
  *   vlad_gather_v (0)                 one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the round-6
  *                                     hazard study (tools/stress_vlad.py); 0 = the shipped arithmetic
  *   kmeans_max_chunks (0 = two per CU)
