@@ -11,7 +11,8 @@
  *            without re-normalisation / intra-normalisation, cosine and euclidean labels
  *   kmeans   one anyloc_kmeans_step + anyloc_kmeans_update against one fpk iteration
  *   topk     anyloc_l2norm_rows + anyloc_topk(NORMALIZE_DB): a few queries of long rows (the split-K stream over the
- *            database) and many queries of short rows (score panels), IP and L2, k > ndb padding, index_base
+ *            database) and many queries of short rows (score panels), IP and L2, k > ndb padding, index_base; two of them a
+ *            second time through anyloc_topk_index_build + anyloc_topk_search_index (ABI 8: the database side prepared once)
  *   vit      anyloc_vit_create / anyloc_vit_forward (two taps in one call) on GELU-mlp and SwiGLU models, on the fp32 matrix-core
  *            kernels and with anyloc_split_h2 images attached (the default two-term fp16 arithmetic), against the C restatement
  *            of the hub model
@@ -228,8 +229,10 @@ static void case_kmeans(hipStream_t stream, int64_t n, int64_t D, int64_t K, int
 }
 
 /* ----------------------------------------------------------------- top-k */
+/* indexed != 0: the same search a second time through the database side prepared once (ABI 8: anyloc_topk_index_build +
+ * anyloc_topk_search_index -- faiss' index.add apart from index.search), checked against the same oracle lists */
 static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, int64_t k, int metric, int64_t base,
-                      const char* name) {
+                      int indexed, const char* name) {
   float* db = (float*)malloc(sizeof(float) * (size_t)(ndb * dim));
   float* qu = (float*)malloc(sizeof(float) * (size_t)(nq * dim));
   clustered_rows(db, ndb, dim, 12, 1.0f, 1);                 /* raw rows of very different norms: NORMALIZE_DB has work to do */
@@ -251,15 +254,30 @@ static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, 
   size_t ws_bytes = anyloc_topk_workspace_bytes(nq, ndb, dim, k);
   void* d_ws = dev_alloc(ws_bytes);
   ANYLOC_OK_OR_FAIL(anyloc_l2norm_rows(d_qu, d_qn, nq, dim, 1e-12f, stream));
-  ANYLOC_OK_OR_FAIL(anyloc_topk(d_qn, nq, d_db, ndb, dim, k, metric, ANYLOC_TOPK_NORMALIZE_DB, base, d_dist, d_idx, d_ws,
-                                ws_bytes, stream));
   float* got_d = (float*)malloc(sizeof(float) * (size_t)(nq * k));
   int64_t* got_i = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq * k));
+  void *d_index = NULL, *d_iws = NULL;
+  int ok = 1;
+  int64_t swaps = 0, bad = 0, pad_bad = 0;
+  double worst = 0.0;
+  for (int pass = 0; pass < (indexed ? 2 : 1); ++pass) {
+  if (pass == 0) {
+    ANYLOC_OK_OR_FAIL(anyloc_topk(d_qn, nq, d_db, ndb, dim, k, metric, ANYLOC_TOPK_NORMALIZE_DB, base, d_dist, d_idx, d_ws,
+                                  ws_bytes, stream));
+  } else {
+    const size_t ib = anyloc_topk_index_bytes(ndb, dim), iw = anyloc_topk_index_workspace_bytes(nq, ndb, dim, k);
+    if (ib == 0 || iw == 0) { report(name, 0, "anyloc_topk_index_bytes says the shape is not served"); ok = -1; break; }
+    d_index = dev_alloc(ib);
+    d_iws = dev_alloc(iw);
+    HIP_OK(hipMemsetAsync(d_dist, 0xff, sizeof(float) * (size_t)(nq * k), stream));
+    HIP_OK(hipMemsetAsync(d_idx, 0xff, sizeof(int64_t) * (size_t)(nq * k), stream));
+    ANYLOC_OK_OR_FAIL(anyloc_topk_index_build(d_db, ndb, dim, d_index, ib, stream));
+    ANYLOC_OK_OR_FAIL(anyloc_topk_search_index(d_qn, nq, d_index, ndb, dim, k, metric, ANYLOC_TOPK_NORMALIZE_DB, base, d_dist, d_idx,
+                                               d_iws, iw, stream));
+  }
   HIP_OK(hipMemcpyAsync(got_d, d_dist, sizeof(float) * (size_t)(nq * k), hipMemcpyDeviceToHost, stream));
   HIP_OK(hipMemcpyAsync(got_i, d_idx, sizeof(int64_t) * (size_t)(nq * k), hipMemcpyDeviceToHost, stream));
   HIP_OK(hipStreamSynchronize(stream));
-  int64_t swaps = 0, bad = 0, pad_bad = 0;
-  double worst = 0.0;
   for (int64_t q = 0; q < nq; ++q)
     for (int64_t j = 0; j < k; ++j) {
       int64_t w = want_i[q * k + j], g = got_i[q * k + j];
@@ -271,19 +289,23 @@ static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, 
         if (dd > 3e-6) ++bad;
       }
     }
-  int ok = bad == 0 && pad_bad == 0 && worst <= 3e-6;
-  if (ndb > 10) {                                            /* the duplicated row: wherever both appear, 4 comes before 9 */
+  if (ok > 0) ok = bad == 0 && pad_bad == 0 && worst <= 3e-6;
+  if (ok > 0 && ndb > 10) {                                            /* the duplicated row: wherever both appear, 4 comes before 9 */
     for (int64_t q = 0; q < nq; ++q) {
       int64_t p4 = -1, p9 = -1;
       for (int64_t j = 0; j < k; ++j) { if (got_i[q * k + j] == 4 + base) p4 = j; if (got_i[q * k + j] == 9 + base) p9 = j; }
       if (p9 >= 0 && (p4 < 0 || p4 > p9)) ok = 0;
     }
   }
-  char detail[200];
-  snprintf(detail, sizeof detail, "%lld x %lld x %lld, k=%lld: %lld near-tie swaps (%lld outside 3e-6), max |dist err| %.2e, padding %s",
-           (long long)nq, (long long)ndb, (long long)dim, (long long)k, (long long)swaps, (long long)bad, worst, pad_bad ? "WRONG" : "ok");
-  report(name, ok, detail);
+  }                                                          /* (both passes accumulate into the same counters) */
+  char detail[240];
+  snprintf(detail, sizeof detail, "%lld x %lld x %lld, k=%lld%s: %lld near-tie swaps (%lld outside 3e-6), max |dist err| %.2e, padding %s",
+           (long long)nq, (long long)ndb, (long long)dim, (long long)k, indexed ? " (one-shot + prepared index)" : "", (long long)swaps,
+           (long long)bad, worst, pad_bad ? "WRONG" : "ok");
+  if (ok >= 0) report(name, ok, detail);                     /* (-1: already reported) */
   hipFree(d_db); hipFree(d_qu); hipFree(d_qn); hipFree(d_dist); hipFree(d_idx); hipFree(d_ws);
+  if (d_index) hipFree(d_index);
+  if (d_iws) hipFree(d_iws);
   free(db); free(qu); free(qn); free(want_d); free(want_i); free(got_d); free(got_i);
 }
 
@@ -523,10 +545,11 @@ int main(void) {
   }
   case_kmeans(stream, 40000, 1536, 32, 0, "kmeans step+update 40000x1536 K=32 cosine");
   case_kmeans(stream, 5000, 64, 16, 1, "kmeans step+update 5000x64 K=16 euclidean");
-  case_topk(stream, 5, 2000, 49152, 20, 0, 0, "topk 5 queries x 49152 dims, IP");
-  case_topk(stream, 5, 2000, 49152, 20, 1, 1000000, "topk 5 queries x 49152 dims, L2, base 1e6");
-  case_topk(stream, 300, 3000, 256, 10, 0, 0, "topk 300 queries x 256 dims, IP");
-  case_topk(stream, 3, 12, 64, 20, 0, 0, "topk k > ndb padding");
+  case_topk(stream, 5, 2000, 49152, 20, 0, 0, 0, "topk 5 queries x 49152 dims, IP");
+  case_topk(stream, 5, 2000, 49152, 20, 1, 1000000, 0, "topk 5 queries x 49152 dims, L2, base 1e6");
+  case_topk(stream, 300, 3000, 256, 10, 0, 0, 1, "topk 300 queries x 256 dims, IP");
+  case_topk(stream, 280, 9000, 1024, 20, 1, 77, 1, "topk 280 queries x 9000 rows x 1024 dims, L2, base 77 (ragged last panel)");
+  case_topk(stream, 3, 12, 64, 20, 0, 0, 0, "topk k > ndb padding");
   case_vit(stream, 0, "vit 3 blocks D=384 mlp");
   case_vit(stream, 1, "vit 3 blocks D=384 swiglu");
   case_pca(stream, 70, 131, 9, "pca fit products 70 x 131 (float64 matrix cores)");
