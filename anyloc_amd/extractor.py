@@ -215,6 +215,7 @@ class HipDinoV2:
             raise RuntimeError(f"{self.name}: the model forward needs all {self.full_depth} blocks and the final "
                                f"norm.weight / norm.bias (loaded: {self.depth} blocks)")
         with _on_device(self.device):          # every launch of the call on the model's device, whatever the current one is
+            self._begin_call()
             tok = self._forward_taps(img, [(self.depth - 1, "token")], True, False, False)
             res = ops.layernorm(tok[:, 0].contiguous(), self._final_norm[0], self._final_norm[1], 1e-6)
         return res if img.is_cuda else ops.to_home(res, img.device)
@@ -231,7 +232,14 @@ class HipDinoV2:
         CURRENT HIP device and stream, so the call runs with this model's device current (a caller that built the
         extractor with device="cuda:N" need not have called torch.cuda.set_device(N))."""
         with _on_device(self.device):
+            self._begin_call()
             return self._forward_taps(img, taps, use_cls, norm_taps, norm_concat)
+
+    def _begin_call(self):
+        """The per-call record of the FFN-bound check starts empty (a batch forwarded in chunks is ONE call: the chunks'
+        figures are merged)."""
+        self.ffn_looseness = None
+        self.ffn_exact_blocks = set()
 
     def _forward_taps(self, img, taps, use_cls, norm_taps, norm_concat):
         if img.ndim != 4 or img.shape[1] != 3:
@@ -292,8 +300,9 @@ class HipDinoV2:
             self._telemetry_host[:n_blocks * B].copy_(self._telemetry[:n_blocks * B], non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()                        # (the call's one host sync)
             loose = self._telemetry_host.numpy()[:n_blocks * B].reshape(n_blocks, B)
-            self.ffn_looseness = loose.max(axis=1)
-            self.ffn_exact_blocks = set()
+            worst = loose.max(axis=1)
+            self.ffn_looseness = worst if self.ffn_looseness is None or len(self.ffn_looseness) != len(worst) \
+                else np.maximum(self.ffn_looseness, worst)
             bad = loose > FFN_LOOSENESS_MAX
             if bad.any():
                 # images grouped by the set of blocks THEY trip: for each such set the call runs again with exactly those
