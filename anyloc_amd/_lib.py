@@ -73,6 +73,7 @@ SIGNATURES = {
     "anyloc_split_h2": (C.c_int, [c_f32p, c_i64, c_i64, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
     "anyloc_gemm_nt_h3": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64,
                                     C.c_void_p]),
+    "anyloc_h3_lead_plan_check": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_i64, C.POINTER(C.c_uint32)]),
     "anyloc_gemm_nt": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64,
                                  c_i64, c_i64, c_i64, C.c_void_p]),
     "anyloc_layernorm": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, C.c_float, C.c_void_p]),
@@ -121,7 +122,7 @@ SIGNATURES = {
     "anyloc_profile_dump": (C.c_int, [C.c_char_p, c_sz]),
 }
 
-ABI_VERSION = 8          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
+ABI_VERSION = 9          # include/anyloc_hip.h ANYLOC_ABI_VERSION the structs and signatures above were written for
 
 _lib = None
 

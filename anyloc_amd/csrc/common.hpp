@@ -95,6 +95,8 @@ enum Option {
   OPT_H3S_W12_TALL,      // small-M plan of the w12 / fc1 GEMM of one image: 1 = 192 x 128 tiles (one workgroup per CU), 0 = 128 x 128
   OPT_ATTN_H3_QG,        // attention_h3: 32-query groups per wave, 1 (four waves of 32 queries, default) or 2 (two waves of 64: A/B)
   OPT_ATTN_H3_KS,        // attention_h3: key splits across the waves of a workgroup, 0 = by grid size (2 when all workgroups are resident), 1, 2
+  OPT_H3S_LN_LEAD,       // one image per call: LayerNorm as the lead role of its consumer GEMM's launch (LN1 + qkv, LN2 + w12); 0 = two launches
+  OPT_H3_LN_LEAD,        // batched calls: LayerNorm as lead workgroups interleaved with its consumer GEMM's tiles (LN1 + qkv, LN2 + fc1 / w12); 0 = two launches
   OPT_VLAD_GATHER_V,     // one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the hazard study (0 = shipped)
   OPT_COUNT
 };
@@ -262,6 +264,13 @@ struct H3Problem {
   // FFN-bound telemetry (optional): c_max[row] = bits of the largest scaled magnitude the row holds in the output image, merged by
   // atomicMax (one per row and wave: +0.09 ms per one-image ViT-g forward, lost in the noise of a batched one)
   unsigned* c_max;
+  // LayerNorm LEAD role (small-M plans, gemm_h3s.hip; round 6): when ln_x is set, the first ln_wgs workgroups of the launch
+  // normalise the rows of ln_x (one row per wave, the arithmetic of layernorm_h2) straight into THIS GEMM's operand image (A2 /
+  // a_inv, and c_inv when ln_bound is set) with write-through stores and count the rows of every BM-row tile in ln_tickets; a
+  // GEMM workgroup waits for its row tile's count before it stages A.  One launch instead of two for LN1 + qkv and LN2 + w12.
+  const float* ln_x; const float* ln_w; const float* ln_b; float ln_eps; int ln_dim;
+  float ln_bound[4]; int ln_has_bound;
+  unsigned* ln_tickets; int ln_wgs;
   const char* tag;
 };
 
@@ -304,6 +313,10 @@ constexpr size_t H3_SPLIT_PART_BYTES = 48u << 20;      // partial accumulators o
 constexpr size_t H3_SPLIT_TICKETS = 4096;               // tiles of one split-K launch
 inline size_t h3_split_workspace_bytes() { return H3_SPLIT_PART_BYTES + H3_SPLIT_TICKETS * sizeof(unsigned) + 512; }
 bool h3_small_supported(int epilogue);
+// would gemm_h3 run this GEMM with the LayerNorm lead role (H3Problem::ln_x)?  The caller then skips its LayerNorm launch.
+bool h3_ln_lead_feasible(const H3Problem& p, int epilogue);       // gemm_h3.hip: small-M rule below or the batched rule
+bool h3s_ln_lead_feasible(const H3Problem& p, int epilogue);      // gemm_h3s.hip (one image per call)
+int h3_lead_plan_check(int tiles_m, int tiles_n, int group_m, int64_t M, unsigned* grid);
 int gemm_h3_small(const H3Problem& p, int epilogue, hipStream_t stream);
 // the same GEMM on v_mfma_f32_16x16x32_f16 (gemm_h3m.hip); ANYLOC_ERR_UNSUPPORTED for epilogues it does not have
 int gemm_h3m(const H3Problem& p, int epilogue, hipStream_t stream);

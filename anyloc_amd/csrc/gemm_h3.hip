@@ -13,7 +13,12 @@
 //
 // Operand image ("h2"): [k/16][plane 0..1][row][16] fp16, 32 bytes per (k-block, plane, row), 16-byte halves swapped
 // when (row >> 3) & 1 -- the x3 image of gemm_x6.hip with two planes; same DMA staging, same fragment reads.
+#include <algorithm>
+#include <array>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "gemm_h3_kernel.hpp"
 
@@ -21,70 +26,7 @@ namespace anyloc {
 
 namespace {
 
-// ---- quantisers: rows held in registers (NV float4 per lane and row, 4 rows per wave, 16 rows per block) ----
-// the scaled values of 16 rows go through a 16 x 256 LDS tile, chunk by chunk, and are stored in IMAGE order
-// (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
-// store chunk i (256 columns) of 16 rows, already scaled and sitting in the LDS tile, in IMAGE order
-// (thread = (k-block, row, half): whole 512-byte runs per store instruction, 16 bytes per lane and plane)
-template <int RB = 16, int NT = 256>
-__device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, int dim, int64_t row0, int64_t rows,
-                                               unsigned char* out, int64_t R) {
-  static_assert(RB == 32 || RB == 16 || RB == 8 || RB == 4, "rows per block: a power of two (k-block, row, half) decoding");
-  const int tid = threadIdx.x;
-  constexpr int ITEMS = RB * 32;                           // (k-block, row, half) triples of one 256-column chunk
-#pragma unroll
-  for (int u = 0; u < (ITEMS + NT - 1) / NT; ++u) {
-    const int item = tid + NT * u;
-    const int kbl = item / (2 * RB), r = (item >> 1) & (RB - 1), half = item & 1;
-    const int k0 = 256 * i + 16 * kbl + 8 * half;
-    const int64_t row = row0 + r;
-    if (item < ITEMS && k0 < dim && row < rows) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
-      hu32x4 ph, plo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x2 pr;
-        pr[0] = j < 2 ? lo[2 * j] : hi[2 * j - 4];
-        pr[1] = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
-        const f16x2 h = __builtin_convertvector(pr, f16x2);
-        f32x2 res;
-        res[0] = pr[0] - (float)h[0];
-        res[1] = pr[1] - (float)h[1];
-        const f16x2 l = __builtin_convertvector(res, f16x2);
-        ph[j] = __builtin_bit_cast(unsigned, h);
-        plo[j] = __builtin_bit_cast(unsigned, l);
-      }
-      unsigned char* dst = out + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4);
-      *reinterpret_cast<hu32x4*>(dst) = ph;
-      *reinterpret_cast<hu32x4*>(dst + R * 32) = plo;
-    }
-  }
-}
-
-// rows held in registers: the scaled values of 16 rows go through the LDS tile chunk by chunk
-template <int NV, int RPW = 4, int NW = 4>
-__device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[RPW][NV], const float (&scale)[RPW], float (*tile)[256 + 4],
-                                              int dim, int64_t row0, int64_t rows, unsigned char* out, int64_t R) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n4 = dim >> 2;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int idx = lane + 64 * i;
-    if (i > 0) __syncthreads();
-    if (idx < n4) {
-#pragma unroll
-      for (int q = 0; q < RPW; ++q) {
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = v[q][i][j] * scale[q];
-        *reinterpret_cast<f32x4*>(&tile[wave * RPW + q][4 * lane]) = o;
-      }
-    }
-    __syncthreads();
-    h2_store_chunk<NW * RPW, 64 * NW>(tile, i, dim, row0, rows, out, R);
-  }
-}
+// (h2_store_chunk / h2_store_rows / ln_rows_tiled: gemm_h3_kernel.hpp -- shared with the LayerNorm lead role of the GEMM kernel)
 
 // wide rows (K > 2048): two passes over the row instead of holding it in registers -- pass 1 finds the maximum,
 // pass 2 re-reads the 16 rows (L2-resident: 16 x 4 K floats) and quantises; 8x the occupancy of the register version
@@ -252,60 +194,8 @@ __global__ __launch_bounds__(64 * NW) void layernorm_h2_kernel(const float* __re
                                                            unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
                                                            const f32x4 bound4, float* __restrict__ bound_inv) {
   __shared__ __attribute__((aligned(16))) float tile[NW * RPW][256 + 4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n4 = dim >> 2;
-  const int64_t row0 = (int64_t)blockIdx.x * (NW * RPW);
-  f32x4 v[RPW][NV];
-  float scale[RPW];
-#pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    const int64_t row = min(row0 + wave * RPW + q, rows - 1);
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < n4) {
-        v[q][i] = xr[idx];
-        s += (v[q][i][0] + v[q][i][1]) + (v[q][i][2] + v[q][i][3]);
-      }
-    }
-    const float mean = wave_sum(s) / (float)dim;
-    float qs = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < n4) {
-        const float d0 = v[q][i][0] - mean, d1 = v[q][i][1] - mean, d2 = v[q][i][2] - mean, d3 = v[q][i][3] - mean;
-        qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-    const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
-    float amax = 0.f, ysq = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < n4) {
-        const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[q][i][j] = (v[q][i][j] - mean) * rstd * wv[j] + bv[j];
-          amax = fmaxf(amax, fabsf(v[q][i][j]));
-          ysq += v[q][i][j] * v[q][i][j];
-        }
-      }
-    }
-    float iv;
-    scale[q] = h2_row_scale(wave_max(amax), iv);
-    if (lane == 0 && row0 + wave * RPW + q < rows) inv[row] = iv;
-    if (bound_inv) {
-      const float yn = sqrtf(wave_sum(ysq)) * 1.001f;                 // 0.1 % head room for the fp32 roundings
-      const float bg = yn * bound4[0] + bound4[1];
-      const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
-      float biv;
-      h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
-      if (lane == 0 && row0 + wave * RPW + q < rows) bound_inv[row] = biv;
-    }
-  }
-  h2_store_rows<NV, RPW, NW>(v, scale, tile, dim, row0, rows, out, R);
+  ln_rows_tiled<NV, RPW, NW, false>(x, w, b, dim, rows, eps, out, inv, R, (int64_t)blockIdx.x * (NW * RPW), bound4, bound_inv, tile,
+                                    null_rsrc());          // (gemm_h3_kernel.hpp)
 }
 
 
@@ -321,68 +211,7 @@ __global__ __launch_bounds__(64) void layernorm_h2_direct_kernel(const float* __
                                                                  const float* __restrict__ b, int dim, int64_t rows, float eps,
                                                                  unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
                                                                  const f32x4 bound4, float* __restrict__ bound_inv) {
-  const int lane = threadIdx.x;
-  const int n4 = dim >> 2;
-  const int64_t row = blockIdx.x;
-  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
-  f32x4 v[NV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int idx = lane + 64 * i;
-    if (idx < n4) {
-      v[i] = xr[idx];
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
-  }
-  const float mean = wave_sum(s) / (float)dim;
-  float qs = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < n4) {
-      const float d0 = v[i][0] - mean, d1 = v[i][1] - mean, d2 = v[i][2] - mean, d3 = v[i][3] - mean;
-      qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-  const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
-  float amax = 0.f, ysq = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int idx = lane + 64 * i;
-    if (idx < n4) {
-      const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[i][j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
-        amax = fmaxf(amax, fabsf(v[i][j]));
-        ysq += v[i][j] * v[i][j];
-      }
-    }
-  }
-  float iv;
-  const float scale = h2_row_scale(wave_max(amax), iv);
-  if (lane == 0) inv[row] = iv;
-  if (bound_inv) {
-    const float yn = sqrtf(wave_sum(ysq)) * 1.001f;
-    const float bg = yn * bound4[0] + bound4[1];
-    const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
-    float biv;
-    h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
-    if (lane == 0) bound_inv[row] = biv;
-  }
-  const int swap = (int)((row >> 3) & 1);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int idx = lane + 64 * i;                        // columns 4 idx .. 4 idx + 3: k-block idx / 4, quarter idx % 4
-    if (idx < n4) {
-      unsigned h0, l0, h1, l1;
-      h2_pack2(v[i][0] * scale, v[i][1] * scale, h0, l0);
-      h2_pack2(v[i][2] * scale, v[i][3] * scale, h1, l1);
-      const int q = idx & 3;
-      unsigned char* dst = out + (((int64_t)(idx >> 2) * 2) * R + row) * 32 + (((q >> 1) ^ swap) << 4) + ((q & 1) << 3);
-      *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
-      *reinterpret_cast<uint2*>(dst + R * 32) = uint2{l0, l1};
-    }
-  }
+  ln_row_direct<NV, false>(x, w, b, dim, eps, out, inv, R, (int64_t)blockIdx.x, bound4, bound_inv);   // (gemm_h3_kernel.hpp)
 }
 
 // FFN-bound telemetry (anyloc_vit_set_telemetry).  The fc1 / w12 epilogue leaves, per block and token row, the largest scaled
@@ -529,6 +358,58 @@ int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, i
   return launch_status("layernorm_h2_kernel");
 }
 
+// ---- LayerNorm lead role inside a batched launch (gemm_h3_kernel<..., LNL = 2>; tile_order.hpp: LeadPlan) ----
+// The plan of a shape is simulated once on the host: every GEMM tile exactly once, every row normalised exactly once, and every
+// lead workgroup of a tile row ahead (in workgroup-id order) of every GEMM tile of that row.  grid = 8 x the longest XCD sequence.
+struct LeadPlanInfo { bool ok; unsigned grid; };
+LeadPlanInfo lead_plan_info(const LeadPlan& lp) {
+  static std::mutex mu;
+  static std::map<std::array<long long, 5>, LeadPlanInfo> cache;
+  const std::array<long long, 5> key{lp.tiles_m, lp.tiles_n, lp.group_m, lp.bm, lp.M};
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  LeadPlanInfo info{false, 0};
+  const int nb = lp.tiles_m * lp.tiles_n;
+  bool ok = lp.tiles_m >= 8 * lp.group_m && lp.bm % LEAD_ROWS == 0 && lp.M > 0 && (lp.M + lp.bm - 1) / lp.bm == lp.tiles_m;
+  if (ok) {
+    std::vector<int> tile_seen((size_t)nb, 0);
+    std::vector<long long> first_tile_id((size_t)lp.tiles_m, -1), last_lead_id((size_t)lp.tiles_m, -1), rows_done((size_t)lp.tiles_m, 0);
+    int longest = 0;
+    for (int x = 0; x < 8 && ok; ++x) {
+      int len = 0;
+      lead_decode(lp, x, 0, &len);
+      longest = std::max(longest, len);
+      for (int loc = 0; loc < len && ok; ++loc) {
+        const LeadRole role = lead_decode(lp, x, loc);
+        const long long id = (long long)loc * 8 + x;
+        if (role.kind == 1) {
+          if (role.tm < 0 || role.tm >= lp.tiles_m || role.tn < 0 || role.tn >= lp.tiles_n || tile_seen[(size_t)role.tm * lp.tiles_n + role.tn]++) ok = false;
+          else if (first_tile_id[role.tm] < 0 || id < first_tile_id[role.tm]) first_tile_id[role.tm] = id;
+        } else if (role.kind == 2) {
+          if (role.row0 < 0 || role.row0 >= lp.M || role.row0 % LEAD_ROWS) { ok = false; break; }
+          const int tm = (int)(role.row0 / lp.bm);
+          rows_done[tm] += std::min<long long>(LEAD_ROWS, lp.M - role.row0);
+          last_lead_id[tm] = std::max(last_lead_id[tm], id);
+        } else {
+          ok = false;
+        }
+      }
+      if (lead_decode(lp, x, len).kind != 0) ok = false;
+    }
+    for (int t = 0; t < nb && ok; ++t) ok = tile_seen[t] == 1;
+    for (int tm = 0; tm < lp.tiles_m && ok; ++tm)
+      ok = rows_done[tm] == std::min<long long>(lp.bm, lp.M - (long long)tm * lp.bm) && last_lead_id[tm] >= 0 && last_lead_id[tm] < first_tile_id[tm];
+    info.ok = ok;
+    info.grid = (unsigned)(8 * longest);
+  }
+  cache[key] = info;
+  return info;
+}
+
+template <int EPI>
+constexpr bool lead_compiled() { return EPI == EPI_QKV_PLANES || EPI == EPI_SWIGLU_T_H2 || EPI == EPI_SWIGLU_H2 || EPI == EPI_GELU_H2; }
+
 template <int EPI>
 int dispatch_h3(const H3Problem& p, hipStream_t stream) {
   // option h3_cfg (micro-benchmarks): 0 = 128x256 tile, 3-deep ring (default; 128x128 when there are few tiles); 1 = 2-deep;
@@ -557,6 +438,23 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
       return launch_status("gemm_h3_kernel");
     }
   }
+  if (p.ln_x) {
+    // LayerNorm in front of this GEMM as the lead role of this launch (linear_h3 asked h3_ln_lead_feasible first)
+    if constexpr (lead_compiled<EPI>()) {
+      using Cfg = H3Cfg<2, 4, 2, 2, 3, 1>;
+      const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
+      const LeadPlanInfo info = lead_plan_info(LeadPlan{tiles_m, tiles_n, p.group_m, Cfg::BM, (long long)p.M});
+      ANYLOC_CHECK_ARG(cfg == 0 && info.ok && p.ln_tickets && p.ln_w && p.ln_b && (!p.ln_has_bound || p.c_inv) && p.ln_dim == 16 * p.K16 &&
+                           p.ln_dim <= 1536 && p.ksplit <= 1,
+                       "gemm_h3: LayerNorm lead role asked for a launch it does not fit (h3_ln_lead_feasible)");
+      static DynLds dyn_lds_lead;
+      ANYLOC_TRY(ensure_dyn_lds(dyn_lds_lead, reinterpret_cast<const void*>(&gemm_h3_kernel<2, 4, 2, 2, 3, 2, EPI, 1, 2>), (int)(Cfg::LDS)));
+      hipLaunchKernelGGL((gemm_h3_kernel<2, 4, 2, 2, 3, 2, EPI, 1, 2>), dim3(info.grid), dim3(256), Cfg::LDS, stream, p, tiles_m, tiles_n);
+      return launch_status("gemm_h3_kernel (LayerNorm lead role)");
+    } else {
+      ANYLOC_CHECK_ARG(false, "gemm_h3: LayerNorm lead role asked for an epilogue it is not compiled for (h3_ln_lead_feasible)");
+    }
+  }
   switch (cfg) {
     case 1: ANYLOC_LAUNCH_H3(2, 4, 2, 2, 2, 2); break;
     case 2: ANYLOC_LAUNCH_H3(2, 4, 4, 2, 3, 2); break;     // 256x256, 8 waves (2 per SIMD, one workgroup per CU), 96 KiB ring
@@ -568,6 +466,27 @@ int dispatch_h3(const H3Problem& p, hipStream_t stream) {
 #undef ANYLOC_LAUNCH_H3
 #undef ANYLOC_LAUNCH_H3K
   return launch_status("gemm_h3_kernel");
+}
+
+// would gemm_h3 run this GEMM with the LayerNorm lead role (H3Problem::ln_x)?  The caller then skips its LayerNorm launch.
+// One image per call: the small-M plans' rule (gemm_h3s.hip, option h3s_ln_lead); batched: option h3_ln_lead, the default tile
+// configuration, an epilogue the role is compiled for, rows of at most 1536 columns, and a plan that passes lead_plan_info.
+bool h3_ln_lead_feasible(const H3Problem& p, int epilogue) {
+  if (option(OPT_H3_CFG) != 0) return false;
+  if (((p.M + 127) / 128) * ((p.N + 255) / 256) < 512) return h3s_ln_lead_feasible(p, epilogue);
+  if (option(OPT_H3_LN_LEAD) == 0) return false;
+  if (epilogue != EPI_QKV_PLANES && epilogue != EPI_SWIGLU_T_H2 && epilogue != EPI_SWIGLU_H2 && epilogue != EPI_GELU_H2) return false;
+  if (16 * (int64_t)p.K16 > 1536 || p.ksplit > 1) return false;
+  using Cfg = H3Cfg<2, 4, 2, 2, 3, 1>;
+  const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
+  const int gm = (int)std::max<int64_t>(1, option(OPT_H3_GROUP_M));
+  return lead_plan_info(LeadPlan{tiles_m, tiles_n, gm, Cfg::BM, (long long)p.M}).ok;
+}
+// host-side check of a lead plan (tests, no GPU needed): 1 = the plan passes, 0 = it does not (the caller keeps two launches)
+int h3_lead_plan_check(int tiles_m, int tiles_n, int group_m, int64_t M, unsigned* grid) {
+  const LeadPlanInfo info = lead_plan_info(LeadPlan{tiles_m, tiles_n, group_m, 128, (long long)M});
+  if (grid) *grid = info.grid;
+  return info.ok ? 1 : 0;
 }
 
 int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
@@ -637,6 +556,14 @@ int gemm_h3(const H3Problem& p_in, int epilogue, hipStream_t stream) {
 using namespace anyloc;
 
 extern "C" size_t anyloc_h2_bytes(int64_t rows, int64_t K) { return h2_bytes(rows, K); }
+
+extern "C" int anyloc_h3_lead_plan_check(int32_t tiles_m, int32_t tiles_n, int32_t group_m, int64_t M, uint32_t* grid) {
+  if (tiles_m <= 0 || tiles_n <= 0 || group_m <= 0 || M <= 0) return 0;
+  unsigned g = 0;
+  const int ok = anyloc::h3_lead_plan_check(tiles_m, tiles_n, group_m, M, &g);
+  if (grid) *grid = g;
+  return ok;
+}
 
 extern "C" int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, void* stream) {
   return split_h2(x, ldx, rows, K, h2, inv_scale, (hipStream_t)stream);

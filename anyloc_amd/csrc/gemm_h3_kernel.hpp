@@ -72,7 +72,244 @@ __device__ __forceinline__ float h3_silu_fast(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
-template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1>
+// ---- quantisers: rows held in registers (NV float4 per lane and row, RPW rows per wave, NW * RPW rows per block) ----
+// the scaled values of the block's rows go through an LDS tile of 256 columns, chunk by chunk, and are stored in IMAGE order
+// (thread = (k-block, row, half): whole 512-byte runs per store instruction at 16 rows, 16 bytes per lane and plane).
+// COH (the LayerNorm lead role of gemm_h3_kernel): the same stores WRITE-THROUGH (sc1) through the buffer descriptor `rs` of
+// the image, so that a workgroup of the SAME launch on another XCD can read them once the rows' ticket says so.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t null_rsrc() { return __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(nullptr), 0, 0, 0); }
+template <int RB = 16, int NT = 256, bool COH = false>
+__device__ __forceinline__ void h2_store_chunk(float (*tile)[256 + 4], int i, int dim, int64_t row0, int64_t rows,
+                                               unsigned char* out, int64_t R, __amdgpu_buffer_rsrc_t rs = null_rsrc()) {
+  static_assert(RB == 32 || RB == 16 || RB == 8 || RB == 4, "rows per block: a power of two (k-block, row, half) decoding");
+  const int tid = threadIdx.x;
+  constexpr int ITEMS = RB * 32;                           // (k-block, row, half) triples of one 256-column chunk
+#pragma unroll
+  for (int u = 0; u < (ITEMS + NT - 1) / NT; ++u) {
+    const int item = tid + NT * u;
+    const int kbl = item / (2 * RB), r = (item >> 1) & (RB - 1), half = item & 1;
+    const int k0 = 256 * i + 16 * kbl + 8 * half;
+    const int64_t row = row0 + r;
+    if (item < ITEMS && k0 < dim && row < rows) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
+      hu32x4 ph, plo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 pr;
+        pr[0] = j < 2 ? lo[2 * j] : hi[2 * j - 4];
+        pr[1] = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
+        const f16x2 h = __builtin_convertvector(pr, f16x2);
+        f32x2 res;
+        res[0] = pr[0] - (float)h[0];
+        res[1] = pr[1] - (float)h[1];
+        const f16x2 l = __builtin_convertvector(res, f16x2);
+        ph[j] = __builtin_bit_cast(unsigned, h);
+        plo[j] = __builtin_bit_cast(unsigned, l);
+      }
+      const int64_t off = (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4);
+      if constexpr (COH) {
+        __builtin_amdgcn_raw_buffer_store_b128(ph, rs, (unsigned)off, 0, /*sc1*/ 16);
+        __builtin_amdgcn_raw_buffer_store_b128(plo, rs, (unsigned)(off + R * 32), 0, /*sc1*/ 16);
+      } else {
+        *reinterpret_cast<hu32x4*>(out + off) = ph;
+        *reinterpret_cast<hu32x4*>(out + off + R * 32) = plo;
+      }
+    }
+  }
+}
+
+// rows held in registers: the scaled values of the block's rows go through the LDS tile chunk by chunk
+template <int NV, int RPW = 4, int NW = 4, bool COH = false>
+__device__ __forceinline__ void h2_store_rows(const f32x4 (&v)[RPW][NV], const float (&scale)[RPW], float (*tile)[256 + 4],
+                                              int dim, int64_t row0, int64_t rows, unsigned char* out, int64_t R,
+                                              __amdgpu_buffer_rsrc_t rs = null_rsrc()) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = dim >> 2;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (i > 0) __syncthreads();
+    if (idx < n4) {
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[q][i][j] * scale[q];
+        *reinterpret_cast<f32x4*>(&tile[wave * RPW + q][4 * lane]) = o;
+      }
+    }
+    __syncthreads();
+    h2_store_chunk<NW * RPW, 64 * NW, COH>(tile, i, dim, row0, rows, out, R, rs);
+  }
+}
+
+// LayerNorm (torch semantics, biased variance) of the NW * RPW rows from row0 on, quantised straight into the h2 image: the body of
+// layernorm_h2_kernel (gemm_h3.hip) and of the LayerNorm LEAD role of gemm_h3_kernel<..., LNL = 2> below (COH: every store
+// write-through).  bound4 / bound_inv: the FFN bound (see layernorm_h2_kernel).  Per-row arithmetic independent of RPW / NW / COH.
+template <int NV, int RPW, int NW, bool COH>
+__device__ __forceinline__ void ln_rows_tiled(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                              int dim, int64_t rows, float eps, unsigned char* __restrict__ out, float* __restrict__ inv,
+                                              int64_t R, int64_t row0, const f32x4 bound4, float* __restrict__ bound_inv,
+                                              float (*tile)[256 + 4], __amdgpu_buffer_rsrc_t rs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = dim >> 2;
+  f32x4 v[RPW][NV];
+  float scale[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int64_t row = min(row0 + wave * RPW + q, rows - 1);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < n4) {
+        v[q][i] = xr[idx];
+        s += (v[q][i][0] + v[q][i][1]) + (v[q][i][2] + v[q][i][3]);
+      }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float qs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < n4) {
+        const float d0 = v[q][i][0] - mean, d1 = v[q][i][1] - mean, d2 = v[q][i][2] - mean, d3 = v[q][i][3] - mean;
+        qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
+    float amax = 0.f, ysq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < n4) {
+        const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[q][i][j] = (v[q][i][j] - mean) * rstd * wv[j] + bv[j];
+          amax = fmaxf(amax, fabsf(v[q][i][j]));
+          ysq += v[q][i][j] * v[q][i][j];
+        }
+      }
+    }
+    float iv;
+    scale[q] = h2_row_scale(wave_max(amax), iv);
+    const bool mine = lane == 0 && row0 + wave * RPW + q < rows;
+    if (mine) {
+      if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(inv + row), __float_as_uint(iv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else inv[row] = iv;
+    }
+    if (bound_inv) {
+      const float yn = sqrtf(wave_sum(ysq)) * 1.001f;                 // 0.1 % head room for the fp32 roundings
+      const float bg = yn * bound4[0] + bound4[1];
+      const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
+      float biv;
+      h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
+      if (mine) {
+        if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(bound_inv + row), __float_as_uint(biv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else bound_inv[row] = biv;
+      }
+    }
+  }
+  h2_store_rows<NV, RPW, NW, COH>(v, scale, tile, dim, row0, rows, out, R, rs);
+}
+
+// One LayerNorm row by ONE wave (torch semantics, biased variance), quantised straight into the h2 image: every lane stores its own
+// four-column groups (8 bytes per plane and group) -- no LDS tile, no barriers.  The body of layernorm_h2_direct_kernel
+// (gemm_h3.hip) and of the LayerNorm LEAD role of gemm_h3_kernel below (COH = true: every store write-through at agent scope, so
+// that a workgroup of the SAME launch on another XCD can read the row once its tile's ticket says so).  bound4 / bound_inv: the
+// FFN bound of layernorm_h2_kernel.  Per-row arithmetic identical to the tiled kernel: same bits.
+template <int NV, bool COH>
+__device__ __forceinline__ void ln_row_direct(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                              int dim, float eps, unsigned char* __restrict__ out, float* __restrict__ inv, int64_t R,
+                                              int64_t row, const f32x4 bound4, float* __restrict__ bound_inv) {
+  const int lane = threadIdx.x & 63;
+  const int n4 = dim >> 2;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      v[i] = xr[idx];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)dim;
+  float qs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < n4) {
+      const float d0 = v[i][0] - mean, d1 = v[i][1] - mean, d2 = v[i][2] - mean, d3 = v[i][3] - mean;
+      qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)dim + eps);
+  float amax = 0.f, ysq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < n4) {
+      const f32x4 wv = reinterpret_cast<const f32x4*>(w)[idx], bv = reinterpret_cast<const f32x4*>(b)[idx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+        amax = fmaxf(amax, fabsf(v[i][j]));
+        ysq += v[i][j] * v[i][j];
+      }
+    }
+  }
+  float iv;
+  const float scale = h2_row_scale(wave_max(amax), iv);
+  if (lane == 0) {
+    if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(inv + row), __float_as_uint(iv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else inv[row] = iv;
+  }
+  if (bound_inv) {
+    const float yn = sqrtf(wave_sum(ysq)) * 1.001f;
+    const float bg = yn * bound4[0] + bound4[1];
+    const float bd = (bound4[2] > 0.f || bound4[3] > 0.f) ? bg * (yn * bound4[2] + bound4[3]) : bg;
+    float biv;
+    h2_row_scale(fmaxf(bd * 1.001f, 1e-30f), biv);
+    if (lane == 0) {
+      if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(bound_inv + row), __float_as_uint(biv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else bound_inv[row] = biv;
+    }
+  }
+  const int swap = (int)((row >> 3) & 1);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;                        // columns 4 idx .. 4 idx + 3: k-block idx / 4, quarter idx % 4
+    if (idx < n4) {
+      unsigned h0, l0, h1, l1;
+      h2_pack2(v[i][0] * scale, v[i][1] * scale, h0, l0);
+      h2_pack2(v[i][2] * scale, v[i][3] * scale, h1, l1);
+      const int q = idx & 3;
+      unsigned char* dst = out + (((int64_t)(idx >> 2) * 2) * R + row) * 32 + (((q >> 1) ^ swap) << 4) + ((q & 1) << 3);
+      if constexpr (COH) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), ((unsigned long long)h1 << 32) | h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + R * 32), ((unsigned long long)l1 << 32) | l0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(dst + R * 32) = uint2{l0, l1};
+      }
+    }
+  }
+}
+
+// LNL (small-M plans of one image per call, gemm_h3s.hip): the launch's first p.ln_wgs workgroups are the LayerNorm LEAD role --
+// one row per wave, ln_row_direct<.., true> into this GEMM's own operand image; every wave drains its write-through stores, the
+// workgroup meets, one lane adds the workgroup's rows to the ticket of their BM-row tile (relaxed, agent scope: the hand-off of the
+// split-K plans below).  A GEMM workgroup waits (one lane polls, bounded) until its row tile's ticket holds all the tile's rows,
+// then stages A with sc1 loads.  Placement-independent: lead workgroups never wait, and there are fewer GEMM workgroups than CUs
+// (h3_ln_lead_feasible), so whatever order the dispatcher picks, every lead workgroup finds a CU.
+// LNL = 2 (batched GEMMs, gemm_h3.hip): lead workgroups of LEAD_ROWS = 16 rows (four per wave, the tiled arithmetic and store
+// order of layernorm_h2_kernel) are INTERLEAVED with the GEMM tiles per XCD (tile_order.hpp, LeadPlan: the lead work of tile-row
+// group j + 1 sits among the XCD's tiles of group j), so that LayerNorm's HBM traffic runs under the matrix work instead of in a
+// launch of its own.  In-order dispatch + "every producer has a smaller workgroup id than its consumers" (checked on the host
+// per shape) make it deadlock-free; the poll is bounded all the same.
+template <int MI, int NI, int WM, int WN, int STAGES, int OCC, int EPI, int KB = 1, int LNL = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p, int tiles_m, int tiles_n) {
   using Cfg = H3Cfg<MI, NI, WM, WN, STAGES, KB>;
   constexpr bool TR = EPI == EPI_SWIGLU_T || EPI == EPI_SWIGLU_T_H2;
@@ -83,13 +320,65 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
   // [s * kper, min(K16, (s + 1) * kper)) and the workgroup that draws the tile's last ticket sums the partial
   // accumulators IN SPLIT ORDER (deterministic whichever arrives last) and runs the epilogue
   int bid = blockIdx.x, split = 0;
+  int lead_tm = -1, lead_tn = -1;
+  if constexpr (LNL == 2) {
+    const LeadPlan lp{tiles_m, tiles_n, p.group_m, Cfg::BM, (long long)p.M};
+    const LeadRole role = lead_decode(lp, bid & 7, bid >> 3);
+    if (role.kind == 0) return;
+    if (role.kind == 2) {
+      // ---- LayerNorm lead role: rows role.row0 .. + 15 (four per wave), through a 16 x 256 tile of the idle ring ----
+      static_assert(Cfg::NW == 4 && Cfg::BM % LEAD_ROWS == 0 && Cfg::LDS >= LEAD_ROWS * 260 * 4, "lead role: four waves, whole lead blocks per tile row");
+      unsigned char* o2 = const_cast<unsigned char*>(p.A2);
+      const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o2, 0, (int)((int64_t)p.K16 * 2 * p.RA * 32), 0x00020000);
+      const f32x4 b4 = {p.ln_bound[0], p.ln_bound[1], p.ln_bound[2], p.ln_bound[3]};
+      ln_rows_tiled<6, 4, 4, true>(p.ln_x, p.ln_w, p.ln_b, p.ln_dim, p.M, p.ln_eps, o2, const_cast<float*>(p.a_inv), p.RA, role.row0, b4,
+                                   p.ln_has_bound ? const_cast<float*>(p.c_inv) : nullptr, reinterpret_cast<float(*)[256 + 4]>(smem), o_rsrc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its write-through stores have left
+      __syncthreads();
+      if (tid == 0) {
+        const int cnt = (int)min((int64_t)LEAD_ROWS, p.M - role.row0);
+        __hip_atomic_fetch_add(p.ln_tickets + role.row0 / Cfg::BM, (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    lead_tm = role.tm;
+    lead_tn = role.tn;
+  }
+  if constexpr (LNL == 1) {
+    if (bid < p.ln_wgs) {
+      // ---- LayerNorm lead role: rows bid * NW + wave ----
+      const int64_t row = (int64_t)bid * Cfg::NW + wave;
+      if (row < p.M) {
+        unsigned char* o2 = const_cast<unsigned char*>(p.A2);
+        float* oinv = const_cast<float*>(p.a_inv);
+        float* binv = p.ln_has_bound ? const_cast<float*>(p.c_inv) : nullptr;
+        const f32x4 b4 = {p.ln_bound[0], p.ln_bound[1], p.ln_bound[2], p.ln_bound[3]};
+        const int nv = (p.ln_dim / 4 + 63) / 64;
+        if (nv <= 2) ln_row_direct<2, true>(p.ln_x, p.ln_w, p.ln_b, p.ln_dim, p.ln_eps, o2, oinv, p.RA, row, b4, binv);
+        else if (nv <= 3) ln_row_direct<3, true>(p.ln_x, p.ln_w, p.ln_b, p.ln_dim, p.ln_eps, o2, oinv, p.RA, row, b4, binv);
+        else if (nv <= 4) ln_row_direct<4, true>(p.ln_x, p.ln_w, p.ln_b, p.ln_dim, p.ln_eps, o2, oinv, p.RA, row, b4, binv);
+        else if (nv <= 6) ln_row_direct<6, true>(p.ln_x, p.ln_w, p.ln_b, p.ln_dim, p.ln_eps, o2, oinv, p.RA, row, b4, binv);
+        else ln_row_direct<8, true>(p.ln_x, p.ln_w, p.ln_b, p.ln_dim, p.ln_eps, o2, oinv, p.RA, row, b4, binv);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave: its write-through stores have left
+      __syncthreads();
+      if (tid == 0) {
+        const int64_t r0 = (int64_t)bid * Cfg::NW;
+        const int cnt = (int)max((int64_t)0, min((int64_t)Cfg::NW, p.M - r0));       // (BM % NW == 0: one tile per workgroup)
+        if (cnt > 0) __hip_atomic_fetch_add(p.ln_tickets + r0 / Cfg::BM, (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    bid -= p.ln_wgs;                                       // (ln_wgs is a multiple of 8: the XCD of a GEMM workgroup is still bid % 8)
+  }
   const int ntiles = tiles_m * tiles_n;
   if (p.ksplit > 1) {
     split = bid / ntiles;
     bid -= split * ntiles;
   }
   int tm, tn;
-  xcd_grouped_tile(bid, tiles_m, tiles_n, p.group_m, tm, tn);
+  if constexpr (LNL == 2) { tm = lead_tm; tn = lead_tn; }
+  else xcd_grouped_tile(bid, tiles_m, tiles_n, p.group_m, tm, tn);
   const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
   const int kb0 = p.ksplit > 1 ? split * p.kper : 0;
   const int kend = p.ksplit > 1 ? min(p.K16, kb0 + p.kper) : p.K16;      // the descriptors end here: later k-blocks zero-fill
@@ -119,7 +408,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
       unsigned char* st = smem + stage * Cfg::STAGE + kb * Cfg::KSTAGE;
       const unsigned ao = (unsigned)(kb0 + ks * KB + kb) * a_slab, wo = (unsigned)(kb0 + ks * KB + kb) * w_slab;
 #pragma unroll
-      for (int i = 0; i < Cfg::A_DMA; ++i) dma16_to_lds(a_rsrc, st + a_dst[i], a_voff[i], ao);
+      for (int i = 0; i < Cfg::A_DMA; ++i) {
+        if constexpr (LNL) dma16_to_lds_sc1(a_rsrc, st + a_dst[i], a_voff[i], ao);
+        else dma16_to_lds(a_rsrc, st + a_dst[i], a_voff[i], ao);
+      }
 #pragma unroll
       for (int i = 0; i < Cfg::W_DMA; ++i) dma16_to_lds(w_rsrc, st + w_dst[i], w_voff[i], wo);
     }
@@ -137,6 +429,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_h3_kernel(H3Problem p,
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
   const int nk = (kend - kb0 + KB - 1) / KB;               // stage steps
+  if constexpr (LNL) {
+    // the rows of this tile come from the lead role of this launch: wait for the tile's ticket (one lane polls; bounded -- a
+    // lost hand-off must not hang the device: it would show as a wrong result in every test instead)
+    if (tid == 0) {
+      const unsigned need = (unsigned)min((int64_t)Cfg::BM, p.M - m0);
+      unsigned spins = 0;
+      while (__hip_atomic_load(p.ln_tickets + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1u << 24))
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
 

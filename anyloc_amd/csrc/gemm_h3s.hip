@@ -27,10 +27,35 @@ constexpr int NCFG = 8;
 const int kCfgBM[NCFG] = {64, 64, 64, 64, 128, 64, 64, 192};
 const int kCfgBN[NCFG] = {64, 128, 128, 128, 128, 256, 256, 128};
 
+// the plans the LayerNorm lead role is compiled for: the one-image qkv plan (128 x 128, 6-deep ring) and the one-image w12 plan
+// (192 x 128, 6-deep ring), with the epilogues those two GEMMs have in the fused forward
+template <int EPI, int MI, int NI, int WM, int WN, int KB, int ST>
+constexpr bool ln_lead_compiled() {
+  return KB == 1 && ST == 6 && WM == 2 && WN == 2 && NI == 2 &&
+         ((MI == 2 && EPI == EPI_QKV_PLANES) || (MI == 3 && (EPI == EPI_SWIGLU_T_H2 || EPI == EPI_SWIGLU_H2)));
+}
+constexpr int LN_LEAD_MAX_TILES = 200;        // GEMM workgroups of a lead launch: fewer than CUs, so the lead workgroups always find one
+
 template <int EPI, int MI, int NI, int WM, int WN, int KB, int ST = 3>
 int launch_small(const H3Problem& p, hipStream_t stream) {
   using Cfg = H3Cfg<MI, NI, WM, WN, ST, KB>;
   const int tiles_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM), tiles_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
+  if constexpr (ln_lead_compiled<EPI, MI, NI, WM, WN, KB, ST>()) {
+    if (p.ln_x) {
+      ANYLOC_CHECK_ARG(p.ksplit <= 1 && tiles_m * tiles_n <= LN_LEAD_MAX_TILES && p.ln_tickets && p.ln_w && p.ln_b &&
+                           (!p.ln_has_bound || p.c_inv) && p.ln_dim == 16 * p.K16 && Cfg::BM % Cfg::NW == 0,
+                       "gemm_h3_small: LayerNorm lead role asked for a launch it does not fit (h3s_ln_lead_feasible)");
+      H3Problem q = p;
+      q.ln_wgs = (int)(((p.M + Cfg::NW - 1) / Cfg::NW + 7) / 8 * 8);        // one row per wave; a multiple of 8 (XCD mapping of the GEMM ids)
+      static DynLds dyn_lds_once;
+      ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB, 1>), (int)(Cfg::LDS)));
+      hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB, 1>), dim3((unsigned)(q.ln_wgs + tiles_m * tiles_n)),
+                         dim3(64 * WM * WN), Cfg::LDS, stream, q, tiles_m, tiles_n);
+      return launch_status("gemm_h3_kernel (small-M plan, LayerNorm lead role)");
+    }
+  } else {
+    ANYLOC_CHECK_ARG(!p.ln_x, "gemm_h3_small: LayerNorm lead role asked for a plan it is not compiled for (h3s_ln_lead_feasible)");
+  }
   static DynLds dyn_lds_once;
   ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>), (int)(Cfg::LDS)));
   hipLaunchKernelGGL((gemm_h3_kernel<MI, NI, WM, WN, ST, 2, EPI, KB>), dim3((unsigned)(tiles_m * tiles_n * std::max(1, p.ksplit))),
@@ -149,6 +174,29 @@ Plan choose(const H3Problem& p, int epilogue) {
 
 }  // namespace
 
+// the plan gemm_h3_small will run (shared by it and by h3s_ln_lead_feasible)
+static Plan final_plan(H3Problem& p, int epilogue) {
+  Plan pl = choose(p, epilogue);
+  const int64_t tiles = cdiv(p.M, kCfgBM[pl.cfg]) * cdiv(p.N, kCfgBN[pl.cfg]);
+  if (!p.sk_part || !p.sk_tickets || p.accumulate) pl.ksplit = 1;
+  pl.ksplit = (int)std::min<int64_t>(pl.ksplit, p.K16);
+  while (pl.ksplit > 1 && ((size_t)pl.ksplit * tiles * kCfgBM[pl.cfg] * kCfgBN[pl.cfg] * sizeof(float) > H3_SPLIT_PART_BYTES ||
+                           tiles > (int64_t)H3_SPLIT_TICKETS))
+    --pl.ksplit;
+  return pl;
+}
+
+bool h3s_ln_lead_feasible(const H3Problem& p_in, int epilogue) {
+  if (option(OPT_H3S_LN_LEAD) == 0 || option(OPT_H3_CFG) != 0) return false;
+  if (epilogue != EPI_QKV_PLANES && epilogue != EPI_SWIGLU_T_H2 && epilogue != EPI_SWIGLU_H2) return false;
+  if (((p_in.M + 127) / 128) * ((p_in.N + 255) / 256) >= 512) return false;        // (dispatch_h3's small-M rule)
+  H3Problem p = p_in;
+  const Plan pl = final_plan(p, epilogue);
+  if (pl.ksplit != 1 || pl.kb != 1 || pl.stages != 6) return false;
+  if (!((pl.cfg == 4 && epilogue == EPI_QKV_PLANES) || (pl.cfg == 7 && epilogue != EPI_QKV_PLANES))) return false;
+  return cdiv(p.M, kCfgBM[pl.cfg]) * cdiv(p.N, kCfgBN[pl.cfg]) <= LN_LEAD_MAX_TILES;
+}
+
 bool h3_small_supported(int epilogue) {
   switch (epilogue) {
     case EPI_STORE: case EPI_LS_RESID: case EPI_QKV_PLANES: case EPI_GELU_H2: case EPI_SWIGLU_H2: case EPI_SWIGLU_T_H2: return true;
@@ -158,15 +206,9 @@ bool h3_small_supported(int epilogue) {
 
 int gemm_h3_small(const H3Problem& p_in, int epilogue, hipStream_t stream) {
   H3Problem p = p_in;
-  Plan pl = choose(p, epilogue);
   // the epilogues that write q|k|v tiles need whole heads per wave column block: NI even (all configurations have it)
   // split-K needs the workspace, a plain (non-accumulating) epilogue input and enough k-blocks
-  const int64_t tiles = cdiv(p.M, kCfgBM[pl.cfg]) * cdiv(p.N, kCfgBN[pl.cfg]);
-  if (!p.sk_part || !p.sk_tickets || p.accumulate) pl.ksplit = 1;
-  pl.ksplit = (int)std::min<int64_t>(pl.ksplit, p.K16);
-  while (pl.ksplit > 1 && ((size_t)pl.ksplit * tiles * kCfgBM[pl.cfg] * kCfgBN[pl.cfg] * sizeof(float) > H3_SPLIT_PART_BYTES ||
-                           tiles > (int64_t)H3_SPLIT_TICKETS))
-    --pl.ksplit;
+  Plan pl = final_plan(p, epilogue);
   p.ksplit = pl.ksplit;
   // k-blocks per split: a multiple of the ring stage's k-blocks, so that only the LAST split can end inside a stage
   // (its missing k-blocks lie beyond the buffer descriptors and read as zeros)

@@ -55,8 +55,10 @@ struct VitWs {
   float* qinv;              // fp16 mode, fused attention: 2^-e per (part, head, 32-row group) tile of q | k | v (in qkv)
   float* sk_part;           // fp16 mode, small-M plans: partial accumulators of a split-K launch (gemm_h3s.hip)
   unsigned* sk_tickets;     //                           arrival counters per tile, zero between launches
-  unsigned* hmax;           // fp16 mode, FFN-bound telemetry: [depth][M] largest scaled magnitude per row (bits), RIGHT BEHIND the
-                            // tickets so that one memset clears both
+  unsigned* ln_tickets;     // fp16 mode, LayerNorm lead role (gemm_h3_kernel.hpp): [depth][2][ln_tk] rows done per 128-row tile of a lead launch
+  size_t ln_tk;             //   words per launch: max(16, ceil(M / 128))
+  unsigned* hmax;           // fp16 mode, FFN-bound telemetry: [depth][M] largest scaled magnitude per row (bits); tickets, lead
+                            // tickets and these lie back to back so that ONE memset per forward clears them
   size_t bytes;
 };
 
@@ -78,6 +80,8 @@ VitWs carve(void* ws, size_t cap, const anyloc_vit_config& c, int64_t batch, int
   w.qinv = a.take<float>(qkv_inv_count(M, c.heads));
   w.sk_part = a.take<float>(H3_SPLIT_PART_BYTES / sizeof(float));
   w.sk_tickets = a.take<unsigned>(H3_SPLIT_TICKETS);
+  w.ln_tk = std::max<size_t>(16, (size_t)((M + 127) / 128));
+  w.ln_tickets = a.take<unsigned>((size_t)c.depth * 2 * w.ln_tk);
   w.hmax = a.take<unsigned>((size_t)c.depth * M);
   w.bytes = a.off;
   return w;
@@ -125,11 +129,18 @@ int linear_x6(const float* A, int64_t K, unsigned char* a3, const void* w3, int6
 
 // the same linear layer on the row-scaled two-term fp16 GEMM (gemm_h3.hip).  A == nullptr: a2 / ainv already hold the
 // quantised operand (written by layernorm_h2); otherwise A (fp32, row-major, width K) is quantised here first.
+// a LayerNorm whose output is the GEMM's own operand image (a2 / ainv; with `bound` also the FFN bound into c_inv)
+struct LnFront {
+  const float *x, *w, *b;
+  const float* bound;       // HOST [4] or null
+  unsigned* tickets;        // zeroed words of this launch, one per 128-row tile (VitWs::ln_tk)
+};
+
 int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const void* w2, const float* winv, int64_t w_rows,
               int64_t w_row0, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int epi, const float* gamma,
               const char* tag, hipStream_t stream, unsigned char* c2 = nullptr, const float* c_inv = nullptr,
               unsigned char* qkv_planes = nullptr, float* qkv_inv = nullptr, int heads = 0, const VitWs* ws = nullptr,
-              int kind = H3_KIND_OTHER, unsigned* c_max = nullptr) {
+              int kind = H3_KIND_OTHER, unsigned* c_max = nullptr, const LnFront* ln = nullptr) {
   if (A) ANYLOC_TRY(split_h2(A, K, M, K, a2, ainv, stream));
   H3Problem g{};
   if (ws) { g.sk_part = ws->sk_part; g.sk_tickets = ws->sk_tickets; }
@@ -145,6 +156,18 @@ int linear_h3(const float* A, int64_t K, unsigned char* a2, float* ainv, const v
   g.gamma = gamma;
   g.resid = C;
   g.tag = tag;
+  if (ln) {
+    // LayerNorm in front of this GEMM: as the lead role of the GEMM's own launch where the small-M plan has it (one image per
+    // call: LN1 + qkv, LN2 + w12), as a launch of its own otherwise -- the same arithmetic, the same bits
+    if (h3_ln_lead_feasible(g, epi)) {
+      g.ln_x = ln->x; g.ln_w = ln->w; g.ln_b = ln->b; g.ln_eps = 1e-6f; g.ln_dim = (int)K;
+      g.ln_has_bound = ln->bound != nullptr;
+      for (int i = 0; i < 4; ++i) g.ln_bound[i] = ln->bound ? ln->bound[i] : 0.0f;
+      g.ln_tickets = ln->tickets;
+    } else {
+      ANYLOC_TRY(layernorm_h2(ln->x, ln->w, ln->b, M, (int)K, 1e-6f, a2, ainv, stream, ln->bound, ln->bound ? const_cast<float*>(c_inv) : nullptr));
+    }
+  }
   return gemm_h3(g, epi, stream);
 }
 
@@ -357,7 +380,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
   if (h3m)
     ANYLOC_HIP(hipMemsetAsync(w.sk_tickets, 0,
                               telem ? (size_t)(reinterpret_cast<char*>(w.hmax + (size_t)(last_layer + 1) * M) - reinterpret_cast<char*>(w.sk_tickets))
-                                    : H3_SPLIT_TICKETS * sizeof(unsigned),
+                                    : (size_t)(reinterpret_cast<char*>(w.hmax) - reinterpret_cast<char*>(w.sk_tickets)),
                               stream));
   // does any tap need the block OUTPUT of the last executed layer?
   bool last_needs_full = false;
@@ -401,7 +424,15 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
     const bool last = (l == last_layer);
     // split-bf16 mode, fused producers: LayerNorm / attention / FFN activation write plane images directly
     const bool fuse = fuse_x6;
-    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, w.ainv, stream));
+    bool qkv_tap0 = false;                      // (decided here already: a q / k / v tap keeps the unfused attention data flow)
+    for (int t = 0; t < n_taps; ++t)
+      if (tap_layers[t] == l && tap_facets[t] != ANYLOC_FACET_TOKEN) qkv_tap0 = true;
+    // fp16 mode, fused attention: LayerNorm 1 travels with the QKV GEMM (linear_h3's `ln`: lead role of that launch for one image
+    // per call, a launch of its own otherwise)
+    const bool ln1_with_qkv = h3f && !qkv_tap0 && D % 128 == 0 && !(last && !last_needs_full);
+    const LnFront ln1{w.x, b.norm1_w, b.norm1_b, nullptr, w.ln_tickets + (size_t)l * 2 * w.ln_tk};
+    if (h3m && !ln1_with_qkv) ANYLOC_TRY(layernorm_h2(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, w.ainv, stream));
+    else if (h3m) {}
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm1_w, b.norm1_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm1_w, b.norm1_b, M, D, 1e-6f, stream));
     const float* y_in = fuse ? nullptr : w.y;     // nullptr: the plane image is already in w.a3
@@ -434,7 +465,7 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       // the image of the projection GEMM -- q, k, v and the attention output never exist in fp32
       ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].qkv_w2, h->h2[l].qkv_inv, 3 * D, 0, b.qkv_b, nullptr, 3 * D, M,
                            3 * D, EPI_QKV_PLANES, nullptr, "vit_qkv_gemm", stream, nullptr, nullptr,
-                           reinterpret_cast<unsigned char*>(w.qkv), w.qinv, c.heads, &w, H3_KIND_QKV));
+                           reinterpret_cast<unsigned char*>(w.qkv), w.qinv, c.heads, &w, H3_KIND_QKV, nullptr, &ln1));
       ANYLOC_TRY(attention_h3(reinterpret_cast<const unsigned char*>(w.qkv), w.qinv, batch, T, D, c.heads, w.a3, w.ainv, stream));
       ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].proj_w2, h->h2[l].proj_inv, D, 0, b.proj_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls1, "vit_proj_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_PROJ));
@@ -463,7 +494,11 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
     }
     const float* fb = h3f ? h->h2[l].fc1_bound : nullptr;
     const bool fuse_ffn = fb && (fb[0] > 0.f || fb[1] > 0.f) && !(l < (int)h->ffn_exact.size() && h->ffn_exact[l]);
-    if (h3m) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, fuse_ffn ? fb : nullptr, w.hinv));
+    // (fused FFN: LayerNorm 2 travels with the fc1 / w12 GEMM the same way)
+    const bool ln2_with_fc1 = h3m && fuse_ffn;
+    const LnFront ln2{w.x, b.norm2_w, b.norm2_b, fb, w.ln_tickets + ((size_t)l * 2 + 1) * w.ln_tk};
+    if (h3m && !ln2_with_fc1) ANYLOC_TRY(layernorm_h2(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, w.ainv, stream, nullptr, w.hinv));
+    else if (h3m) {}
     else if (fuse) ANYLOC_TRY(layernorm_x3(w.x, b.norm2_w, b.norm2_b, M, D, 1e-6f, w.a3, stream));
     else ANYLOC_TRY(layernorm(w.x, w.y, b.norm2_w, b.norm2_b, M, D, 1e-6f, stream));
     const int Hh = c.ffn_hidden;
@@ -472,12 +507,12 @@ static int vit_forward_launches(anyloc_vit_t* h, const float* img, int64_t batch
       if (c.ffn_kind == 0)
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, Hh, 0, b.fc1_b, nullptr, Hh, M, Hh,
                              EPI_GELU_H2, nullptr, "vit_fc1_gemm", stream, w.h3, w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1,
-                             telem ? w.hmax + (size_t)l * M : nullptr));
+                             telem ? w.hmax + (size_t)l * M : nullptr, &ln2));
       else
         ANYLOC_TRY(linear_h3(nullptr, D, w.a3, w.ainv, h->h2[l].fc1_w2, h->h2[l].fc1_inv, 2 * Hh, 0,
                              h->h2[l].fc1_b2 ? h->h2[l].fc1_b2 : b.fc1_b, nullptr, Hh, M, 2 * Hh,
                              h->h2[l].fc1_layout == 1 ? EPI_SWIGLU_T_H2 : EPI_SWIGLU_H2, nullptr, "vit_w12_gemm", stream, w.h3,
-                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1, telem ? w.hmax + (size_t)l * M : nullptr));
+                             w.hinv, nullptr, nullptr, 0, &w, H3_KIND_FC1, telem ? w.hmax + (size_t)l * M : nullptr, &ln2));
       ANYLOC_TRY(linear_h3(nullptr, Hh, w.h3, w.hinv, h->h2[l].fc2_w2, h->h2[l].fc2_inv, D, 0, b.fc2_b, w.x, D, M, D,
                            EPI_LS_RESID, b.ls2, "vit_fc2_gemm", stream, nullptr, nullptr, nullptr, nullptr, 0, &w, H3_KIND_FC2));
     } else if (h3m) {

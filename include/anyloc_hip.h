@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ANYLOC_ABI_VERSION 8
+#define ANYLOC_ABI_VERSION 9
 
 typedef enum anyloc_status {
   ANYLOC_OK = 0,
@@ -70,6 +70,15 @@ const char* anyloc_last_error(void);
  *                                     chain of key tiles; partial sums meet in LDS), 1 = none, 0 = 2 when all workgroups are resident
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
+ *   h3_ln_lead (0)                    batched calls (>= 64 tile rows of 128 tokens): 1 = LayerNorm 1 / 2 run as LEAD workgroups of 16 rows
+ *                                     interleaved with the tiles of the qkv / fc1 (w12) GEMM's own launch (per XCD: the lead work of the next
+ *                                     tile-row group sits among the tiles of the current one; write-through stores, one ticket per tile row);
+ *                                     same bits as the separate launch -- and 5 % SLOWER end to end (profiles/r06_batched_ln_lead.log: a lead
+ *                                     workgroup holds a GEMM slot for ~50 us and its vector work takes issue slots from the matrix work)
+ *   h3s_ln_lead (0)                   one image per call: 1 = LayerNorm runs as the LEAD role of its consumer GEMM's launch (LN1 + qkv, LN2 + w12:
+ *                                     the first workgroups normalise the rows write-through and count them per row tile, a GEMM workgroup waits
+ *                                     for its tile's count) instead of as a launch of its own; same bits, 163 launches per ViT-g forward instead
+ *                                     of 225 -- and the same 5.55 ms (profiles/r06_b1_ln_lead.log: the hand-off costs what the launch cost)
  *   vlad_gather_v (0)                 one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the round-6
  *                                     hazard study (tools/stress_vlad.py); 0 = the shipped arithmetic
  *   kmeans_max_chunks (0 = two per CU)
@@ -158,6 +167,12 @@ int anyloc_split_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, void* 
 int anyloc_gemm_nt_h3(const void* a2, const float* a_inv, const void* w2,
                       const float* w_inv, const float* bias, float* C, int64_t ldc,
                       int64_t M, int64_t N, int64_t K, void* stream);
+/* ABI 9 (diagnostic, host only -- no device is touched): the batched ViT forward runs LayerNorm as LEAD workgroups inside its
+ * consumer GEMM's launch (option h3_ln_lead; csrc/tile_order.hpp: LeadPlan).  The plan of a shape -- tiles_m x tiles_n tiles of
+ * 128 rows, scheduling groups of group_m tile rows, M rows -- is simulated on the host before it is used: every GEMM tile exactly
+ * once, every row normalised exactly once, every producer ahead of its consumers in workgroup-id order.  Returns 1 when the plan
+ * passes (and *grid = workgroups of the launch), 0 when the forward keeps LayerNorm as a launch of its own for this shape. */
+int anyloc_h3_lead_plan_check(int32_t tiles_m, int32_t tiles_n, int32_t group_m, int64_t M, uint32_t* grid);
 
 /* ------------------------------------------------------------ pooling ----
  * One global descriptor per image from its patch tokens, without VLAD:

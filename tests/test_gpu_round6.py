@@ -194,3 +194,95 @@ def test_ffn_telemetry_on_the_swiglu_epilogues_against_the_image_itself():
                     assert float((alone / fig[:, 1] - 1).abs().max()) < 1e-3, (alone, fig[:, 1])
     finally:
         weights.unregister_state_dict(name)
+
+
+@pytest.mark.parametrize("facet,layer", [("value", 2), ("token", 2), ("token", 1)])
+def test_layernorm_lead_role_gives_the_bits_of_the_separate_launch(facet, layer):
+    """One image per call (option h3s_ln_lead, csrc/gemm_h3_kernel.hpp): LayerNorm 1 / 2 run as the first workgroups of the qkv /
+    w12 GEMM's own launch -- rows stored write-through into that GEMM's operand image, one relaxed agent-scope ticket per row tile,
+    a GEMM workgroup waits for its tile's count and stages A with sc1 loads.  Same per-row arithmetic as layernorm_h2: the tokens
+    must equal, bit for bit, those of the seven-launch block, on every one of 40 repeats (a stale operand row -- the failure this
+    hand-off could have -- shows as a differing run), with and without the FFN-bound telemetry, at 322 x 322 (530 rows) and
+    224 x 224 (257 rows); a 476 x 630 image (1 531 rows: more GEMM workgroups than the lead role allows) takes the separate
+    launch under either setting.  `layer` 1 of 3 blocks leaves the last block's output unused; "value" keeps the v tap."""
+    import utilities
+    from anyloc_amd import ops, synth, weights
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 6, device=DEV, depth=3))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, layer, facet, device=DEV)
+        for hw, check in (((322, 322), True), ((322, 322), False), ((224, 224), True), ((476, 630), True)):
+            ext.dino_model.ffn_check = check
+            img = torch.randn(1, 3, *hw, generator=torch.Generator().manual_seed(hw[1])).to(DEV)
+            with ops.options(h3s_ln_lead=0):
+                want = ext(img).clone()
+            assert torch.isfinite(want).all()
+            with ops.options(h3s_ln_lead=1):
+                for rep in range(40):
+                    assert torch.equal(ext(img), want), (hw, check, rep, "the lead-role forward differs from the separate launches")
+    finally:
+        weights.unregister_state_dict(name)
+
+
+def test_layernorm_lead_role_under_load_on_the_full_depth_forward():
+    """The same hand-off with the chip busy: 32-block ViT-g forwards of one image, another stream running batched GEMM work
+    meanwhile (its workgroups take CUs away from the lead launch in an order the launch does not choose); 30 forwards, one set of
+    bits."""
+    import utilities
+    from anyloc_amd import ops, synth, weights
+    name = "dinov2_vitg14"
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 7, device=DEV, depth=32))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 31, "value", device=DEV)
+        img = torch.randn(1, 3, 322, 322, generator=torch.Generator().manual_seed(5)).to(DEV)
+        with ops.options(h3s_ln_lead=0):
+            want = ext(img).clone()
+        side = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device=DEV)
+        with ops.options(h3s_ln_lead=1):
+            for rep in range(30):
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        a @ a
+                assert torch.equal(ext(img), want), rep
+        torch.cuda.synchronize()
+    finally:
+        weights.unregister_state_dict(name)
+
+
+@pytest.mark.parametrize("name,hw,batch,facet", [("dinov2_vitg14", (322, 322), 17, "token"), ("dinov2_vitg14", (322, 322), 24, "value"),
+                                                 ("dinov2_vitl14", (518, 518), 7, "token")])
+def test_batched_layernorm_lead_role_gives_the_bits_of_the_separate_launch(name, hw, batch, facet):
+    """Batched calls (option h3_ln_lead, csrc/gemm_h3_kernel.hpp LNL = 2, csrc/tile_order.hpp LeadPlan): LayerNorm 1 / 2 run as
+    lead workgroups of 16 rows interleaved, per XCD, with the tiles of the qkv / w12 (ViT-L: fc1, GELU epilogue) GEMM's own launch;
+    rows stored write-through, one ticket per 128-row tile, a GEMM tile waits for its row's count.  Same per-row arithmetic and
+    store order as layernorm_h2_kernel: the tokens must equal, bit for bit, those of the separate launches on each of 12 repeats
+    (a stale or missing operand row shows as a differing run).  >= 64 tile rows are needed for the plan (17 images x 530 rows)."""
+    import utilities
+    from anyloc_amd import ops, synth, weights
+    weights.register_state_dict(name, synth.synthetic_state_dict(name, 8, device=DEV, depth=3))
+    try:
+        ext = utilities.DinoV2ExtractFeatures(name, 2, facet, device=DEV)
+        img = torch.randn(batch, 3, *hw, generator=torch.Generator().manual_seed(batch)).to(DEV)
+        for check in (True, False):
+            ext.dino_model.ffn_check = check
+            with ops.options(h3_ln_lead=0):
+                ops.profile_enable(True); ops.profile_reset()
+                want = ext(img).clone()
+                torch.cuda.synchronize()
+                assert "layernorm_h2" in ops.profile_dump()
+            with ops.options(h3_ln_lead=1):
+                ops.profile_reset()
+                got = ext(img).clone()
+                torch.cuda.synchronize()
+                prof = ops.profile_dump()
+                ops.profile_enable(False)
+                # the lead role took the LayerNorm launches in front of the fused GEMMs (what is left: the last block's LN1 when a q / k / v
+                # facet is tapped there)
+                assert prof.get("layernorm_h2", {"calls": 0})["calls"] <= 1, prof.get("layernorm_h2")
+                assert torch.isfinite(want).all() and torch.equal(got, want)
+                for rep in range(12):
+                    assert torch.equal(ext(img), want), (check, rep, "the lead-role forward differs from the separate launches")
+    finally:
+        ops.profile_enable(False)
+        weights.unregister_state_dict(name)

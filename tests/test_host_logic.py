@@ -251,3 +251,25 @@ def test_reduce_pca_surface_matches_reference_function(monkeypatch, capsys):
     # the lowest-variance axes of a rank-deficient matrix are not unique: compare the well-defined top half
     m = np.abs(b_tr[:, :3]).max()
     assert np.abs(a_tr[:, :3] - b_tr[:, :3]).max() < 5e-4 * m
+
+
+def test_lead_plans_of_the_batched_layernorm_role_pass_the_host_check():
+    """csrc/tile_order.hpp LeadPlan (ABI 9 diagnostic, host only): for every shape the batched forward can meet -- tile rows x tile
+    columns x scheduling group x row count -- the simulated launch holds every GEMM tile once, normalises every row once and puts
+    every producer ahead of its consumers in workgroup-id order; shapes with fewer than 8 scheduling groups are refused (the
+    forward keeps two launches)."""
+    import ctypes as C
+    from anyloc_amd import _lib
+    lib = _lib.load()
+    g = C.c_uint32()
+    for M in (32330, 8480, 8192, 8193, 109600, 16165, 5300, 64 * 128 - 1, 12345, 1370 * 80, 257 * 40, 1531 * 8):
+        tm = (M + 127) // 128
+        for tn in (12, 16, 18, 32, 6, 7, 33):
+            for gm in (8, 4, 1, 16, 3):
+                ok = lib.anyloc_h3_lead_plan_check(tm, tn, gm, M, C.byref(g))
+                assert bool(ok) == (tm >= 8 * gm), (M, tn, gm, ok)
+                if ok:
+                    leads = (M + 15) // 16
+                    assert tm * tn + leads <= g.value < tm * tn + leads + 8 * 16 * gm + 64, (M, tn, gm, g.value)
+    assert lib.anyloc_h3_lead_plan_check(70, 18, 8, 70 * 128 + 5, C.byref(g)) == 0          # rows and tile rows disagree
+    assert lib.anyloc_h3_lead_plan_check(0, 18, 8, 100, None) == 0
