@@ -105,6 +105,8 @@ SIGNATURES = {
     "anyloc_topk_index_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "anyloc_topk_search_index": (C.c_int, [c_f32p, c_i64, C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.c_uint, c_i64, c_f32p,
                                            c_i64p, C.c_void_p, c_sz, C.c_void_p]),
+    "anyloc_topk_search_index_rows": (C.c_int, [c_f32p, c_i64, c_f32p, C.c_void_p, c_i64, c_i64, c_i64, C.c_int, C.c_uint, c_i64,
+                                                c_f32p, c_i64p, C.c_void_p, c_sz, C.c_void_p]),
     "anyloc_vit_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(VitConfig), c_f32p, c_f32p,
                                     c_f32p, C.POINTER(VitBlockWeights)]),
     "anyloc_vit_destroy": (None, [C.c_void_p]),

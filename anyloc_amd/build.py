@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libanyloc_hip.so")
-SOURCES = ["runtime.hip", "gemm_f32.hip", "rows.hip", "attention.hip", "vit.hip", "vlad.hip", "vlad_fused.hip", "topk.hip", "scores_x6.hip", "scores_h3.hip", "pool.hip", "pca_f64.hip", "gemm_x6.hip", "gemm_h3.hip", "gemm_h3s.hip", "gemm_h3m.hip"]
+SOURCES = ["runtime.hip", "gemm_f32.hip", "rows.hip", "attention.hip", "vit.hip", "vlad.hip", "vlad_fused.hip", "topk.hip", "scores_x6.hip", "scores_h3.hip", "scores_screen.hip", "pool.hip", "pca_f64.hip", "gemm_x6.hip", "gemm_h3.hip", "gemm_h3s.hip", "gemm_h3m.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]

@@ -98,6 +98,7 @@ enum Option {
   OPT_H3S_LN_LEAD,       // one image per call: LayerNorm as the lead role of its consumer GEMM's launch (LN1 + qkv, LN2 + w12); 0 = two launches
   OPT_H3_LN_LEAD,        // batched calls: LayerNorm as lead workgroups interleaved with its consumer GEMM's tiles (LN1 + qkv, LN2 + fc1 / w12); 0 = two launches
   OPT_VLAD_GATHER_V,     // one-pass VLAD kernel at D = 1536: variants of the register-indexed gather kept for the hazard study (0 = shipped)
+  OPT_TOPK_SCREEN,       // many-query retrieval: score panels on the leading fp16 planes + exact re-scoring of the rows inside the bound (scores_screen.hip): -1 = where it pays, 0 = never, 1 = wherever possible
   OPT_COUNT
 };
 int64_t option(Option o);
@@ -320,6 +321,22 @@ int h3_lead_plan_check(int tiles_m, int tiles_n, int group_m, int64_t M, unsigne
 int gemm_h3_small(const H3Problem& p, int epilogue, hipStream_t stream);
 // the same GEMM on v_mfma_f32_16x16x32_f16 (gemm_h3m.hip); ANYLOC_ERR_UNSUPPORTED for epilogues it does not have
 int gemm_h3m(const H3Problem& p, int epilogue, hipStream_t stream);
+// screened retrieval (scores_screen.hip)
+float screen_accum(int k16_chunk, int chunks);
+int screen_resid(const unsigned char* img, int64_t R, int K16, int64_t rows, const float* inv, const float* ss, float* rho,
+                 unsigned* rho_max, hipStream_t stream);
+int gemm_screen(const H3Problem& p, hipStream_t stream);
+int screen_rho_max(const float* rho, int64_t n, unsigned* rho_max, hipStream_t stream);
+int screen_margins(const float* qn, const float* rho_q, const unsigned* rho_max, int64_t nq, int metric, float accum, float* margin,
+                   hipStream_t stream);
+int screen_compact(const float* scores, int64_t ld, int64_t ncols, int64_t nq, int k, int metric, const float* qn, const float* dn,
+                   const float* dnorm, const float* thr, const float* margin, int cmax, int* cand, int* count, int* overflow,
+                   hipStream_t stream);
+bool screen_rescore_supported(int64_t dim);
+int screen_rescore(const float* queries, const float* db, int64_t dim, int64_t nq, int cmax, const int* cand, const int* count,
+                   int metric, const float* qn, const float* dn, const float* dnorm, float* cand_v, hipStream_t stream);
+int screen_select(const int* cand, const float* cand_v, const int* count, int cmax, int64_t col_base, int64_t nq, int k, float* run_v,
+                  int64_t* run_i, int first, hipStream_t stream);
 
 int l2norm_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
                 int64_t dim, float eps, hipStream_t stream);

@@ -51,7 +51,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"kmeans_fused_v", 0},    {"kmeans_max_chunks", 0}, {"h3_mfma16", -1}, {"h3_swiglu_t", 1}, {"h3_fast_silu", 1}, {"topk_fewq_x6", 2}, {"topk_h3", -1},
     {"h3s_cfg", -1}, {"h3s_ksplit", 0}, {"h3s_kb", 0}, {"h3s_stages", 0}, {"h3s_mask", 31}, {"h3s_enable", 1}, {"h3_patch", 1}, {"topk_fewq_qdma", 1},
     {"h3s_w12_tall", 1},      {"attn_h3_qg", 1},     {"attn_h3_ks", 0},
-    {"h3s_ln_lead", 0},       {"h3_ln_lead", 0},       {"vlad_gather_v", 0},
+    {"h3s_ln_lead", 0},       {"h3_ln_lead", 0},       {"vlad_gather_v", 0},    {"topk_screen", -1},
 };
 std::mutex g_opt_mu;
 int64_t g_opt[OPT_COUNT];

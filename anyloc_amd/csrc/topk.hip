@@ -280,7 +280,17 @@ bool h3_scores(int64_t nq, int64_t ndb, int64_t dim) {
   return mode > 0 || (nq >= 256 && dim >= 1024 && ndb >= 2048);
 }
 
+// Screened search (scores_screen.hip): the leading-plane scores of a whole range of database columns [nq, sc_cols], the
+// screened running lists, the per-query margin, the candidates and their re-scored values
+constexpr int SCREEN_CMAX = 512;          // candidates per query and column range; more: the call re-runs unscreened
+constexpr int SCREEN_KMAX = 128;
+constexpr int64_t SCREEN_COLS = 131072;   // database columns per range (a multiple of the panel)
+constexpr size_t SCREEN_SBUF_MAX = 12ull << 30;
 struct TopkWs {
+  float *sbuf, *scr_v, *margin, *cand_v, *rho_q, *rho_d;
+  long long* scr_i;
+  int *cand, *count, *overflow;
+  int64_t sc_cols;                 // 0: no screened search for this shape
   float *scores, *qn, *dn, *dss, *dnorm, *part, *rsq_part;
   unsigned char *qimg, *dimg;      // h3 path: operand images of the queries (per chunk of q_chunk rows) and of one panel
   float *qinv, *dinv;
@@ -290,12 +300,12 @@ struct TopkWs {
 // A prepared database (anyloc_topk_index_build: faiss' index.add): per panel of index_panel(dim) rows the two-plane fp16 image
 // the score GEMM reads, then the rows' 2^-e and their raw sums of squares.  Layout inside the caller's buffer:
 //   [n_panels][align256(h2_bytes(panel, dim))] images (a shorter last panel: an image of its own row count at its slot)
-//   [ndb] float 2^-e      [ndb] float sum of squares
+//   [ndb] float 2^-e      [ndb] float sum of squares      [ndb] float relative residual norm (ABI 9)
 int64_t index_panel(int64_t dim) { return std::min(H3_PANEL, h3_rows_limit(dim)); }
 bool index_supported(int64_t ndb, int64_t dim) { return ndb > 0 && dim % 16 == 0 && dim >= 16 && h3_rows_limit(dim) >= 256; }
 struct IndexView {
   unsigned char* img;
-  float *dinv, *dss;
+  float *dinv, *dss, *drho;        // drho (ABI 9): |row - leading plane| / |row|, the screened search's bound (scores_screen.hip)
   int64_t panel;
   size_t slot, bytes;
 };
@@ -308,11 +318,26 @@ IndexView index_view(void* p, int64_t ndb, int64_t dim) {
   v.img = b;
   v.dinv = reinterpret_cast<float*>(b + (size_t)np * v.slot);
   v.dss = v.dinv + align_up((size_t)ndb, 64);
-  v.bytes = (size_t)np * v.slot + 2 * align_up((size_t)ndb, 64) * sizeof(float);
+  v.drho = v.dss + align_up((size_t)ndb, 64);
+  v.bytes = (size_t)np * v.slot + 3 * align_up((size_t)ndb, 64) * sizeof(float);
   return v;
 }
 
-TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim, bool indexed = false) {
+// Shapes the screened search serves (option topk_screen: 0 = never, 1 = wherever the shape allows, -1 (default) = where it
+// pays: >= 256 queries against >= 16 384 rows of >= 4096 columns): the h3 score panels' shapes with k <= 128, rows the re-scoring kernel holds
+// in registers, and a score buffer of at most 12 GiB (fewer columns per range for more queries)
+int64_t screen_cols(int64_t nq, int64_t ndb, int64_t dim, int64_t k, bool h3) {
+  const int64_t mode = option(OPT_TOPK_SCREEN);
+  if (!h3 || mode == 0 || k > SCREEN_KMAX || k <= 0 || !screen_rescore_supported(dim) || nq <= 0 || ndb <= 0) return 0;
+  if (mode < 0 && !(nq >= 256 && ndb >= 16384 && dim >= 4096)) return 0;
+  const int64_t panel = std::min(H3_PANEL, h3_rows_limit(dim));
+  int64_t cols = std::min<int64_t>(SCREEN_COLS, (ndb + panel - 1) / panel * panel);
+  const int64_t fit = (int64_t)(SCREEN_SBUF_MAX / 4) / nq / panel * panel;
+  cols = std::min(cols, fit);
+  return cols >= panel ? cols : 0;
+}
+
+TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim, bool indexed = false, int64_t k = 0) {
   Arena a(ws, cap);
   TopkWs w;
   const bool h3 = indexed || h3_scores(nq, ndb, dim);
@@ -333,6 +358,18 @@ TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim, bool in
   const bool few = !indexed && few_queries(nq, dim);
   w.part = a.take<float>(few ? (size_t)SPLITK_MAX * panel * 64 : 1);
   w.rsq_part = a.take<float>(few ? (size_t)SPLITK_MAX * panel : 1);
+  w.sc_cols = screen_cols(nq, ndb, dim, k, h3);
+  const bool sc = w.sc_cols > 0;
+  w.sbuf = a.take<float>(sc ? (size_t)nq * w.sc_cols : 1);
+  w.scr_v = a.take<float>(sc ? (size_t)nq * k : 1);
+  w.scr_i = a.take<long long>(sc ? (size_t)nq * k : 1);
+  w.margin = a.take<float>(sc ? (size_t)nq : 1);
+  w.cand = a.take<int>(sc ? (size_t)nq * SCREEN_CMAX : 1);
+  w.cand_v = a.take<float>(sc ? (size_t)nq * SCREEN_CMAX : 1);
+  w.count = a.take<int>(sc ? (size_t)nq : 1);
+  w.rho_q = a.take<float>(sc ? (size_t)nq : 1);
+  w.rho_d = a.take<float>(sc && !indexed ? (size_t)std::max<int64_t>(ndb, 1) : 1);
+  w.overflow = a.take<int>(4);                            // [0] overflow flag, [1] bits of the largest database rho
   w.bytes = a.off;
   return w;
 }
@@ -345,8 +382,7 @@ using namespace anyloc;
 extern "C" {
 
 size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k) {
-  (void)k;
-  return carve(nullptr, 0, nq, ndb, dim).bytes + 256;
+  return carve(nullptr, 0, nq, ndb, dim, false, k).bytes + 256;
 }
 
 }  // extern "C"
@@ -355,7 +391,7 @@ size_t anyloc_topk_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t
 // on the fp16 score panels
 static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t ndb, int64_t dim, int64_t k, int metric,
                      unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace, size_t workspace_bytes,
-                     const void* index, hipStream_t stream) {
+                     const void* index, hipStream_t stream, bool allow_screen = true) {
   ANYLOC_CHECK_ARG(nq >= 0 && ndb >= 0, "topk: negative size");
   if (nq == 0 || k == 0) return ANYLOC_OK;
   ANYLOC_CHECK_ARG(queries && dist && idx, "topk: null pointer");
@@ -367,7 +403,7 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
   ANYLOC_CHECK_ARG(dim >= 4 && dim % 4 == 0, "topk: dim %lld must be a positive multiple of 4", (long long)dim);
   ANYLOC_CHECK_ARG(nq < (1ll << 31), "topk: too many queries");
   ANYLOC_CHECK_ARG((flags & ~ANYLOC_TOPK_NORMALIZE_DB) == 0, "topk: unknown flags %u", flags);
-  TopkWs w = carve(workspace, workspace_bytes, nq, ndb, dim, indexed);
+  TopkWs w = carve(workspace, workspace_bytes, nq, ndb, dim, indexed, k);
   const bool norm_db = (flags & ANYLOC_TOPK_NORMALIZE_DB) != 0;
   const bool few = !indexed && few_queries(nq, dim);
   const bool h3 = indexed || h3_scores(nq, ndb, dim);
@@ -382,7 +418,12 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
   const size_t lds = 16 * (k2 + CAP) + 12 * k2 + 16;      // 37 KiB at k = 20: four blocks per CU
   static DynLds dyn_lds_once;
   ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(topk_merge_kernel), (int)(16 * (KMAX + CAP) + 12 * KMAX + 16)));
-  if (metric == 1) {
+  // screened search (scores_screen.hip): the panels are scored on the leading fp16 planes alone, the rows their error bound
+  // cannot rule out are re-scored exactly from the fp32 rows -- needs those rows (a prepared index WITH its rows:
+  // anyloc_topk_search_index_rows) and database rows that count with norm 1 (ANYLOC_TOPK_NORMALIZE_DB: the bound of a query is
+  // then one number)
+  const bool screen = allow_screen && h3 && w.sc_cols > 0 && norm_db && db != nullptr && ndb > 0;
+  if (metric == 1 || screen) {
     hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)nq), dim3(256), 0, stream, queries, dim, w.qn);
     ANYLOC_TRY(launch_status("rownorm_sq_kernel(q)"));
   }
@@ -412,6 +453,74 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
       const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
       ANYLOC_TRY(split_h2_wide(queries + q0 * dim, dim, qc, dim, w.qimg + c * h2_bytes(w.q_chunk, dim), w.qinv + q0, nullptr, stream));
     }
+  if (screen) {
+    const int64_t K16 = dim / 16;
+    const int64_t KC16 = 1536;                               // k-blocks per accumulated chunk (the bound's accumulation term)
+    const int nchunks = (int)((K16 + KC16 - 1) / KC16);
+    ANYLOC_HIP(hipMemsetAsync(w.overflow, 0, 2 * sizeof(int), stream));
+    unsigned* rho_max = reinterpret_cast<unsigned*>(w.overflow + 1);
+    // the queries' relative residual norms, from the residual planes of their images
+    for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
+      const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
+      ANYLOC_TRY(screen_resid(w.qimg + c * h2_bytes(w.q_chunk, dim), qc, (int)K16, qc, w.qinv + q0, w.qn + q0, w.rho_q + q0, nullptr, stream));
+    }
+    int first_exact = 1;
+    for (int64_t s0 = 0; s0 < ndb; s0 += w.sc_cols) {
+      const int64_t sn = std::min<int64_t>(w.sc_cols, ndb - s0);
+      int first_scr = 1;
+      for (int64_t c0 = s0; c0 < s0 + sn; c0 += PANEL_ROWS) {
+        const int64_t pc = std::min<int64_t>(PANEL_ROWS, s0 + sn - c0);
+        const unsigned char* dimg = w.dimg;
+        const float* dinv = w.dinv;
+        const float* dss = w.dss + c0;
+        if (indexed) {
+          dimg = iv.img + (size_t)(c0 / iv.panel) * iv.slot;
+          dinv = iv.dinv + c0;
+          dss = iv.dss + c0;
+        } else {
+          ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, w.dss + c0, stream));
+          ANYLOC_TRY(screen_resid(w.dimg, pc, (int)K16, pc, w.dinv, w.dss + c0, w.rho_d + c0, rho_max, stream));
+        }
+        hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, dss, pc, w.dnorm + c0, w.dn + c0);
+        ANYLOC_TRY(launch_status("dbnorm_kernel"));
+        for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
+          const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
+          for (int64_t kb0 = 0; kb0 < K16; kb0 += KC16) {
+            H3Problem h{};
+            h.A2 = w.qimg + c * h2_bytes(w.q_chunk, dim) + kb0 * (2 * qc * 32); h.RA = qc; h.a_inv = w.qinv + q0;
+            h.W2 = dimg + kb0 * (2 * pc * 32); h.RW = pc; h.w_inv = dinv;
+            h.C = w.sbuf + q0 * sn + (c0 - s0); h.ldc = sn;
+            h.M = qc; h.N = pc; h.K16 = (int)std::min<int64_t>(KC16, K16 - kb0);
+            h.accumulate = kb0 > 0;
+            h.tag = "topk_screen_gemm";
+            ANYLOC_TRY(gemm_screen(h, stream));
+          }
+        }
+        {
+          ProfScope prof("topk_merge", stream, 0.0, 4.0 * nq * pc);
+          hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.sbuf + (c0 - s0), sn, pc, index_base + c0,
+                             (int)k, metric, w.qn, w.dn + c0, w.dnorm + c0, w.scr_v, w.scr_i, first_scr);
+          ANYLOC_TRY(launch_status("topk_merge_kernel"));
+        }
+        first_scr = 0;
+      }
+      if (indexed) ANYLOC_TRY(screen_rho_max(iv.drho + s0, sn, rho_max, stream));
+      ANYLOC_TRY(screen_margins(w.qn, w.rho_q, rho_max, nq, metric, screen_accum((int)std::min(KC16, K16), nchunks), w.margin, stream));
+      ANYLOC_TRY(screen_compact(w.sbuf, sn, sn, nq, (int)k, metric, w.qn, w.dn + s0, w.dnorm + s0, w.scr_v, w.margin, SCREEN_CMAX, w.cand,
+                                w.count, w.overflow, stream));
+      ANYLOC_TRY(screen_rescore(queries, db + s0 * dim, dim, nq, SCREEN_CMAX, w.cand, w.count, metric, w.qn, w.dn + s0, w.dnorm + s0,
+                                w.cand_v, stream));
+      ANYLOC_TRY(screen_select(w.cand, w.cand_v, w.count, SCREEN_CMAX, index_base + s0, nq, (int)k, dist, idx, first_exact, stream));
+      first_exact = 0;
+    }
+    int over = 0;
+    ANYLOC_HIP(hipMemcpyAsync(&over, w.overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ANYLOC_HIP(hipStreamSynchronize(stream));
+    if (over)   // some query has more candidates than SCREEN_CMAX inside its bound (near-duplicate rows): the unscreened search
+      return topk_impl(queries, nq, db, ndb, dim, k, metric, flags, index_base, dist, idx, workspace, workspace_bytes, index, stream, false);
+    hipLaunchKernelGGL(topk_finish_kernel, dim3((unsigned)((nq * k + 255) / 256)), dim3(256), 0, stream, dist, idx_ll, nq * k, metric);
+    return launch_status("topk_finish_kernel");
+  }
   for (int64_t c0 = 0; c0 < ndb; c0 += PANEL_ROWS) {
     const int64_t pc = std::min<int64_t>(PANEL_ROWS, ndb - c0);
     GemmProblem g{};
@@ -541,13 +650,13 @@ int anyloc_topk_index_build(const float* db, int64_t ndb, int64_t dim, void* ind
   for (int64_t c0 = 0; c0 < ndb; c0 += iv.panel) {
     const int64_t pc = std::min<int64_t>(iv.panel, ndb - c0);
     ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, iv.img + (size_t)(c0 / iv.panel) * iv.slot, iv.dinv + c0, iv.dss + c0, stream));
+    ANYLOC_TRY(screen_resid(iv.img + (size_t)(c0 / iv.panel) * iv.slot, pc, (int)(dim / 16), pc, iv.dinv + c0, iv.dss + c0, iv.drho + c0, nullptr, stream));
   }
   return ANYLOC_OK;
 }
 
 size_t anyloc_topk_index_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, int64_t k) {
-  (void)k;
-  return index_supported(ndb, dim) ? carve(nullptr, 0, nq, ndb, dim, true).bytes + 256 : 0;
+  return index_supported(ndb, dim) ? carve(nullptr, 0, nq, ndb, dim, true, k).bytes + 256 : 0;
 }
 
 int anyloc_topk_search_index(const float* queries, int64_t nq, const void* index, int64_t ndb, int64_t dim, int64_t k, int metric,
@@ -555,6 +664,14 @@ int anyloc_topk_search_index(const float* queries, int64_t nq, const void* index
                              size_t workspace_bytes, void* stream) {
   ANYLOC_CHECK_ARG(index && index_supported(ndb, dim), "topk_search_index: no index / shape not served by the fp16 score panels");
   return topk_impl(queries, nq, nullptr, ndb, dim, k, metric, flags, index_base, dist, idx, workspace, workspace_bytes, index,
+                   static_cast<hipStream_t>(stream));
+}
+
+int anyloc_topk_search_index_rows(const float* queries, int64_t nq, const float* db, const void* index, int64_t ndb, int64_t dim,
+                                  int64_t k, int metric, unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  ANYLOC_CHECK_ARG(index && index_supported(ndb, dim), "topk_search_index_rows: no index / shape not served by the fp16 score panels");
+  return topk_impl(queries, nq, db, ndb, dim, k, metric, flags, index_base, dist, idx, workspace, workspace_bytes, index,
                    static_cast<hipStream_t>(stream));
 }
 

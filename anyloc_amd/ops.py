@@ -460,10 +460,16 @@ def topk_index_build(db):
     return index
 
 
-def topk_indexed(queries, index, ndb, k, metric="ip", index_base=0, normalize_db=False):
-    """``topk`` against a database prepared by ``topk_index_build`` (same results; the fp32 rows are not read)."""
+def topk_indexed(queries, index, ndb, k, metric="ip", index_base=0, normalize_db=False, db=None):
+    """``topk`` against a database prepared by ``topk_index_build`` (same results; the fp32 rows are not read).  ``db``: the
+    fp32 rows the index was built from -- with them the screened search (option ``topk_screen``) can re-score its candidates."""
     _need_cuda(queries, index)
     queries = _f32c(queries)
+    if db is not None:
+        _need_cuda(db)
+        db = _f32c(db)
+        if tuple(db.shape) != (int(ndb), queries.shape[1]):
+            raise ValueError(f"topk_indexed: db {tuple(db.shape)} is not the [{ndb}, {queries.shape[1]}] database of the index")
     if not 1 <= int(k) <= 1024:
         raise ValueError(f"k={k} outside [1, 1024] (candidate lists are merged in LDS)")
     nq, dim = queries.shape
@@ -471,10 +477,11 @@ def topk_indexed(queries, index, ndb, k, metric="ip", index_base=0, normalize_db
     idx = torch.empty(nq, k, dtype=torch.int64, device=queries.device)
     lib = _lib.load()
     ws = _lib.workspace(lib.anyloc_topk_index_workspace_bytes(nq, ndb, dim, k), queries.device, "topk")
-    _lib.check(lib.anyloc_topk_search_index(_lib.ptr(queries), nq, _lib.ptr(index), int(ndb), dim, k,
-                                            0 if metric == "ip" else 1, TOPK_NORMALIZE_DB if normalize_db else 0, index_base,
-                                            _lib.ptr(dist), _lib.ptr(idx), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-               "anyloc_topk_search_index")
+    _lib.check(lib.anyloc_topk_search_index_rows(_lib.ptr(queries), nq, _lib.ptr(db) if db is not None else None, _lib.ptr(index),
+                                                 int(ndb), dim, k, 0 if metric == "ip" else 1,
+                                                 TOPK_NORMALIZE_DB if normalize_db else 0, index_base, _lib.ptr(dist), _lib.ptr(idx),
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+               "anyloc_topk_search_index_rows")
     return dist, idx
 
 

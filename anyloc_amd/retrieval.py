@@ -77,7 +77,7 @@ class FlatIndex:
         metric = "ip" if self.method == "cosine" else "l2"
         if self.planes is not None and (self.db is None or
                                         _lib.load().anyloc_topk_path(int(qu_d.shape[0]), self.ntotal, self.dim) == 2):
-            return ops.topk_indexed(qu_d, self.planes, self.ntotal, int(k), metric, normalize_db=self.norm_descs)
+            return ops.topk_indexed(qu_d, self.planes, self.ntotal, int(k), metric, normalize_db=self.norm_descs, db=self.db)
         return ops.topk(qu_d, self.db, int(k), metric, normalize_db=self.norm_descs)
 
 

@@ -54,6 +54,8 @@ def roofline_of(prof, gemm, value_per_gpu, steps):
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = dom["ms"] / dom["calls"]
     achieved = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
+    # screened search (csrc/scores_screen.hip): the dominant kernel runs ONE fp16 product per k (peak 2500); unscreened: three (2500 / 3)
+    dom_peak = PEAK_BF16_MFMA_TFLOPS if dom_name == "topk_screen_gemm" else PEAK_BF16_MFMA_TFLOPS / 3
     gemm_ms = sum(v["ms"] for k, v in prof.items() if k.endswith("_gemm"))
     gemm_fl = sum(v["flops"] for k, v in prof.items() if k.endswith("_gemm"))
     kern_ms = sum(v["ms"] for v in prof.values())
@@ -400,6 +402,8 @@ def main_config3(args):
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = dom["ms"] / dom["calls"]
     achieved = dom["flops"] / dom["calls"] / (avg_ms * 1e-3) / 1e12
+    # screened search (csrc/scores_screen.hip): the dominant kernel runs ONE fp16 product per k (peak 2500); unscreened: three (2500 / 3)
+    dom_peak = PEAK_BF16_MFMA_TFLOPS if dom_name == "topk_screen_gemm" else PEAK_BF16_MFMA_TFLOPS / 3
     out = {
         "metric": f"queries/sec ({NQ} query VLADs x database sharded {NSHARD} rows per GPU, top-20)",
         "value": round(steps * NQ / elapsed, 3), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warm,
@@ -413,10 +417,12 @@ def main_config3(args):
         "planted_neighbours_found": planted_ok, "setup_s": round(t_setup, 1),
         "rccl": rccl_record(dist, world, legs, elapsed / steps * 1e3, legs_all,
                             overlapped=db.has_planes and world > 1 and len(set(q_counts)) == 1),
-        "dtype_note": "scores: operands as power-of-two-scaled two-term fp16 splits (22 bits), 3 fp16 MFMA products, fp32 accumulate "
-                      "in K chunks of 8192; norms, merge and distances in fp32",
-        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
-                     "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+        "dtype_note": "screened search: every panel scored on the leading fp16 planes of the power-of-two-scaled two-term splits (one "
+                      "fp16 MFMA product per k, fp32 accumulate) under a proven bound, the rows inside the bound re-scored from the fp32 "
+                      "rows with float64 sums; option topk_screen = 0: three fp16 products per k for every row (rounds 3-5)",
+        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": round(dom_peak, 1),
+                     "unit": "TFLOP/s", "frac": round(achieved / dom_peak, 4),
+                     "job_algorithmic_tflops": round(2.0 * NQ * NSHARD * KC * D * steps / elapsed / 1e12, 1),
                      "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(avg_ms, 4),
                      "launches": dom["calls"], "traffic": None,
                      "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in
@@ -803,6 +809,9 @@ def flat_evidence(out):
     put("kmeans_frac", (st.get("kmeans_5Mx1536") or {}).get("frac"))
     put("config3_shard_frac", (st.get("config3_shard") or {}).get("frac"))
     put("config3_shard_ms", (st.get("config3_shard") or {}).get("ms"), 2)
+    put("config3_shard_ms_unscreened", (st.get("config3_shard") or {}).get("ms_unscreened"), 2)
+    put("config3_shard_speedup_vs_unscreened", (st.get("config3_shard") or {}).get("speedup_vs_unscreened"), 3)
+    put("config3_shard_queries_per_s", (st.get("config3_shard") or {}).get("queries_per_s"), 1)
     put("config3_whole_db_s", (st.get("config3_whole_db") or {}).get("seconds_per_retrieval"), 3)
     put("vitl_518_images_per_s", (st.get("vitl_518_2taps") or {}).get("images_per_s"), 1)
     put("config2_full_job_s", (st.get("config2_full_job") or {}).get("seconds"), 2)
@@ -1249,22 +1258,49 @@ def stage_config3_shard(dev, check):
     t_build = time.perf_counter() - t0
     el, (d, i), kern = _timed(lambda: index.search(qu, TOPK), iters=2, warm=1)
     same_lists = bool(torch.equal(i, i1) and torch.equal(d, d1))
+    screened = "topk_screen_gemm" in kern
+    # round 6: the default search is SCREENED (csrc/scores_screen.hip: leading-plane score panels under a proven bound + float64
+    # re-scoring of the rows inside it); the three-product panels of rounds 3-5 timed next to it on the same index
+    with ops.options(topk_screen=0):
+        el_u, (d_u, i_u), kern_u = _timed(lambda: index.search(qu, TOPK), iters=1, warm=1)
+    lists_differ = int((i_u != i).sum())
+    dist_diff = float((d_u - d).abs().max())
     del index
+    # float64 check of the screened lists: 32 queries against the whole shard (the products in row blocks: no float64 copy of it)
+    sel = torch.arange(0, nq, nq // 32, device=dev)[:32]
+    qn64 = torch.nn.functional.normalize(qu[sel].double())
+    s64 = torch.empty(len(sel), ndb, dtype=torch.float64, device=dev)
+    for r0 in range(0, ndb, 8192):
+        s64[:, r0:r0 + 8192] = qn64 @ torch.nn.functional.normalize(db[r0:r0 + 8192].double()).t()
+    o64 = torch.sort(s64, dim=1, descending=True, stable=True)
+    got64 = torch.gather(s64, 1, i[sel])
+    f64_mism = i[sel] != o64.indices[:, :TOPK]
+    f64_ok = bool((not f64_mism.any()) or float((got64[f64_mism] - o64.values[:, :TOPK][f64_mism]).abs().max()) <= 3e-6)
+    f64_err = float((d[sel].double() - got64).abs().max())
+    del s64, o64, qn64
     flops = 2.0 * nq * ndb * dv
     planted = bool((i[:64, 0] == rows).all()) and same_lists
+    peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_BF16_MFMA_TFLOPS / 3
     res = {"workload": "BASELINE.json configs[2], one shard: 10k queries x 125k rows x 49152-d, top-20 (cosine, normalise inside); "
                        "`ms` / `frac`: a retrieval against the RESIDENT shard (operand images prepared once: retrieval.FlatIndex = "
-                       "faiss index.add), `ms_one_shot`: index.add + search in one call, as get_top_k_recall does",
+                       "faiss index.add), `ms_one_shot`: index.add + search in one call, as get_top_k_recall does; `ms_unscreened`: the "
+                       "three-product score panels of rounds 3-5 on the same index (option topk_screen = 0)",
            "ms": round(el * 1e3, 2), "ms_one_shot": round(el1 * 1e3, 2), "index_build_ms": round(t_build * 1e3, 2),
-           "frac_one_shot": round(flops / el1 / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "kernels_ms_one_shot": kern1,
+           "ms_unscreened": round(el_u * 1e3, 2), "speedup_vs_unscreened": round(el_u / el, 3), "screened": screened,
+           "frac_unscreened_of_peak_over_3": round(flops / el_u / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+           "screened_vs_unscreened": {"indices_that_differ": lists_differ, "of": int(i.numel()), "max_abs_distance_difference": dist_diff},
+           "float64_check": {"queries": int(len(sel)), "ok": f64_ok, "index_mismatches": int(f64_mism.sum()), "max_abs_distance_error": f64_err},
+           "kernels_ms_one_shot": kern1, "kernels_ms_unscreened": kern_u,
            "resident_lists_equal_one_shot": same_lists,
            "queries_per_s": round(nq / el, 1), "bound": "mfma", "achieved": round(flops / el / 1e12, 2),
-           "unit": "TFLOP/s (algorithmic, fp32-equivalent)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
-           "frac": round(flops / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
-           "peak_note": "the score panels run on the two-term fp16 GEMM: 3 fp16 products per fp32-accurate product, dense 16-bit "
-                        "peak 2500 / 3 = 833.3; `vs_fp32_mfma_peak` = achieved / 157.3 (the roofline of the round-2 fp32-MFMA panels)",
+           "unit": "TFLOP/s (algorithmic, fp32-equivalent)", "peak": round(peak, 1),
+           "frac": round(flops / el / 1e12 / peak, 4),
+           "peak_note": "screened search: ONE fp16 matrix-core product per k on the leading planes (dense 16-bit peak 2500) + an exact "
+                        "re-scoring of the rows inside the bound; `frac` = algorithmic flops / time / 2500.  Rounds 3-5 (`ms_unscreened`): "
+                        "three products per k, priced against 2500 / 3 = 833.3 (`frac_unscreened_of_peak_over_3`); "
+                        "`vs_fp32_mfma_peak` = achieved / 157.3 (the roofline of the round-2 fp32-MFMA panels)",
            "vs_fp32_mfma_peak": round(flops / el / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-           "kernels_ms": kern, "planted_neighbours_found": planted, "oracle_ok": None}
+           "kernels_ms": kern, "planted_neighbours_found": planted, "oracle_ok": bool(planted and f64_ok) if screened else None}
     if check:
         # the many-query panel path on a slice the CPU can score: 96 queries x 3000 rows vs the flat-index restatement
         from oracle import faiss_flat
@@ -1273,7 +1309,7 @@ def stage_config3_shard(dev, check):
         d_r, i_r = faiss_flat.flat_search(torch.nn.functional.normalize(qs.cpu()), torch.nn.functional.normalize(dbs.cpu()), TOPK)
         same = bool(torch.equal(i_g.cpu(), i_r))
         derr = float((d_g.cpu() - d_r).abs().max())
-        res.update({"oracle_ok": bool(planted and same and derr <= 3e-6), "oracle_indices_equal": same, "oracle_dist_err": derr})
+        res.update({"oracle_ok": bool(planted and same and derr <= 3e-6 and f64_ok), "oracle_indices_equal": same, "oracle_dist_err": derr})
     del db, qu
     torch.cuda.empty_cache()
     return res
@@ -1408,16 +1444,24 @@ def stage_config3_whole_db(dev, nq=10000, ndb=1_000_000):
     t_gen = time.perf_counter() - t0
     retrieval.search(db[:8192], qu[:64], TOPK)                   # warm-up of the kernels / workspaces on a small panel
     torch.cuda.synchronize()
+    ops.profile_enable(True)                                     # (a handful of scopes per retrieval: which kernels scored it)
+    ops.profile_reset()
     t0 = time.perf_counter()
     d, i = retrieval.search(db, qu, TOPK)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    ops.profile_enable(False)
+    kern = {k: round(v["ms"], 2) for k, v in sorted(ops.profile_dump().items(), key=lambda kv: -kv[1]["ms"])}
+    screened = "topk_screen_gemm" in kern and "topk_scores_gemm" not in kern
+    peak = PEAK_BF16_MFMA_TFLOPS if screened else PEAK_BF16_MFMA_TFLOPS / 3
     planted = bool((i[:64, 0] == rows).all())
     flops = 2.0 * nq * ndb * dv
     res = {"workload": f"BASELINE.json configs[2] WHOLE on one GPU: {nq} queries x {ndb} rows x {dv}-d resident in HBM ({ndb * dv * 4 / 1e9:.1f} GB), top-{TOPK}",
            "seconds_per_retrieval": round(el, 3), "queries_per_s": round(nq / el, 1), "generate_db_s": round(t_gen, 1), "bound": "mfma",
-           "achieved": round(flops / el / 1e12, 1), "unit": "TFLOP/s (algorithmic, fp32-equivalent)", "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
-           "frac": round(flops / el / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "planted_neighbours_found": planted, "oracle_ok": planted}
+           "achieved": round(flops / el / 1e12, 1), "unit": "TFLOP/s (algorithmic, fp32-equivalent)", "peak": round(peak, 1),
+           "frac": round(flops / el / 1e12 / peak, 4), "screened": screened, "kernels_ms": kern,
+           "peak_note": "screened search (one fp16 product per k + exact re-scoring): dense 16-bit peak 2500; unscreened: 2500 / 3",
+           "planted_neighbours_found": planted, "oracle_ok": planted}
     del db, qu, d, i
     _lib.release_workspaces()
     torch.cuda.empty_cache()

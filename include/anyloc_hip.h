@@ -70,6 +70,9 @@ const char* anyloc_last_error(void);
  *                                     chain of key tiles; partial sums meet in LDS), 1 = none, 0 = 2 when all workgroups are resident
  *   vlad_parts (0 = auto) vlad_two_pass (0) vlad_fused_v (0) kmeans_fused_v (0)
  *                                     which VLAD / k-means kernel serves a call
+ *   topk_screen (-1)                  many queries against long rows: the screened search described at anyloc_topk_search_index_rows,
+ *                                     -1 = where it pays (>= 256 queries, >= 16 384 rows, dim >= 4096), 1 = wherever the shape allows,
+ *                                     0 = never (every panel on the three-product scores)
  *   h3_ln_lead (0)                    batched calls (>= 64 tile rows of 128 tokens): 1 = LayerNorm 1 / 2 run as LEAD workgroups of 16 rows
  *                                     interleaved with the tiles of the qkv / fc1 (w12) GEMM's own launch (per XCD: the lead work of the next
  *                                     tile-row group sits among the tiles of the current one; write-through stores, one ticket per tile row);
@@ -362,6 +365,18 @@ size_t anyloc_topk_index_workspace_bytes(int64_t nq, int64_t ndb, int64_t dim, i
 int anyloc_topk_search_index(const float* queries, int64_t nq, const void* index, int64_t ndb, int64_t dim, int64_t k,
                              int metric, unsigned flags, int64_t index_base, float* dist, int64_t* idx, void* workspace,
                              size_t workspace_bytes, void* stream);
+/* ABI 9: the same search with the database's fp32 rows next to the prepared index (db: [ndb, dim], the rows the index was built
+ * from).  With the rows at hand the SCREENED search can run (option topk_screen, csrc/scores_screen.hip; anyloc_topk runs it too):
+ * every panel is scored on the LEADING fp16 planes alone (one matrix-core product per k instead of three) under a proven bound
+ * |s - s~| <= eps |q| |d|, the k-th best screened value of a query minus twice its bound is a threshold no row of the true list can
+ * fall below, and the few tens of rows above it are re-scored from the fp32 rows with float64 sums and ranked (value, then lower
+ * index).  Needs ANYLOC_TOPK_NORMALIZE_DB (database rows count with norm 1: one bound per query), k <= 128, dim <= 49 152; a query
+ * with more than 512 rows inside its bound makes the call run the unscreened search instead (one 4-byte read-back per call decides).
+ * Lists: the rows of the exact search; distances within 1e-6 of it (more accurate, not bit-identical).  db == NULL: as
+ * anyloc_topk_search_index. */
+int anyloc_topk_search_index_rows(const float* queries, int64_t nq, const float* db, const void* index, int64_t ndb, int64_t dim,
+                                  int64_t k, int metric, unsigned flags, int64_t index_base, float* dist, int64_t* idx,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- ViT ----
  * DINOv2 ViT forward with early exit at the last tapped layer.

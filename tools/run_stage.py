@@ -29,6 +29,8 @@ def main():
             res = bench.stage_vlad(dev, _Vocab(dev), int(n.split("_")[1].replace("img", "")), check)
         elif n.startswith("vitl_518_2taps"):           # vitl_518_2taps[:batch]
             res = bench.stage_vitl(dev, check, *([int(n.split(":")[1])] if ":" in n else []))
+        elif n == "config3_whole_db":
+            res = bench.stage_config3_whole_db(dev)
         else:
             res = {"kmeans_5Mx1536": bench.stage_kmeans, "config3_shard": bench.stage_config3_shard}[n](dev, check)
         print(json.dumps({n: res, "options": os.environ.get("ANYLOC_OPTIONS", "")}), flush=True)
