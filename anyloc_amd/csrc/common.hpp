@@ -293,6 +293,8 @@ int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2
                   hipStream_t stream);
 // the first half of it alone: inv_scale[row] = 2^-e of the row-scaled split (and the rows' sums of squares when asked)
 int row_scales_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, float* inv_scale, float* row_sumsq, hipStream_t stream);
+int split_h1_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, float* row_sumsq, float* resid_sq,
+                  hipStream_t stream);
 // bound (HOST array of 4 floats) != nullptr: also writes bound_inv[row] = 2^-e for an upper bound of the FFN hidden activation of that row
 // (Cauchy-Schwarz: |fc1 output| <= ||ln(x)||_2 * max_j ||W_j||_2 + max |b|), bound = {gate_norm, gate_bias, val_norm, val_bias}
 int layernorm_h2(const float* x, const float* w, const float* b, int64_t rows, int dim, float eps, void* h2,
@@ -327,6 +329,8 @@ int screen_resid(const unsigned char* img, int64_t R, int K16, int64_t rows, con
                  unsigned* rho_max, hipStream_t stream);
 int gemm_screen(const H3Problem& p, hipStream_t stream);
 int screen_rho_max(const float* rho, int64_t n, unsigned* rho_max, hipStream_t stream);
+int screen_rho_from_resid(const float* resid_sq, const float* inv, const float* ss, int64_t rows, float* rho, unsigned* rho_max,
+                          hipStream_t stream);
 int screen_margins(const float* qn, const float* rho_q, const unsigned* rho_max, int64_t nq, int metric, float accum, float* margin,
                    hipStream_t stream);
 int screen_compact(const float* scores, int64_t ld, int64_t ncols, int64_t nq, int k, int metric, const float* qn, const float* dn,

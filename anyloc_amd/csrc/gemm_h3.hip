@@ -150,6 +150,81 @@ __global__ __launch_bounds__(256) void split_h2_wide_kernel(const float* __restr
   }
 }
 
+// The screened retrieval's quantiser (scores_screen.hip): only the LEADING plane of the image is written (the score panels
+// read nothing else) and the squared norm of what the leading plane leaves out, sum (x 2^e - hi)^2, is added to resid_sq[row]
+// (zeroed by the caller; one atomicAdd per row and workgroup: the sum's rounding varies run to run, which only moves the
+// candidate margin by an ulp -- the re-scored result does not depend on it).  Same staging as split_h2_wide_kernel.
+__global__ __launch_bounds__(256) void split_h1_wide_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
+                                                            unsigned char* __restrict__ out, const float* __restrict__ inv,
+                                                            int64_t R, float* __restrict__ resid_sq) {
+  __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+  __shared__ float rpart[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int c0 = blockIdx.y * WIDE_CHUNKS;
+  const int nchunks = min(WIDE_CHUNKS, (dim + 255) / 256 - c0);
+  const int n4 = dim >> 2;
+  const f32x4* xr[4];
+  float scale[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = min(row0 + wave * 4 + q, rows - 1);
+    xr[q] = reinterpret_cast<const f32x4*>(x + row * ldx);
+    scale[q] = h2_scale_of_inv(inv[row]);
+  }
+  f32x4 cur[4], nxt[4];
+  auto load = [&](int i, f32x4 (&dst)[4]) {
+    const int idx = lane + 64 * (c0 + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = idx < n4 ? xr[q][idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  float rs = 0.f;                                          // this thread's items all belong to row (tid >> 1) & 15
+  load(0, cur);
+  for (int i = 0; i < nchunks; ++i) {
+    if (i + 1 < nchunks) load(i + 1, nxt);
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = cur[q];
+      o[0] *= scale[q]; o[1] *= scale[q]; o[2] *= scale[q]; o[3] *= scale[q];
+      *reinterpret_cast<f32x4*>(&tile[wave * 4 + q][4 * lane]) = o;
+    }
+    __syncthreads();
+    // (k-block, row, half) items of the chunk: 16 rows x 32 = 512 items, two per thread, both of row (tid >> 1) & 15
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int item = tid + 256 * u;
+      const int kbl = item >> 5, r = (item >> 1) & 15, half = item & 1;
+      const int k0 = 256 * (c0 + i) + 16 * kbl + 8 * half;
+      const int64_t row = row0 + r;
+      if (k0 < dim && row < rows) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&tile[r][16 * kbl + 8 * half + 4]);
+        hu32x4 ph;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x2 pr;
+          pr[0] = j < 2 ? lo[2 * j] : hi[2 * j - 4];
+          pr[1] = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
+          const f16x2 h = __builtin_convertvector(pr, f16x2);
+          const float d0 = pr[0] - (float)h[0], d1 = pr[1] - (float)h[1];
+          rs += d0 * d0 + d1 * d1;
+          ph[j] = __builtin_bit_cast(unsigned, h);
+        }
+        *reinterpret_cast<hu32x4*>(out + (((int64_t)(k0 >> 4) * 2) * R + row) * 32 + ((half ^ (int)((row >> 3) & 1)) << 4)) = ph;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+  }
+  // threads of one row: lane bits 0 and 5 within a wave, all four waves
+  rs += __shfl_xor(rs, 1, 64);
+  rs += __shfl_xor(rs, 32, 64);
+  if ((lane & 33) == 0) rpart[wave][(lane >> 1) & 15] = rs;
+  __syncthreads();
+  if (tid < 16 && row0 + tid < rows) atomicAdd(resid_sq + row0 + tid, (rpart[0][tid] + rpart[1][tid]) + (rpart[2][tid] + rpart[3][tid]));
+}
+
 // fp32 row-major [rows, K] -> h2 image + inv[row] = 2^-e
 template <int NV>
 __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, int64_t ldx, int dim, int64_t rows,
@@ -272,6 +347,24 @@ int split_h2_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2
   hipLaunchKernelGGL(split_h2_wide_kernel, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, static_cast<unsigned char*>(h2),
                      inv_scale, rows);
   return launch_status("split_h2_wide_kernel");
+}
+
+// split_h2_wide for the screened retrieval: leading plane only + resid_sq[row] += |x 2^e - hi|^2 (scaled units; the caller
+// zeroes resid_sq)
+int split_h1_wide(const float* x, int64_t ldx, int64_t rows, int64_t K, void* h2, float* inv_scale, float* row_sumsq, float* resid_sq,
+                  hipStream_t stream) {
+  ANYLOC_CHECK_ARG(x && h2 && inv_scale && resid_sq && rows > 0 && K > 0 && ldx >= K, "split_h1_wide: bad arguments");
+  ANYLOC_CHECK_ARG(K % 16 == 0 && ldx % 4 == 0 && K < (1ll << 31) && rows < (1ll << 31) && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                   "split_h1_wide: K must be a multiple of 16, rows 16-byte aligned (K=%lld)", (long long)K);
+  ProfScope prof("split_h1_wide", stream, 0.0, 10.0 * rows * K);
+  hipLaunchKernelGGL(row_amax_sq_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, ldx, K, inv_scale, row_sumsq);
+  ANYLOC_TRY(launch_status("row_amax_sq_kernel"));
+  const int chunks = (int)((K + 255) / 256);
+  const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)((chunks + WIDE_CHUNKS - 1) / WIDE_CHUNKS));
+  ANYLOC_CHECK_ARG(grid.y < 65536, "split_h1_wide: K too large");
+  hipLaunchKernelGGL(split_h1_wide_kernel, grid, dim3(256), 0, stream, x, ldx, (int)K, rows, static_cast<unsigned char*>(h2),
+                     inv_scale, rows, resid_sq);
+  return launch_status("split_h1_wide_kernel");
 }
 
 int row_scales_h2(const float* x, int64_t ldx, int64_t rows, int64_t K, float* inv_scale, float* row_sumsq, hipStream_t stream) {

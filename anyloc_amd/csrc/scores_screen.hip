@@ -316,6 +316,20 @@ __global__ __launch_bounds__(256) void plane_resid_kernel(const unsigned char* _
   }
 }
 
+// the same rho from the quantiser's own residual sums (split_h1_wide: sum (x 2^e - hi)^2 per row, the exact residual)
+__global__ void rho_from_resid_kernel(const float* __restrict__ resid_sq, const float* __restrict__ inv, const float* __restrict__ ss,
+                                      int64_t rows, float* __restrict__ rho, unsigned* __restrict__ rho_max) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float r = 0.f;
+  if (i < rows) {
+    if (ss[i] > 0.f) r = sqrtf(resid_sq[i]) * inv[i] / sqrtf(ss[i]) * 1.01f + 1e-9f;
+    r = fminf(r, 1.0f / 2048.0f * 1.01f);
+    rho[i] = r;
+  }
+  const float m = wave_max(r);
+  if (rho_max && (threadIdx.x & 63) == 0) atomicMax(rho_max, __float_as_uint(m));
+}
+
 __global__ void rho_max_kernel(const float* __restrict__ rho, int64_t n, unsigned* __restrict__ rho_max) {
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, rho[i]);
@@ -367,6 +381,12 @@ int gemm_screen(const H3Problem& p_in, hipStream_t stream) {
   ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(&gemm_screen_kernel), SC_LDS));
   hipLaunchKernelGGL(gemm_screen_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * SC_NW), SC_LDS, stream, p, tiles_m, tiles_n);
   return launch_status("gemm_screen_kernel");
+}
+
+int screen_rho_from_resid(const float* resid_sq, const float* inv, const float* ss, int64_t rows, float* rho, unsigned* rho_max,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(rho_from_resid_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, resid_sq, inv, ss, rows, rho, rho_max);
+  return launch_status("rho_from_resid_kernel");
 }
 
 int screen_rho_max(const float* rho, int64_t n, unsigned* rho_max, hipStream_t stream) {

@@ -287,7 +287,7 @@ constexpr int SCREEN_KMAX = 128;
 constexpr int64_t SCREEN_COLS = 131072;   // database columns per range (a multiple of the panel)
 constexpr size_t SCREEN_SBUF_MAX = 12ull << 30;
 struct TopkWs {
-  float *sbuf, *scr_v, *margin, *cand_v, *rho_q, *rho_d;
+  float *sbuf, *scr_v, *margin, *cand_v, *rho_q, *rho_d, *resid;
   long long* scr_i;
   int *cand, *count, *overflow;
   int64_t sc_cols;                 // 0: no screened search for this shape
@@ -369,6 +369,7 @@ TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim, bool in
   w.count = a.take<int>(sc ? (size_t)nq : 1);
   w.rho_q = a.take<float>(sc ? (size_t)nq : 1);
   w.rho_d = a.take<float>(sc && !indexed ? (size_t)std::max<int64_t>(ndb, 1) : 1);
+  w.resid = a.take<float>(sc && !indexed ? (size_t)panel : 1);
   w.overflow = a.take<int>(4);                            // [0] overflow flag, [1] bits of the largest database rho
   w.bytes = a.off;
   return w;
@@ -478,8 +479,10 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
           dinv = iv.dinv + c0;
           dss = iv.dss + c0;
         } else {
-          ANYLOC_TRY(split_h2_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, w.dss + c0, stream));
-          ANYLOC_TRY(screen_resid(w.dimg, pc, (int)K16, pc, w.dinv, w.dss + c0, w.rho_d + c0, rho_max, stream));
+          // leading plane only; the residual norms come out of the quantiser itself
+          ANYLOC_HIP(hipMemsetAsync(w.resid, 0, (size_t)pc * sizeof(float), stream));
+          ANYLOC_TRY(split_h1_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, w.dss + c0, w.resid, stream));
+          ANYLOC_TRY(screen_rho_from_resid(w.resid, w.dinv, w.dss + c0, pc, w.rho_d + c0, rho_max, stream));
         }
         hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, dss, pc, w.dnorm + c0, w.dn + c0);
         ANYLOC_TRY(launch_status("dbnorm_kernel"));

@@ -230,7 +230,9 @@ static void case_kmeans(hipStream_t stream, int64_t n, int64_t D, int64_t K, int
 
 /* ----------------------------------------------------------------- top-k */
 /* indexed != 0: the same search a second time through the database side prepared once (ABI 8: anyloc_topk_index_build +
- * anyloc_topk_search_index -- faiss' index.add apart from index.search), checked against the same oracle lists */
+ * anyloc_topk_search_index -- faiss' index.add apart from index.search), and a third time SCREENED (ABI 9:
+ * anyloc_topk_search_index_rows with the fp32 rows next to the index, option topk_screen = 1: leading-plane scores under a
+ * proven bound + float64 re-scoring of the rows inside it), all checked against the same oracle lists */
 static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, int64_t k, int metric, int64_t base,
                       int indexed, const char* name) {
   float* db = (float*)malloc(sizeof(float) * (size_t)(ndb * dim));
@@ -260,10 +262,21 @@ static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, 
   int ok = 1;
   int64_t swaps = 0, bad = 0, pad_bad = 0;
   double worst = 0.0;
-  for (int pass = 0; pass < (indexed ? 2 : 1); ++pass) {
+  for (int pass = 0; pass < (indexed ? 3 : 1); ++pass) {
   if (pass == 0) {
     ANYLOC_OK_OR_FAIL(anyloc_topk(d_qn, nq, d_db, ndb, dim, k, metric, ANYLOC_TOPK_NORMALIZE_DB, base, d_dist, d_idx, d_ws,
                                   ws_bytes, stream));
+  } else if (pass == 2) {
+    ANYLOC_OK_OR_FAIL(anyloc_set_option("topk_screen", 1));
+    const size_t iw2 = anyloc_topk_index_workspace_bytes(nq, ndb, dim, k);    /* (sized with the option set: the screened buffers) */
+    void* d_iws2 = dev_alloc(iw2);
+    HIP_OK(hipMemsetAsync(d_dist, 0xff, sizeof(float) * (size_t)(nq * k), stream));
+    HIP_OK(hipMemsetAsync(d_idx, 0xff, sizeof(int64_t) * (size_t)(nq * k), stream));
+    ANYLOC_OK_OR_FAIL(anyloc_topk_search_index_rows(d_qn, nq, d_db, d_index, ndb, dim, k, metric, ANYLOC_TOPK_NORMALIZE_DB, base, d_dist,
+                                                    d_idx, d_iws2, iw2, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    hipFree(d_iws2);
+    ANYLOC_OK_OR_FAIL(anyloc_set_option("topk_screen", -1));
   } else {
     const size_t ib = anyloc_topk_index_bytes(ndb, dim), iw = anyloc_topk_index_workspace_bytes(nq, ndb, dim, k);
     if (ib == 0 || iw == 0) { report(name, 0, "anyloc_topk_index_bytes says the shape is not served"); ok = -1; break; }
@@ -300,7 +313,7 @@ static void case_topk(hipStream_t stream, int64_t nq, int64_t ndb, int64_t dim, 
   }                                                          /* (both passes accumulate into the same counters) */
   char detail[240];
   snprintf(detail, sizeof detail, "%lld x %lld x %lld, k=%lld%s: %lld near-tie swaps (%lld outside 3e-6), max |dist err| %.2e, padding %s",
-           (long long)nq, (long long)ndb, (long long)dim, (long long)k, indexed ? " (one-shot + prepared index)" : "", (long long)swaps,
+           (long long)nq, (long long)ndb, (long long)dim, (long long)k, indexed ? " (one-shot + prepared index + screened with rows)" : "", (long long)swaps,
            (long long)bad, worst, pad_bad ? "WRONG" : "ok");
   if (ok >= 0) report(name, ok, detail);                     /* (-1: already reported) */
   hipFree(d_db); hipFree(d_qu); hipFree(d_qn); hipFree(d_dist); hipFree(d_idx); hipFree(d_ws);
