@@ -809,6 +809,7 @@ def flat_evidence(out):
     put("kmeans_frac", (st.get("kmeans_5Mx1536") or {}).get("frac"))
     put("config3_shard_frac", (st.get("config3_shard") or {}).get("frac"))
     put("config3_shard_ms", (st.get("config3_shard") or {}).get("ms"), 2)
+    put("config3_shard_peak_tflops", (st.get("config3_shard") or {}).get("peak"), 1)
     put("config3_shard_ms_unscreened", (st.get("config3_shard") or {}).get("ms_unscreened"), 2)
     put("config3_shard_speedup_vs_unscreened", (st.get("config3_shard") or {}).get("speedup_vs_unscreened"), 3)
     put("config3_shard_queries_per_s", (st.get("config3_shard") or {}).get("queries_per_s"), 1)
