@@ -122,3 +122,70 @@ def test_screened_search_through_the_prepared_index_with_its_rows():
         d3, i3 = retrieval.search(db, qu, 20)
     assert torch.equal(d2, d3) and torch.equal(i2, i3)
     _check(d, i, qu, db, 20, "ip", "indexed")
+
+
+@pytest.mark.parametrize("nq,ndb,dim,k,metric,qscale", [(300, 20000, 4112, 20, "ip", 1.0),       # odd number of k-blocks: a half-empty last pair
+                                                         (300, 20000, 24592, 10, "l2", 1.0),     # two K chunks, the second one k-block long
+                                                         (260, 18000, 8192, 20, "l2", 7.5),      # queries that are NOT unit vectors (L2 against normalised rows)
+                                                         (260, 18000, 8192, 128, "ip", 0.01)])   # the largest k the screened search serves
+def test_screened_search_chunk_edges_and_query_norms(nq, ndb, dim, k, metric, qscale):
+    from anyloc_amd import ops
+    qu, db = _data(nq, ndb, dim, nq + dim)
+    qu = qu * qscale
+    with ops.options(topk_screen=1, topk_h3=1):
+        ops.profile_enable(True); ops.profile_reset()
+        d, i = ops.topk(qu, db, k, metric, normalize_db=True)
+        torch.cuda.synchronize()
+        prof = ops.profile_dump()
+        ops.profile_enable(False)
+    assert "topk_screen_gemm" in prof and "topk_scores_gemm" not in prof, sorted(prof)
+    q64, d64 = qu.double(), torch.nn.functional.normalize(db.double())
+    s = q64 @ d64.t()
+    if metric == "l2":
+        s = -((q64 * q64).sum(1, keepdim=True) + 1.0 - 2.0 * s)
+    o = torch.sort(s, dim=1, descending=True, stable=True)
+    got = torch.gather(s, 1, i)
+    scale = max(1.0, qscale * qscale) if metric == "l2" else max(qscale, 1e-30)
+    tol = (1e-5 if metric == "l2" else 3e-6) * scale
+    val = -d.double() if metric == "l2" else d.double()
+    assert float((val - got).abs().max()) <= tol, float((val - got).abs().max())
+    mism = i != o.indices[:, :k]
+    if bool(mism.any()):
+        assert float((got[mism] - o.values[:, :k][mism]).abs().max()) <= tol
+
+
+def test_screened_search_degenerate_rows():
+    """Zero rows, rows of tiny and huge norm, one dominant element per row (the leading plane carries almost nothing of the
+    rest), a zero query: the bound is measured per row, so none of them may cost a list entry."""
+    from anyloc_amd import ops
+    qu, db = _data(300, 17000, 4096, 77)
+    db[5] = 0.0
+    db[6] *= 1e-18
+    db[7] *= 1e18
+    db[100:400, 17] = 1e4                                  # one element 4 decades above the rest of its row
+    qu[3] = 0.0
+    qu[4, 33] = 50.0
+    qu[4] = torch.nn.functional.normalize(qu[4], dim=0)      # (unit like the others: the bars below are absolute)
+    with ops.options(topk_screen=1, topk_h3=1):
+        d, i = ops.topk(qu, db, 20, "ip", normalize_db=True)
+    assert torch.isfinite(d).all()
+    _check(d, i, qu, db, 20, "ip", "degenerate rows")
+    with ops.options(topk_screen=0, topk_h3=1):
+        d0, i0 = ops.topk(qu, db, 20, "ip", normalize_db=True)
+    assert float((d - d0).abs().max()) <= 3e-6
+
+
+def test_screened_search_more_queries_than_one_operand_image_holds():
+    """11 000 queries of 49 152 columns exceed the 2 GiB addressing range of one query image (10 752 rows): two query chunks."""
+    from anyloc_amd import ops
+    qu, db = _data(11000, 16500, 49152, 3)
+    with ops.options(topk_screen=1):
+        d, i = ops.topk(qu, db, 20, "ip", normalize_db=True)
+    sel = torch.cat([torch.arange(0, 11000, 400, device=DEV), torch.tensor([10751, 10752, 10999], device=DEV)])
+    s = qu[sel].double() @ torch.nn.functional.normalize(db.double()).t()
+    o = torch.sort(s, dim=1, descending=True, stable=True)
+    got = torch.gather(s, 1, i[sel])
+    assert float((d[sel].double() - got).abs().max()) <= 3e-6
+    mism = i[sel] != o.indices[:, :20]
+    if bool(mism.any()):
+        assert float((got[mism] - o.values[:, :20][mism]).abs().max()) <= 3e-6
