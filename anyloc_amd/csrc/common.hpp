@@ -331,8 +331,8 @@ int gemm_screen(const H3Problem& p, hipStream_t stream);
 int screen_rho_max(const float* rho, int64_t n, unsigned* rho_max, hipStream_t stream);
 int screen_rho_from_resid(const float* resid_sq, const float* inv, const float* ss, int64_t rows, float* rho, unsigned* rho_max,
                           hipStream_t stream);
-int screen_margins(const float* qn, const float* rho_q, const unsigned* rho_max, int64_t nq, int metric, float accum, float* margin,
-                   hipStream_t stream);
+int screen_margins(const float* qn, const float* rho_q, const unsigned* rho_max, const unsigned* ss_max, int64_t nq, int metric,
+                   float accum, float* margin, hipStream_t stream);
 int screen_compact(const float* scores, int64_t ld, int64_t ncols, int64_t nq, int k, int metric, const float* qn, const float* dn,
                    const float* dnorm, const float* thr, const float* margin, int cmax, int* cand, int* count, int* overflow,
                    hipStream_t stream);

@@ -341,15 +341,19 @@ __global__ void rho_max_kernel(const float* __restrict__ rho, int64_t n, unsigne
 // (norm_db only: every database row counts with norm 1).  bound = ((rho_q + rho_db + rho_q rho_db) (1 + 2^-10) + accum) |q|,
 // rho_db = the largest relative residual norm among the database rows scored so far (Cauchy-Schwarz on the three neglected
 // terms a_hi r_w + r_a w_hi + r_a r_w), accum = the fp32 accumulation term of screen_accum().
+// ss_max (searches WITHOUT ANYLOC_TOPK_NORMALIZE_DB): bits of the largest raw sum of squares among the database rows scored so
+// far -- the rows then count with their raw norms, and the bound of every column is at most the one of the longest row.
 __global__ void screen_margin_kernel(const float* __restrict__ qn, const float* __restrict__ rho_q, const unsigned* __restrict__ rho_max,
-                                     int64_t nq, int metric, float accum, float* __restrict__ margin) {
+                                     const unsigned* __restrict__ ss_max, int64_t nq, int metric, float accum,
+                                     float* __restrict__ margin) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const float nrm = sqrtf(qn[q]);
+  const float dmax = ss_max ? sqrtf(__uint_as_float(*ss_max)) * 1.0001f : 1.0f;
   const float rd = __uint_as_float(*rho_max), rq = rho_q[q];
   const float eps = (rq + rd + rq * rd) * (1.0f + 1.0f / 1024.0f) + accum;
-  const float d = eps * nrm * (metric ? 2.0f : 1.0f);
-  margin[q] = 2.0f * d * 1.0001f + 1e-6f * (1.0f + (metric ? qn[q] + 1.0f + 2.0f * nrm : nrm));
+  const float d = eps * nrm * dmax * (metric ? 2.0f : 1.0f);
+  margin[q] = 2.0f * d * 1.0001f + 1e-6f * (1.0f + (metric ? qn[q] + dmax * dmax + 2.0f * nrm * dmax : nrm * dmax));
 }
 
 }  // namespace
@@ -394,9 +398,10 @@ int screen_rho_max(const float* rho, int64_t n, unsigned* rho_max, hipStream_t s
   return launch_status("rho_max_kernel");
 }
 
-int screen_margins(const float* qn, const float* rho_q, const unsigned* rho_max, int64_t nq, int metric, float accum, float* margin,
-                   hipStream_t stream) {
-  hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, qn, rho_q, rho_max, nq, metric, accum, margin);
+int screen_margins(const float* qn, const float* rho_q, const unsigned* rho_max, const unsigned* ss_max, int64_t nq, int metric,
+                   float accum, float* margin, hipStream_t stream) {
+  hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, qn, rho_q, rho_max, ss_max, nq, metric,
+                     accum, margin);
   return launch_status("screen_margin_kernel");
 }
 

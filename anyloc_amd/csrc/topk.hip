@@ -370,7 +370,7 @@ TopkWs carve(void* ws, size_t cap, int64_t nq, int64_t ndb, int64_t dim, bool in
   w.rho_q = a.take<float>(sc ? (size_t)nq : 1);
   w.rho_d = a.take<float>(sc && !indexed ? (size_t)std::max<int64_t>(ndb, 1) : 1);
   w.resid = a.take<float>(sc && !indexed ? (size_t)panel : 1);
-  w.overflow = a.take<int>(4);                            // [0] overflow flag, [1] bits of the largest database rho
+  w.overflow = a.take<int>(4);                            // [0] overflow flag, [1] bits of the largest database rho, [2] of the largest raw sum of squares
   w.bytes = a.off;
   return w;
 }
@@ -421,9 +421,9 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
   ANYLOC_TRY(ensure_dyn_lds(dyn_lds_once, reinterpret_cast<const void*>(topk_merge_kernel), (int)(16 * (KMAX + CAP) + 12 * KMAX + 16)));
   // screened search (scores_screen.hip): the panels are scored on the leading fp16 planes alone, the rows their error bound
   // cannot rule out are re-scored exactly from the fp32 rows -- needs those rows (a prepared index WITH its rows:
-  // anyloc_topk_search_index_rows) and database rows that count with norm 1 (ANYLOC_TOPK_NORMALIZE_DB: the bound of a query is
-  // then one number)
-  const bool screen = allow_screen && h3 && w.sc_cols > 0 && norm_db && db != nullptr && ndb > 0;
+  // anyloc_topk_search_index_rows).  The bound of a query is one number: its own norm and residual x the LARGEST row norm the
+  // compared value sees -- 1 with ANYLOC_TOPK_NORMALIZE_DB, the largest raw row norm of the database without it
+  const bool screen = allow_screen && h3 && w.sc_cols > 0 && db != nullptr && ndb > 0;
   if (metric == 1 || screen) {
     hipLaunchKernelGGL(rownorm_sq_kernel, dim3((unsigned)nq), dim3(256), 0, stream, queries, dim, w.qn);
     ANYLOC_TRY(launch_status("rownorm_sq_kernel(q)"));
@@ -458,8 +458,10 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
     const int64_t K16 = dim / 16;
     const int64_t KC16 = 1536;                               // k-blocks per accumulated chunk (the bound's accumulation term)
     const int nchunks = (int)((K16 + KC16 - 1) / KC16);
-    ANYLOC_HIP(hipMemsetAsync(w.overflow, 0, 2 * sizeof(int), stream));
+    ANYLOC_HIP(hipMemsetAsync(w.overflow, 0, 3 * sizeof(int), stream));
     unsigned* rho_max = reinterpret_cast<unsigned*>(w.overflow + 1);
+    unsigned* ss_max = reinterpret_cast<unsigned*>(w.overflow + 2);   // bits of the largest raw sum of squares (searches without NORMALIZE_DB)
+    const float* dnorm_all = norm_db ? w.dnorm : nullptr;             // the divisor array of the compared value, or none
     // the queries' relative residual norms, from the residual planes of their images
     for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
       const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
@@ -484,8 +486,14 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
           ANYLOC_TRY(split_h1_wide(db + c0 * dim, dim, pc, dim, w.dimg, w.dinv, w.dss + c0, w.resid, stream));
           ANYLOC_TRY(screen_rho_from_resid(w.resid, w.dinv, w.dss + c0, pc, w.rho_d + c0, rho_max, stream));
         }
-        hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, dss, pc, w.dnorm + c0, w.dn + c0);
-        ANYLOC_TRY(launch_status("dbnorm_kernel"));
+        if (norm_db) {
+          hipLaunchKernelGGL(dbnorm_kernel, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, stream, dss, pc, w.dnorm + c0, w.dn + c0);
+          ANYLOC_TRY(launch_status("dbnorm_kernel"));
+        } else {
+          // raw rows: the L2 term is the raw sum of squares; the bound scales with the largest raw norm seen so far
+          if (dss != w.dn + c0) ANYLOC_HIP(hipMemcpyAsync(w.dn + c0, dss, (size_t)pc * sizeof(float), hipMemcpyDeviceToDevice, stream));
+          ANYLOC_TRY(screen_rho_max(dss, pc, ss_max, stream));
+        }
         for (int64_t q0 = 0, c = 0; q0 < nq; q0 += w.q_chunk, ++c) {
           const int64_t qc = std::min<int64_t>(w.q_chunk, nq - q0);
           for (int64_t kb0 = 0; kb0 < K16; kb0 += KC16) {
@@ -502,16 +510,18 @@ static int topk_impl(const float* queries, int64_t nq, const float* db, int64_t 
         {
           ProfScope prof("topk_merge", stream, 0.0, 4.0 * nq * pc);
           hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, stream, w.sbuf + (c0 - s0), sn, pc, index_base + c0,
-                             (int)k, metric, w.qn, w.dn + c0, w.dnorm + c0, w.scr_v, w.scr_i, first_scr);
+                             (int)k, metric, w.qn, w.dn + c0, dnorm_all ? dnorm_all + c0 : (const float*)nullptr, w.scr_v, w.scr_i, first_scr);
           ANYLOC_TRY(launch_status("topk_merge_kernel"));
         }
         first_scr = 0;
       }
       if (indexed) ANYLOC_TRY(screen_rho_max(iv.drho + s0, sn, rho_max, stream));
-      ANYLOC_TRY(screen_margins(w.qn, w.rho_q, rho_max, nq, metric, screen_accum((int)std::min(KC16, K16), nchunks), w.margin, stream));
-      ANYLOC_TRY(screen_compact(w.sbuf, sn, sn, nq, (int)k, metric, w.qn, w.dn + s0, w.dnorm + s0, w.scr_v, w.margin, SCREEN_CMAX, w.cand,
+      ANYLOC_TRY(screen_margins(w.qn, w.rho_q, rho_max, norm_db ? nullptr : ss_max, nq, metric,
+                                screen_accum((int)std::min(KC16, K16), nchunks), w.margin, stream));
+      const float* dnorm_s = dnorm_all ? dnorm_all + s0 : nullptr;
+      ANYLOC_TRY(screen_compact(w.sbuf, sn, sn, nq, (int)k, metric, w.qn, w.dn + s0, dnorm_s, w.scr_v, w.margin, SCREEN_CMAX, w.cand,
                                 w.count, w.overflow, stream));
-      ANYLOC_TRY(screen_rescore(queries, db + s0 * dim, dim, nq, SCREEN_CMAX, w.cand, w.count, metric, w.qn, w.dn + s0, w.dnorm + s0,
+      ANYLOC_TRY(screen_rescore(queries, db + s0 * dim, dim, nq, SCREEN_CMAX, w.cand, w.count, metric, w.qn, w.dn + s0, dnorm_s,
                                 w.cand_v, stream));
       ANYLOC_TRY(screen_select(w.cand, w.cand_v, w.count, SCREEN_CMAX, index_base + s0, nq, (int)k, dist, idx, first_exact, stream));
       first_exact = 0;

@@ -370,7 +370,8 @@ int anyloc_topk_search_index(const float* queries, int64_t nq, const void* index
  * every panel is scored on the LEADING fp16 planes alone (one matrix-core product per k instead of three) under a proven bound
  * |s - s~| <= eps |q| |d|, the k-th best screened value of a query minus twice its bound is a threshold no row of the true list can
  * fall below, and the few tens of rows above it are re-scored from the fp32 rows with float64 sums and ranked (value, then lower
- * index).  Needs ANYLOC_TOPK_NORMALIZE_DB (database rows count with norm 1: one bound per query), k <= 128, dim <= 49 152; a query
+ * index).  One bound per query: its norm and measured residual x the largest row norm the compared value sees (1 with
+ * ANYLOC_TOPK_NORMALIZE_DB, the largest raw row norm without it: rows of very different raw norms make it loose).  k <= 128, dim <= 49 152; a query
  * with more than 512 rows inside its bound makes the call run the unscreened search instead (one 4-byte read-back per call decides).
  * Lists: the rows of the exact search; distances within 1e-6 of it (more accurate, not bit-identical).  db == NULL: as
  * anyloc_topk_search_index. */

@@ -189,3 +189,34 @@ def test_screened_search_more_queries_than_one_operand_image_holds():
     mism = i[sel] != o.indices[:, :20]
     if bool(mism.any()):
         assert float((got[mism] - o.values[:, :20][mism]).abs().max()) <= 3e-6
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_screened_search_on_raw_rows(metric):
+    """Without ANYLOC_TOPK_NORMALIZE_DB the rows count with their raw norms (here 0.3 ... 2.3, planted neighbours up to 5.5): the
+    bound of a query scales with the LARGEST raw norm of the database; the lists are those of the float64 search over the raw rows."""
+    from anyloc_amd import ops
+    qu, db = _data(400, 20000, 4096, 21)
+    with ops.options(topk_screen=1, topk_h3=1):
+        ops.profile_enable(True); ops.profile_reset()
+        d, i = ops.topk(qu, db, 20, metric, normalize_db=False)
+        torch.cuda.synchronize()
+        prof = ops.profile_dump()
+        ops.profile_enable(False)
+    assert "topk_screen_gemm" in prof and "topk_scores_gemm" not in prof, sorted(prof)
+    q64, d64 = qu.double(), db.double()
+    s = q64 @ d64.t()
+    if metric == "l2":
+        s = -((q64 * q64).sum(1, keepdim=True) + (d64 * d64).sum(1)[None, :] - 2.0 * s)
+    o = torch.sort(s, dim=1, descending=True, stable=True)
+    got = torch.gather(s, 1, i)
+    val = -d.double() if metric == "l2" else d.double()
+    scale = float(d64.norm(dim=1).max()) ** (2 if metric == "l2" else 1)
+    tol = 3e-6 * scale
+    assert float((val - got).abs().max()) <= tol, (float((val - got).abs().max()), tol)
+    mism = i != o.indices[:, :20]
+    if bool(mism.any()):
+        assert float((got[mism] - o.values[:, :20][mism]).abs().max()) <= tol
+    with ops.options(topk_screen=0, topk_h3=1):
+        d0, i0 = ops.topk(qu, db, 20, metric, normalize_db=False)
+    assert float((d - d0).abs().max()) <= 2 * tol and int((i != i0).sum()) <= int(mism.sum()) + 4
