@@ -220,3 +220,23 @@ def test_screened_search_on_raw_rows(metric):
     with ops.options(topk_screen=0, topk_h3=1):
         d0, i0 = ops.topk(qu, db, 20, metric, normalize_db=False)
     assert float((d - d0).abs().max()) <= 2 * tol and int((i != i0).sum()) <= int(mism.sum()) + 4
+
+
+def test_screened_search_is_reproducible_under_load():
+    """The one-shot quantiser adds its residual sums with atomics (their rounding varies run to run, which can move the candidate
+    margin by an ulp) and the candidate lists are filled in arrival order: neither may reach the result -- ten searches with
+    another stream keeping the chip busy give one set of bits."""
+    from anyloc_amd import ops
+    qu, db = _data(700, 33000, 4096, 31)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    with ops.options(topk_screen=1, topk_h3=1):
+        d0, i0 = ops.topk(qu, db, 20, "ip", normalize_db=True)
+        for rep in range(10):
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    a @ a
+            d, i = ops.topk(qu, db, 20, "ip", normalize_db=True)
+            assert torch.equal(i, i0) and torch.equal(d, d0), rep
+    torch.cuda.synchronize()
+    _check(d0, i0, qu, db, 20, "ip", "under load")
