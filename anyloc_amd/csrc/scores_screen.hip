@@ -359,10 +359,11 @@ __global__ void screen_margin_kernel(const float* __restrict__ qn, const float* 
 }  // namespace
 
 // fp32 accumulation term of the bound, relative to |a| |w|: one accumulator over K16 / 2 matrix-core instructions per chunk
-// (each adds a 32-term partial sum: K16 / 2 + 32 roundings of 2^-24 relative to sum |a_i w_i| <= |a| |w|), one more rounding
-// per chunk added into the panel and two for the descaling
+// (each adds a 32-term partial sum: K16 / 2 + 32 roundings relative to sum |a_i w_i| <= |a| |w|), one more rounding per chunk
+// added into the panel and two for the descaling -- each priced at 2^-23, not 2^-24: the matrix core's internal rounding is not
+// documented as round-to-nearest, and a truncating adder would err by a whole ulp
 float screen_accum(int k16_chunk, int chunks) {
-  return (float)((((double)k16_chunk / 2.0 + 32.0 + 3.0 * chunks) / 16777216.0) * 1.01);
+  return (float)((((double)k16_chunk / 2.0 + 32.0 + 3.0 * chunks) / 8388608.0) * 1.01);
 }
 
 int screen_resid(const unsigned char* img, int64_t R, int K16, int64_t rows, const float* inv, const float* ss, float* rho,
