@@ -118,6 +118,50 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_screened(rank, world, port, out_dir):
+    """The same step at a shape the SCREENED search serves (forced: topk_screen = 1): every rank's shard search scores on the
+    leading planes and re-scores its candidates; the merged lists are checked against a float64 search over the whole database."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from anyloc_amd import ops, retrieval
+        dev = torch.device("cuda", 0)
+        dim = 4096
+        db, qu = _rows(36000, dim, 7), _rows(600, dim, 8)
+        bounds = [0, 17000, 36000]
+        with ops.options(topk_screen=1, topk_h3=1):
+            shard = retrieval.FlatIndex(db[bounds[rank]:bounds[rank + 1]].to(dev), "cosine", planes=True)
+            q_loc = qu[300 * rank:300 * (rank + 1)].to(dev)
+            outs = [retrieval.sharded_search(shard, bounds[rank], q_loc, 20, counts=[300, 300], overlap=ov) for ov in (True, False)]
+            ops.profile_enable(True); ops.profile_reset()
+            retrieval.sharded_search(shard, bounds[rank], q_loc, 20, counts=[300, 300], overlap=True)
+            torch.cuda.synchronize()
+            prof = ops.profile_dump()
+            ops.profile_enable(False)
+        assert "topk_screen_gemm" in prof and "topk_scores_gemm" not in prof, sorted(prof)
+        if rank == 0:
+            s = torch.nn.functional.normalize(qu.to(dev).double()) @ torch.nn.functional.normalize(db.to(dev).double()).t()
+            o = torch.sort(s, dim=1, descending=True, stable=True)
+            for d, i in outs:
+                i_t = torch.as_tensor(i, device=dev)
+                got = torch.gather(s, 1, i_t)
+                assert float((torch.as_tensor(d, device=dev).double() - got).abs().max()) <= 3e-6
+                mism = i_t != o.indices[:, :20]
+                assert (not bool(mism.any())) or float((got[mism] - o.values[:, :20][mism]).abs().max()) <= 3e-6
+            assert np.array_equal(outs[0][1], outs[1][1])
+            open(os.path.join(out_dir, "ok_screened"), "w").write("1")
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_sharded_step_with_the_screened_shard_search(tmp_path):
+    mp.spawn(_worker_screened, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_screened").exists()
+
+
 def test_overlapped_sharded_step_on_a_prepared_shard_two_ranks_one_gpu(tmp_path):
     """The overlapped sharded step (own queries searched while the others' travel, the rest afterwards) on prepared shards with
     the real kernels: two ranks share cuda:0 over gloo; the merged lists are those of one flat search, with and without overlap."""
